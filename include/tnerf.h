@@ -1,0 +1,217 @@
+/*
+ * tnerf.h — C ABI of libtnerf_hip.so: the MI355X (gfx950) TinyNeRF render/train hot path.
+ *
+ * The reference (avihaig/tiny-nerf-pytorch) has no FFI/plugin interface of its own: its hot
+ * path is the Python call surface src/{rays,sampling,encoding,nerf,volume}.py + the step body
+ * and render_one of src/train.py.  Each entry point below names the reference function
+ * (file:line under /root/reference) whose arithmetic it replaces; the Python mirror of that call
+ * surface (tiny-nerf-pytorch_amd/src/{rays,sampling,...}.py) binds these symbols with ctypes.
+ *
+ * Conventions
+ *   - plain C: raw device pointers (tensor.data_ptr()), explicit sizes, scalars; no torch types.
+ *   - return int: 0 = ok, <0 = TNERF_E* (bad argument), >0 = hipError_t of a failed HIP call.
+ *     tnerf_last_error_string() gives a thread-local description.  Nothing throws across the ABI.
+ *   - the CALLER owns all memory (outputs, stashes, workspaces, tables); the library never
+ *     allocates or frees device memory and keeps no mutable global state.
+ *   - every device entry point is asynchronous on the given stream (hipStream_t passed as void*)
+ *     and performs no host synchronisation, so it can be captured into a hipGraph.
+ *   - all tensors are contiguous fp32 unless stated; index tensors are int64.
+ *   - functions marked HOST touch no GPU and may be called without one (unit-tested on CPU).
+ */
+#ifndef TNERF_H
+#define TNERF_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TNERF_ABI_VERSION 1
+
+#define TNERF_OK            0
+#define TNERF_EINVAL       (-1)  /* bad size / NULL pointer / inconsistent arguments        */
+#define TNERF_EUNSUPPORTED (-2)  /* valid in the reference, not built here (see message)    */
+#define TNERF_ESMALL       (-3)  /* caller-provided table/workspace too small               */
+
+typedef void* tnerf_stream_t;    /* hipStream_t */
+
+/* TinyNeRF(in_dim, hidden, depth, skip_at)                       [src/nerf.py:10-27]
+ * skip_at: the input is concatenated after layer index skip_at-1 (cat([h, x]), nerf.py:37-38);
+ * 1 <= skip_at <= depth-1, or 0 for "no skip".  hidden must be 128 or 256; in_dim <= 64. */
+typedef struct tnerf_mlp_desc {
+    int32_t in_dim;
+    int32_t hidden;
+    int32_t depth;
+    int32_t skip_at;
+} tnerf_mlp_desc;
+
+/* Sizes (in elements) of everything the caller must allocate for a model + sample count. */
+typedef struct tnerf_plan_sizes {
+    int64_t n_params;        /* flat fp32 parameter / gradient / Adam-moment buffers          */
+    int64_t packed_floats;   /* MFMA-fragment-ordered copy of the weights (fwd + transposed)  */
+    int64_t stash_floats;    /* activations saved by a training forward, feature-major        */
+    int64_t slab_floats;     /* weight-gradient partial slabs (one per wgrad workgroup)       */
+    int64_t job_ints;        /* wgrad job table (int32)                                       */
+    int64_t reduce_ints;     /* slab -> flat-gradient gather table (int32, 2 per parameter)   */
+    int64_t n_jobs;          /* wgrad workgroups                                              */
+    int64_t stash_row_stride;/* padded sample count Mp (row stride of the stash)              */
+} tnerf_plan_sizes;
+
+/* ---------------------------------------------------------------------------------- misc */
+int         tnerf_version(void);                 /* HOST: TNERF_ABI_VERSION                    */
+const char* tnerf_last_error_string(void);       /* HOST: thread-local, never NULL             */
+
+/* ------------------------------------------------------------------------ host-side tables */
+/* HOST. Depth tables of stratified_samples: t = torch.linspace(0,1,S) as ATen computes it on CPU,
+ * z = near*(1-t) + far*t, and the jitter interval [lo, hi] around each z (mids of neighbours).
+ * Bit-exact with the reference's CPU fp32 arithmetic.            [src/sampling.py:16-23]
+ * out: ztab[3*S] = { z[S] | lo[S] | hi[S] };  t_out[S] (may be NULL). */
+int tnerf_sample_tables(float near, float far, int32_t n_samples, float* ztab, float* t_out);
+
+/* HOST. Offsets (in floats) of the 2*depth+4 parameter tensors inside the flat buffer, in
+ * state_dict order layers.i.weight, layers.i.bias, sigma.0.weight, sigma.0.bias, rgb.0.weight,
+ * rgb.0.bias, plus their (rows, cols).                         [src/nerf.py:18-27]           */
+int64_t tnerf_param_count(const tnerf_mlp_desc* d);
+int     tnerf_param_layout(const tnerf_mlp_desc* d, int64_t* offsets, int64_t* rows, int64_t* cols);
+
+/* HOST. Column pairing of the network input used by the MFMA kernels: step s feeds input column
+ * emap[2*s+0] to lane-half 0 and emap[2*s+1] to lane-half 1 (-1 = zero padding).  For
+ * in_dim = 6L+3 (PositionalEncoding(L, include_input=True), encoding.py:27-33) the pairing is
+ * (sin(2^k x_c), cos(2^k x_c)); otherwise consecutive columns.  n_steps is 20 or 32. */
+int tnerf_input_pairing(int32_t in_dim, int32_t* emap /* [64] */, int32_t* n_steps);
+
+/* HOST. Sizes of the buffers/tables for `n_samples_total` = rays*samples (or rows of x), with the
+ * wgrad work split over `n_cu` compute units (256 on MI355X). */
+int tnerf_plan_sizes_query(const tnerf_mlp_desc* d, int64_t n_samples_total, int32_t n_cu,
+                           tnerf_plan_sizes* out);
+
+/* HOST. Fill the three int32 tables (caller uploads them to the GPU):
+ *   pack_table  [packed_floats]: packed[i] = params[pack_table[i]] (or 0 if < 0)
+ *   job_table   [job_ints]     : one record per wgrad workgroup
+ *   reduce_table[reduce_ints]  : for parameter i: {slab offset of chunk 0, job-class id}       */
+int tnerf_plan_fill(const tnerf_mlp_desc* d, int64_t n_samples_total, int32_t n_cu,
+                    int32_t* pack_table, int32_t* job_table, int32_t* reduce_table);
+
+/* --------------------------------------------------------------------------- stage kernels */
+/* get_rays(H, W, focal, c2w)                                     [src/rays.py:3-33]
+ * c2w: device, 16 floats row-major.  rays_d: [H*W,3] unit directions, flat index row*W+col.
+ * rays_o: [H*W,3] or NULL (the reference returns a stride-0 expand of the translation). */
+int tnerf_get_rays(int32_t H, int32_t W, float focal, const float* c2w,
+                   float* rays_o, float* rays_d, tnerf_stream_t stream);
+
+/* stratified_samples (+ optional PositionalEncoding of the points)
+ *                                      [src/sampling.py:3-28, src/encoding.py:21-33]
+ * ztab: device copy of tnerf_sample_tables' table (3*S).
+ * randomized=0: z = ztab.z;  randomized=1: z = lo + (hi-lo)*u with u = t_rand[r,s] if t_rand != NULL
+ * (parity mode: the caller drew torch.rand) else Philox4x32-10(seed, offset + r*S+s).
+ * Outputs (each may be NULL): z_vals [R,S], pts [R,S,3], enc [R*S, 6L(+3)]. */
+int tnerf_sample_encode_fwd(const float* rays_o, const float* rays_d, int64_t n_rays, int32_t n_samples,
+                            const float* ztab, int32_t randomized, const float* t_rand,
+                            uint64_t seed, uint64_t offset,
+                            float* z_vals, float* pts,
+                            float* enc, int32_t num_freqs, int32_t include_input,
+                            tnerf_stream_t stream);
+
+/* PositionalEncoding.forward on arbitrary points x [n,3] -> out [n, 6L(+3)]   [src/encoding.py:21-33] */
+int tnerf_posenc_fwd(const float* x, int64_t n, int32_t num_freqs, int32_t include_input,
+                     float* out, tnerf_stream_t stream);
+
+/* volume_render forward                                          [src/volume.py:3-44]
+ * rgb [R,S,3], sigma [R,S], z_vals [R,S], rays_d [R,3] -> comp_rgb [R,3], depth [R], acc [R],
+ * weights [R,S] (depth/acc/weights may be NULL).  One ray per wavefront. */
+int tnerf_composite_fwd(const float* rgb, const float* sigma, const float* z_vals, const float* rays_d,
+                        int64_t n_rays, int32_t n_samples, int32_t white_bkgd,
+                        float* comp_rgb, float* depth, float* acc, float* weights,
+                        tnerf_stream_t stream);
+
+/* volume_render backward w.r.t. rgb and sigma (what autograd derives from volume.py:18-42).
+ * Upstream gradients g_comp [R,3], g_depth [R], g_acc [R], g_weights [R,S]; any may be NULL (= 0). */
+int tnerf_composite_bwd(const float* rgb, const float* sigma, const float* z_vals, const float* rays_d,
+                        int64_t n_rays, int32_t n_samples, int32_t white_bkgd,
+                        const float* g_comp, const float* g_depth, const float* g_acc, const float* g_weights,
+                        float* d_rgb, float* d_sigma, tnerf_stream_t stream);
+
+/* ------------------------------------------------------------------------------- MLP (MFMA) */
+/* Re-order the flat parameters into MFMA fragment order: packed[i] = params[pack_table[i]]. */
+int tnerf_mlp_pack(const float* params, const int32_t* pack_table, int64_t packed_floats,
+                   float* packed, tnerf_stream_t stream);
+
+/* TinyNeRF.forward                                               [src/nerf.py:29-41]
+ * x [M,in_dim] -> rgb [M,3] (sigmoid), sigma [M,1] (ReLU).  stash != NULL saves the activations
+ * needed by tnerf_mlp_bwd (row stride stash_row_stride from the plan of M). */
+int tnerf_mlp_fwd(const tnerf_mlp_desc* d, const float* packed, const float* x, int64_t n_rows,
+                  float* rgb, float* sigma, float* stash, int64_t stash_row_stride,
+                  tnerf_stream_t stream);
+
+/* Backward of TinyNeRF.forward w.r.t. all parameters: grads [n_params] is OVERWRITTEN with
+ * dL/dparams for upstream d_rgb [M,3], d_sigma [M,1].  (No gradient w.r.t. x: the reference never
+ * asks for one — pts carry no grad, train.py:114-117.)  Deterministic (slab reduction, no atomics). */
+int tnerf_mlp_bwd(const tnerf_mlp_desc* d, const float* packed, int64_t n_rows,
+                  const float* d_rgb, const float* d_sigma,
+                  float* stash, int64_t stash_row_stride,
+                  const int32_t* job_table, int64_t n_jobs, float* slabs,
+                  const int32_t* reduce_table, float* grads, tnerf_stream_t stream);
+
+/* ----------------------------------------------------------------------------- fused paths */
+/* Body of render_one for a batch of rays: sample -> encode -> MLP -> composite with nothing but
+ * rays in and colours out of HBM.                                [src/train.py:50-56]
+ * randomized / t_rand / seed / offset as in tnerf_sample_encode_fwd.
+ * comp_rgb [R,3]; depth [R], acc [R] may be NULL.  Requires in_dim == 6L+3. */
+int tnerf_render_fused(const tnerf_mlp_desc* d, const float* packed,
+                       const float* rays_o, const float* rays_d, int64_t n_rays, int32_t n_samples,
+                       const float* ztab, int32_t randomized, const float* t_rand,
+                       uint64_t seed, uint64_t offset, int32_t white_bkgd,
+                       float* comp_rgb, float* depth, float* acc, tnerf_stream_t stream);
+
+/* Training forward of the same body (train.py:114-121): also fills `stash`. */
+int tnerf_train_fwd_fused(const tnerf_mlp_desc* d, const float* packed,
+                          const float* rays_o, const float* rays_d, int64_t n_rays, int32_t n_samples,
+                          const float* ztab, int32_t randomized, const float* t_rand,
+                          uint64_t seed, uint64_t offset, int32_t white_bkgd,
+                          float* comp_rgb, float* stash, int64_t stash_row_stride,
+                          tnerf_stream_t stream);
+
+/* Training backward: given g_comp = dL/dcomp_rgb [R,3], overwrite grads [n_params]
+ * (what loss.backward() accumulates, train.py:126).  Same sampling arguments as the forward. */
+int tnerf_train_bwd_fused(const tnerf_mlp_desc* d, const float* packed,
+                          const float* rays_o, const float* rays_d, int64_t n_rays, int32_t n_samples,
+                          const float* ztab, int32_t randomized, const float* t_rand,
+                          uint64_t seed, uint64_t offset, int32_t white_bkgd,
+                          const float* g_comp, float* stash, int64_t stash_row_stride,
+                          const int32_t* job_table, int64_t n_jobs, float* slabs,
+                          const int32_t* reduce_table, float* grads, tnerf_stream_t stream);
+
+/* One whole minibatch step up to (not including) the optimizer (train.py:114-126):
+ * forward, loss = sum((comp-target)^2)/loss_denominator, backward -> grads (overwritten),
+ * loss_out[0] = this batch's loss contribution (device scalar), comp_rgb [R,3].
+ * loss_denominator = 3*R reproduces torch.mean (train.py:122); a ray shard passes the GLOBAL 3*R. */
+int tnerf_train_step_fused(const tnerf_mlp_desc* d, const float* packed,
+                           const float* rays_o, const float* rays_d, const float* target,
+                           int64_t n_rays, int32_t n_samples,
+                           const float* ztab, int32_t randomized, const float* t_rand,
+                           uint64_t seed, uint64_t offset, int32_t white_bkgd, double loss_denominator,
+                           float* comp_rgb, float* g_comp_ws, float* loss_out,
+                           float* stash, int64_t stash_row_stride,
+                           const int32_t* job_table, int64_t n_jobs, float* slabs,
+                           const int32_t* reduce_table, float* grads, tnerf_stream_t stream);
+
+/* torch.optim.Adam(lr, betas, eps, weight_decay=0) on the flat buffers   [src/train.py:80,127]
+ * step = 1-based step count t used for the bias corrections; grad_scale multiplies the gradient
+ * first (1/world_size after an all-reduce SUM of already globally-normalised shards = 1). */
+int tnerf_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                    int64_t n, float lr, float beta1, float beta2, float eps, int64_t step,
+                    float grad_scale, tnerf_stream_t stream);
+
+/* --------------------------------------------------------------------------- RCCL (optional) */
+/* Sum the flat gradient over ranks with RCCL (ncclAllReduce, ncclSum) on `stream`.
+ * `comm` is an ncclComm_t created by tnerf_comm_init_rank.  librccl.so is dlopen'ed on first use. */
+int tnerf_comm_unique_id(void* id128 /* 128 bytes out */);
+int tnerf_comm_init_rank(const void* id128, int32_t n_ranks, int32_t rank, void** comm_out);
+int tnerf_comm_destroy(void* comm);
+int tnerf_allreduce_grads(void* comm, float* grads, int64_t n, tnerf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TNERF_H */

@@ -1,0 +1,305 @@
+"""Host-side logic of libtnerf_hip.so, checked without a GPU:
+  * the C-ABI library loads and exports every symbol declared in include/tnerf.h,
+  * depth tables are bit-exact with torch.linspace / the reference arithmetic,
+  * the MFMA fragment packing table reproduces the MLP when the kernel's data flow is emulated in numpy,
+  * the wgrad job table + slab reduce table reproduce autograd's parameter gradients.
+"""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_golden, golden_params
+from oracle import tnerf_oracle as O
+from tnerf import lib as tl
+
+
+def _desc(in_dim, hidden, depth, skip_at):
+    return tl.MlpDesc(in_dim, hidden, depth, skip_at)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "tnerf.h")).read()
+    declared = set(re.findall(r"\b(tnerf_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"tnerf_mlp_desc", "tnerf_plan_sizes"}
+    assert len(declared) >= 24
+    lib = tl.load()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in tnerf.h but not exported"
+        assert name in tl.SIGNATURES, f"{name} has no ctypes signature"
+    assert lib.tnerf_version() == 1
+    assert tl.last_error() == "ok"
+
+
+def test_error_reporting_no_throw():
+    lib = tl.load()
+    d = _desc(39, 200, 8, 4)
+    assert lib.tnerf_param_count(C.byref(d)) == -1
+    assert "hidden=200" in tl.last_error()
+    with pytest.raises(NotImplementedError):
+        tl.check(tl.EUNSUPPORTED, "x")
+    d = _desc(39, 256, 8, 8)     # skip_at == depth: heads would see hidden+in_dim (reference raises too)
+    assert lib.tnerf_param_count(C.byref(d)) == -1
+
+
+@pytest.mark.parametrize("S", [1, 2, 3, 7, 32, 50, 63, 64, 65, 100, 128, 255, 256, 257])
+@pytest.mark.parametrize("near,far", [(2.0, 6.0), (0.5, 3.25), (0.1, 7.3), (1e-3, 1e3)])
+def test_sample_tables_bitexact_vs_torch(S, near, far):
+    lib = tl.load()
+    ztab = np.empty(3 * S, np.float32); t = np.empty(S, np.float32)
+    assert lib.tnerf_sample_tables(near, far, S, _ptr(ztab), _ptr(t)) == 0
+    tt = torch.linspace(0., 1., steps=S)
+    assert np.array_equal(t, tt.numpy()), "linspace"
+    z = near * (1. - tt) + far * tt
+    assert np.array_equal(ztab[:S], z.numpy()), "z"
+    zz = z.expand(2, S)
+    if S > 1:
+        mids = 0.5 * (zz[:, :-1] + zz[:, 1:])
+        hi = torch.cat([mids, zz[:, -1:]], -1)[0]; lo = torch.cat([zz[:, :1], mids], -1)[0]
+    else:
+        hi = lo = zz[0]
+    assert np.array_equal(ztab[S:2 * S], lo.numpy()) and np.array_equal(ztab[2 * S:], hi.numpy())
+
+
+def test_sample_tables_golden():
+    g = load_golden("sampling")
+    lib = tl.load()
+    for S in (64, 128, 256):
+        ztab = np.empty(3 * S, np.float32); t = np.empty(S, np.float32)
+        lib.tnerf_sample_tables(2.0, 6.0, S, _ptr(ztab), _ptr(t))
+        assert np.array_equal(t, g[f"linspace_{S}"].numpy())
+        assert np.array_equal(ztab[:S], g[f"zbase_{S}"].numpy())
+        # the jittered depths of the fixture follow from the table + the recorded draws, bit for bit
+        u = g[f"u_{S}"].numpy()
+        z = (ztab[S:2 * S] + ((ztab[2 * S:] - ztab[S:2 * S]).astype(np.float32) * u).astype(np.float32)).astype(np.float32)
+        assert np.array_equal(z, g[f"z_rand_{S}"].numpy())
+
+
+def test_param_layout_matches_state_dict_order():
+    lib = tl.load()
+    for cfg in ((39, 256, 8, 4), (63, 128, 4, 2), (39, 128, 3, 0)):
+        d = _desc(*cfg)
+        shapes = O.mlp_shapes(*cfg)
+        n = 2 * cfg[2] + 4
+        off = np.zeros(n, np.int64); rows = np.zeros(n, np.int64); cols = np.zeros(n, np.int64)
+        assert lib.tnerf_param_layout(C.byref(d), _ptr(off), _ptr(rows), _ptr(cols)) == 0
+        run = 0
+        for i, sh in enumerate(shapes):
+            assert off[i] == run
+            assert int(rows[i] * cols[i]) == int(np.prod(sh))
+            run += int(np.prod(sh))
+        assert lib.tnerf_param_count(C.byref(d)) == run
+    assert lib.tnerf_param_count(C.byref(_desc(39, 256, 8, 4))) == 481796
+    assert lib.tnerf_param_count(C.byref(_desc(63, 128, 4, 2))) == 66308
+
+
+def _plan(cfg, M, n_cu=256):
+    lib = tl.load()
+    d = _desc(*cfg)
+    sz = tl.PlanSizes()
+    assert lib.tnerf_plan_sizes_query(C.byref(d), M, n_cu, C.byref(sz)) == 0, tl.last_error()
+    pack = np.empty(sz.packed_floats, np.int32); jobs = np.empty(sz.job_ints, np.int32); red = np.empty(sz.reduce_ints, np.int32)
+    assert lib.tnerf_plan_fill(C.byref(d), M, n_cu, _ptr(pack), _ptr(jobs), _ptr(red)) == 0, tl.last_error()
+    emap = np.empty(64, np.int32); ne = C.c_int32()
+    assert lib.tnerf_input_pairing(cfg[0], _ptr(emap), C.byref(ne)) == 0
+    return sz, pack, jobs.reshape(-1, 16), red, emap.reshape(32, 2), ne.value
+
+
+def _acc_row(r, h):
+    return (r & 3) + 8 * (r >> 2) + 4 * h
+
+
+def _mfma(a, b, acc):
+    """v_mfma_f32_32x32x2_f32: a, b: [64] lane values; acc: [16, 64].  D[i][j] += sum_k A[i][k] B[k][j]."""
+    A = a.reshape(2, 32).T            # [i][k]
+    B = b.reshape(2, 32)              # [k][j]
+    D = A @ B                         # [32, 32]
+    for r in range(16):
+        for h in range(2):
+            acc[r, 32 * h:32 * h + 32] += D[_acc_row(r, h), :]
+    return acc
+
+
+@pytest.mark.parametrize("cfg", [(39, 256, 8, 4), (63, 128, 4, 2), (10, 128, 2, 1)])
+def test_pack_table_emulated_mfma_chain_equals_mlp(cfg):
+    """Run the forward kernel's exact register data flow (fragments, accumulator->operand chaining) in numpy."""
+    in_dim, hidden, depth, skip_at = cfg
+    sz, pack, jobs, red, emap, NE = _plan(cfg, 64)
+    g = torch.Generator().manual_seed(7)
+    params = O.mlp_init(in_dim, hidden, depth, skip_at, g)
+    flat = torch.cat([p.reshape(-1) for p in params]).double().numpy()
+    packed = np.where(pack >= 0, flat[np.clip(pack, 0, None)], 0.0)
+    x = torch.randn(32, in_dim, generator=g)
+    NT = hidden // 32
+    lane = np.arange(64); j = lane & 31; h = lane >> 5
+    # network input registers: enc[st][lane]
+    enc = np.zeros((NE, 64))
+    for st in range(NE):
+        for L_ in range(64):
+            c = emap[st, h[L_]]
+            enc[st, L_] = x[j[L_], c].item() if c >= 0 else 0.0
+    # walk the packed buffer in the order tn_build_layout lays it out
+    pos = 0
+
+    def take(n):
+        nonlocal pos
+        out = packed[pos:pos + n]; pos += n
+        return out
+
+    hcur = None
+    for l in range(depth):
+        bias = take(NT * 32).reshape(NT, 2, 16)
+        has_enc = (l == 0) or (skip_at > 0 and l == skip_at)
+        We = take(NT * NE * 64).reshape(NT, NE // 4, 64, 4) if has_enc else None
+        Wh = take(NT * NT * 1024).reshape(NT, NT * 4, 64, 4) if l > 0 else None
+        hnext = np.zeros((hidden // 2, 64))
+        for t in range(NT):
+            acc = np.zeros((16, 64))
+            for r in range(16):
+                acc[r] = bias[t, h, r]
+            if Wh is not None:
+                for gq in range(NT * 4):
+                    for p in range(4):
+                        acc = _mfma(Wh[t, gq, :, p], hcur[gq * 4 + p], acc)
+            if We is not None:
+                for gq in range(NE // 4):
+                    for p in range(4):
+                        acc = _mfma(We[t, gq, :, p], enc[gq * 4 + p], acc)
+            hnext[t * 16:(t + 1) * 16] = np.maximum(acc, 0.0)
+        hcur = hnext
+    hb = take(32).reshape(2, 16)
+    Wd = take(NT * 1024).reshape(NT * 4, 64, 4)
+    acc = np.zeros((16, 64))
+    for r in range(4):
+        acc[r] = hb[h, r]
+    for gq in range(NT * 4):
+        for p in range(4):
+            acc = _mfma(Wd[gq, :, p], hcur[gq * 4 + p], acc)
+    rgb = 1.0 / (1.0 + np.exp(-acc[:3, :32])); sigma = np.maximum(acc[3, :32], 0.0)
+    want_rgb, want_sigma = O.mlp_forward([p.double() for p in params], x.double(), skip_at)
+    np.testing.assert_allclose(rgb.T, want_rgb.numpy(), rtol=0, atol=1e-12)
+    np.testing.assert_allclose(sigma, want_sigma.numpy()[:, 0], rtol=0, atol=1e-12)
+
+    # transposed fragments: dH_{l-1} = W_l^T dZ_l for every hidden layer, and the heads
+    dz = np.random.RandomState(0).randn(hidden // 2, 64)           # registers [t*16+r][lane] = dZ[32t+row(r,h)][j]
+    dZ = np.zeros((hidden, 32))
+    for t in range(NT):
+        for r in range(16):
+            for hh in range(2):
+                dZ[32 * t + _acc_row(r, hh)] = dz[t * 16 + r, 32 * hh:32 * hh + 32]
+    for l in range(1, depth):
+        Wt = take(NT * NT * 1024).reshape(NT, NT * 4, 64, 4)
+        W = params[2 * l].double().numpy()[:, :hidden]
+        want = W.T @ dZ
+        for t in range(NT):
+            acc = np.zeros((16, 64))
+            for gq in range(NT * 4):
+                for p in range(4):
+                    acc = _mfma(Wt[t, gq, :, p], dz[gq * 4 + p], acc)
+            for r in range(16):
+                for hh in range(2):
+                    np.testing.assert_allclose(acc[r, 32 * hh:32 * hh + 32], want[32 * t + _acc_row(r, hh)], atol=1e-12)
+    Wth = take(NT * 256).reshape(NT, 64, 4)
+    dzh = np.random.RandomState(1).randn(4, 32)
+    Whead = np.concatenate([params[2 * depth + 2].double().numpy(), params[2 * depth].double().numpy()], 0)   # r,g,b,sigma
+    want = Whead.T @ dzh
+    for t in range(NT):
+        acc = np.zeros((16, 64))
+        for p in range(4):
+            b = np.concatenate([dzh[p], np.zeros(32)])
+            acc = _mfma(Wth[t, :, p], b, acc)
+        for r in range(16):
+            for hh in range(2):
+                np.testing.assert_allclose(acc[r, 32 * hh:32 * hh + 32], want[32 * t + _acc_row(r, hh)], atol=1e-12)
+    assert pos == sz.packed_floats
+
+
+@pytest.mark.parametrize("cfg,M,n_cu", [((39, 256, 8, 4), 2048, 256), ((63, 128, 4, 2), 1000, 256), ((39, 128, 3, 0), 96, 8)])
+def test_wgrad_jobs_and_reduce_table_reproduce_autograd(cfg, M, n_cu):
+    in_dim, hidden, depth, skip_at = cfg
+    sz, pack, jobs, red, emap, NE = _plan(cfg, M, n_cu)
+    Mp = sz.stash_row_stride
+    assert Mp % 64 == 0 and Mp >= M and len(jobs) == sz.n_jobs
+    g = torch.Generator().manual_seed(11)
+    params = [p.double().requires_grad_(True) for p in O.mlp_init(in_dim, hidden, depth, skip_at, g)]
+    x = torch.randn(M, in_dim, generator=g).double()
+    # forward with the intermediate activations kept, as the stash would hold them
+    hs, zs = [], []
+    hcur = x
+    for l in range(depth):
+        z = torch.nn.functional.linear(hcur, params[2 * l], params[2 * l + 1]); z.retain_grad(); zs.append(z)
+        hh = torch.relu(z); hs.append(hh)
+        hcur = torch.cat([hh, x], -1) if l == skip_at - 1 else hh
+    zr = torch.nn.functional.linear(hcur, params[2 * depth + 2], params[2 * depth + 3]); zr.retain_grad()
+    zsg = torch.nn.functional.linear(hcur, params[2 * depth], params[2 * depth + 1]); zsg.retain_grad()
+    loss = (torch.sigmoid(zr) * torch.randn(M, 3, generator=g).double()).sum() + (torch.relu(zsg) * torch.randn(M, 1, generator=g).double()).sum()
+    loss.backward()
+    rows = 2 * NE + 2 * depth * hidden + 8
+    assert sz.stash_floats == rows * Mp
+    stash = np.full((rows, Mp), np.nan)
+    r0 = 0
+    for st in range(NE):
+        for hh in range(2):
+            c = emap[st, hh]
+            stash[r0 + 2 * st + hh, :M] = x[:, c].numpy() if c >= 0 else 0.0
+    r0 += 2 * NE
+    for l in range(depth):
+        stash[r0:r0 + hidden, :M] = hs[l].detach().numpy().T; r0 += hidden
+    r0 += 4
+    for l in range(depth):
+        stash[r0:r0 + hidden, :M] = zs[l].grad.numpy().T; r0 += hidden
+    stash[r0:r0 + 3, :M] = zr.grad.numpy().T; stash[r0 + 3, :M] = zsg.grad.numpy()[:, 0]
+    # run every job in numpy
+    slabs = np.zeros(sz.slab_floats)
+    covered = {}
+    for jb in jobs:
+        a0, ar, b0, br, nat, nbt, wa, blk0, nblk, soff, cls, hasb = (int(v) for v in jb[:12])
+        assert nat % wa == 0 and nbt % (4 // wa) == 0
+        m0, m1 = blk0 * 32, min(M, (blk0 + nblk) * 32)
+        assert nblk > 0 and m0 < M
+        covered.setdefault(cls, []).append((m0, m1))
+        A = np.zeros((nat * 32, m1 - m0)); B = np.zeros((nbt * 32, m1 - m0))
+        A[:ar] = stash[a0:a0 + ar, m0:m1]; B[:br] = stash[b0:b0 + br, m0:m1]
+        blk = A @ B.T
+        slabs[soff:soff + blk.size] = blk.reshape(-1)
+        slabs[soff + blk.size: soff + blk.size + nat * 32] = A.sum(1)
+    for cls, spans in covered.items():            # every class covers [0, M) exactly once
+        spans.sort()
+        assert spans[0][0] == 0 and spans[-1][1] == M
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    assert sz.n_jobs <= max(2 * n_cu, 64)
+    ncls = red[0]
+    hdr = red[1:1 + 4 * ncls].reshape(ncls, 4)
+    ent = red[260:].reshape(-1, 2)
+    grads = np.zeros(sz.n_params)
+    for i in range(sz.n_params):
+        off, cls = ent[i]
+        first, stride, nch = hdr[cls, 0], hdr[cls, 1], hdr[cls, 2]
+        grads[i] = sum(slabs[first + off + c * stride] for c in range(nch))
+    want = torch.cat([p.grad.reshape(-1) for p in params]).numpy()
+    np.testing.assert_allclose(grads, want, rtol=1e-9, atol=1e-9)
+
+
+def test_input_pairing_is_a_permutation():
+    lib = tl.load()
+    for in_dim in (3, 9, 10, 39, 40, 45, 63, 64):
+        emap = np.empty(64, np.int32); ne = C.c_int32()
+        assert lib.tnerf_input_pairing(in_dim, _ptr(emap), C.byref(ne)) == 0
+        used = emap[emap >= 0]
+        assert sorted(used.tolist()) == list(range(in_dim))
+        assert ne.value in (20, 32) and (emap[2 * ne.value:] == -1).all()
+    L = 6
+    emap = np.empty(64, np.int32); ne = C.c_int32()
+    lib.tnerf_input_pairing(39, _ptr(emap), C.byref(ne))
+    e = emap.reshape(32, 2)
+    for k in range(L):
+        for c in range(3):
+            assert e[3 * k + c, 0] == 3 + 6 * k + c and e[3 * k + c, 1] == 3 + 6 * k + 3 + c     # (sin, cos) pair
+    assert e[18].tolist() == [0, 1] and e[19].tolist() == [2, -1]

@@ -1,0 +1,137 @@
+// Device-side helpers shared by the HIP kernels (gfx950 only; wavefront = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "tnerf_internal.h"
+
+typedef float f32x4  __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define TN_WAVE 64
+
+#define TN_HIP_CHECK_LAUNCH(name)                                              \
+    do {                                                                       \
+        hipError_t e_ = hipGetLastError();                                     \
+        if (e_ != hipSuccess) {                                                \
+            tn_set_error("%s: launch failed: %s", name, hipGetErrorString(e_)); \
+            return (int)e_;                                                    \
+        }                                                                      \
+    } while (0)
+
+__device__ __forceinline__ int tn_lane() { return (int)(threadIdx.x & 63); }
+
+// ----------------------------------------------------------------------------- Philox4x32-10
+// Counter-based generator for the "speed mode" jitter (t_rand == NULL).  One 128-bit block per
+// (sample index / 4); lane takes word (index & 3).  u in [0,1) with 24 random bits, like
+// torch's uniform_ for float.
+__device__ __forceinline__ uint32_t tn_mulhi(uint32_t a, uint32_t b) { return __umulhi(a, b); }
+
+__device__ __forceinline__ float tn_philox_uniform(uint64_t seed, uint64_t index) {
+    uint32_t c0 = (uint32_t)(index >> 2), c1 = (uint32_t)(index >> 34), c2 = 0u, c3 = 0u;
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t h0 = tn_mulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+        const uint32_t h1 = tn_mulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = h1 ^ c1 ^ k0, n1 = l1, n2 = h0 ^ c3 ^ k1, n3 = l0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    const uint32_t w = (uint32_t)(index & 3);
+    const uint32_t x = w == 0 ? c0 : (w == 1 ? c1 : (w == 2 ? c2 : c3));
+    return (float)(x & 0xFFFFFFu) * (1.0f / 16777216.0f);
+}
+
+// ------------------------------------------------------------------------------ sin / cos
+// Both sin and cos of the same argument with ONE Cody-Waite reduction (3-term pi/2 split, fma) and
+// minimax polynomials on [-pi/4, pi/4]: <= 1.5 ulp (max abs error 7.1e-8) for |x| < 1e5, checked
+// against fp64 on the host.  The encoder's arguments 2^k * p are exact in fp32 and far
+// inside that range; anything larger (or NaN/Inf) takes the ocml full-range path, kept out of line so
+// the 18-30 call sites per tile stay ~25 instructions each.
+__device__ __attribute__((noinline)) void tn_sincos_slow(float x, float* s, float* c) { sincosf(x, s, c); }
+
+__device__ __forceinline__ void tn_sincos(float x, float& sn, float& cs) {
+    if (__builtin_expect(!(fabsf(x) < 1.0e5f), 0)) { tn_sincos_slow(x, &sn, &cs); return; }
+    const float j = fmaf(x, 0.636619747f, 12582912.0f) - 12582912.0f;
+    float a = fmaf(j, -1.57079601e+00f, x);
+    a = fmaf(j, -3.13916473e-07f, a);
+    a = fmaf(j, -5.39030253e-15f, a);
+    const int q = (int)j;
+    const float s2 = __fmul_rn(a, a);
+    float r = 2.86567956e-6f;
+    r = fmaf(r, s2, -1.98559923e-4f); r = fmaf(r, s2, 8.33338592e-3f); r = fmaf(r, s2, -1.66666672e-1f);
+    const float ps = fmaf(r, __fmul_rn(a, s2), a);
+    float pc = 2.44677067e-5f;
+    pc = fmaf(pc, s2, -1.38877297e-3f); pc = fmaf(pc, s2, 4.16666567e-2f); pc = fmaf(pc, s2, -0.5f); pc = fmaf(pc, s2, 1.0f);
+    float S = (q & 1) ? pc : ps, C = (q & 1) ? ps : pc;
+    if (q & 2) S = -S;
+    if ((q + 1) & 2) C = -C;
+    sn = S; cs = C;
+}
+
+// ------------------------------------------------------------------------- sampling arithmetic
+// Everything that defines a "sample bin" is rounded op by op exactly like the reference's
+// separate ATen kernels (no FMA contraction): sampling.py:25 and :27.
+struct SampleArgs {
+    const float* ztab;      // [3*S]: z | lo | hi
+    const float* t_rand;    // [R*S] or NULL
+    uint64_t seed, offset;
+    int32_t S;
+    int32_t randomized;
+};
+
+__device__ __forceinline__ float tn_depth(const SampleArgs& a, int64_t ray, int s) {
+    if (!a.randomized) return a.ztab[s];
+    const float lo = a.ztab[a.S + s], hi = a.ztab[2 * a.S + s];
+    const int64_t idx = ray * a.S + s;
+    const float u = a.t_rand ? a.t_rand[idx] : tn_philox_uniform(a.seed, a.offset + (uint64_t)idx);
+    return __fadd_rn(lo, __fmul_rn(__fsub_rn(hi, lo), u));
+}
+
+__device__ __forceinline__ float tn_point(float o, float d, float z) { return __fadd_rn(o, __fmul_rn(d, z)); }
+
+// --------------------------------------------------------------------------- wave primitives
+__device__ __forceinline__ float tn_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float tn_wave_prod(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v *= __shfl_xor(v, o, 64);
+    return v;
+}
+// inclusive product scan over the 64 lanes
+__device__ __forceinline__ float tn_wave_scan_mul(float v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float n = __shfl_up(v, o, 64);
+        if (lane >= o) v *= n;
+    }
+    return v;
+}
+// inclusive suffix sum: out[l] = sum_{k>=l} v[k]
+__device__ __forceinline__ float tn_wave_suffix_sum(float v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float n = __shfl_down(v, o, 64);
+        if (lane + o < 64) v += n;
+    }
+    return v;
+}
+
+// Per-sample compositing terms of volume_render (volume.py:18-34) for one lane.
+struct CompTerms { float delta, e, alpha, om; };
+__device__ __forceinline__ CompTerms tn_comp_terms(float sigma, float z, float z_next, bool last, float dnorm) {
+    CompTerms c;
+    const float gap = last ? 1e10f : __fsub_rn(z_next, z);
+    c.delta = __fmul_rn(gap, dnorm);
+    c.e = expf(__fmul_rn(-sigma, c.delta));
+    c.alpha = __fsub_rn(1.0f, c.e);
+    c.om = __fadd_rn(__fsub_rn(1.0f, c.alpha), 1e-10f);
+    return c;
+}
+
+__device__ __forceinline__ float tn_norm3(float x, float y, float z) {
+    return sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z)));
+}

@@ -1,0 +1,349 @@
+// Host-side planning for libtnerf_hip.so: no GPU calls in this file.
+//   * bit-exact depth tables of stratified_samples            [reference src/sampling.py:16-23]
+//   * flat parameter layout of TinyNeRF                         [reference src/nerf.py:18-27]
+//   * MFMA-fragment packing table, wgrad job table, slab->gradient gather table
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+#include <algorithm>
+#include "tnerf_internal.h"
+
+static thread_local char g_err[512] = "ok";
+
+extern "C" void tn_set_error(const char* fmt, ...) {
+    va_list ap; va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" int tnerf_version(void) { return TNERF_ABI_VERSION; }
+extern "C" const char* tnerf_last_error_string(void) { return g_err; }
+
+// ---------------------------------------------------------------------------- depth tables
+// torch.linspace(0,1,S) on CPU fp32 (ATen RangeFactories): step = (end-start)/(S-1) in fp32,
+// element i = start + step*i for i < S/2 and end - step*(S-1-i) otherwise, each as ONE fused
+// multiply-add.  z = near*(1-t) + far*t with every product/sum rounded separately.
+extern "C" int tnerf_sample_tables(float near_, float far_, int32_t S, float* ztab, float* t_out) {
+    if (S < 1 || !ztab) { tn_set_error("tnerf_sample_tables: n_samples=%d, ztab=%p", S, (void*)ztab); return TNERF_EINVAL; }
+    volatile float nearf = near_, farf = far_;
+    float* z = ztab; float* lo = ztab + S; float* hi = ztab + 2 * S;
+    const float step = (S > 1) ? (1.0f - 0.0f) / (float)(S - 1) : 0.0f;
+    const int half = S / 2;
+    for (int i = 0; i < S; ++i) {
+        float t;
+        if (S == 1) t = 0.0f;
+        else if (i < half) t = fmaf(step, (float)i, 0.0f);
+        else t = fmaf(-step, (float)(S - 1 - i), 1.0f);
+        if (t_out) t_out[i] = t;
+        volatile float om = 1.0f - t;
+        volatile float a = nearf * om;
+        volatile float b = farf * t;
+        volatile float zz = a + b;
+        z[i] = zz;
+    }
+    for (int i = 0; i < S; ++i) {
+        if (i == 0) lo[i] = z[0];
+        else { volatile float s = z[i - 1] + z[i]; volatile float m = 0.5f * s; lo[i] = m; }
+        if (i == S - 1) hi[i] = z[S - 1];
+        else { volatile float s = z[i] + z[i + 1]; volatile float m = 0.5f * s; hi[i] = m; }
+    }
+    return TNERF_OK;
+}
+
+// ------------------------------------------------------------------------------ model layout
+static int check_desc(const tnerf_mlp_desc* d) {
+    if (!d) { tn_set_error("NULL tnerf_mlp_desc"); return TNERF_EINVAL; }
+    if (d->hidden != 128 && d->hidden != 256) {
+        tn_set_error("hidden=%d: only 128 and 256 are built", d->hidden); return TNERF_EUNSUPPORTED; }
+    if (d->depth < 1 || d->depth > TN_MAXD) { tn_set_error("depth=%d out of [1,%d]", d->depth, TN_MAXD); return TNERF_EUNSUPPORTED; }
+    if (d->in_dim < 1 || d->in_dim > 64) { tn_set_error("in_dim=%d out of [1,64]", d->in_dim); return TNERF_EUNSUPPORTED; }
+    if (d->skip_at < 0 || d->skip_at >= d->depth) {
+        // skip_at == depth would feed hidden+in_dim features to Linear(hidden, .) heads: the reference raises there too
+        tn_set_error("skip_at=%d must be 0 (none) or in [1, depth-1]", d->skip_at); return TNERF_EINVAL; }
+    return TNERF_OK;
+}
+
+extern "C" int tnerf_input_pairing(int32_t in_dim, int32_t* emap, int32_t* n_steps) {
+    if (in_dim < 1 || in_dim > 64 || !emap || !n_steps) { tn_set_error("tnerf_input_pairing: bad args"); return TNERF_EINVAL; }
+    for (int i = 0; i < 64; ++i) emap[i] = -1;
+    int used;
+    if (in_dim >= 9 && (in_dim - 3) % 6 == 0) {          // [x, sin(2^k x), cos(2^k x)]: pair sin with cos
+        const int L = (in_dim - 3) / 6;
+        for (int k = 0; k < L; ++k)
+            for (int c = 0; c < 3; ++c) {
+                emap[2 * (3 * k + c) + 0] = 3 + 6 * k + c;
+                emap[2 * (3 * k + c) + 1] = 3 + 6 * k + 3 + c;
+            }
+        emap[2 * (3 * L) + 0] = 0; emap[2 * (3 * L) + 1] = 1;
+        emap[2 * (3 * L + 1) + 0] = 2;
+        used = 3 * L + 2;
+    } else {
+        for (int c = 0; c < in_dim; ++c) emap[c] = c;
+        used = (in_dim + 1) / 2;
+    }
+    *n_steps = used <= 20 ? 20 : 32;
+    return TNERF_OK;
+}
+
+extern "C" int tn_build_layout(const tnerf_mlp_desc* d, MlpLayout* L) {
+    int rc = check_desc(d); if (rc) return rc;
+    memset(L, 0, sizeof(*L));
+    L->in_dim = d->in_dim; L->hidden = d->hidden; L->depth = d->depth; L->skip_at = d->skip_at;
+    L->NT = d->hidden / 32;
+    int32_t em[64], ne;
+    rc = tnerf_input_pairing(d->in_dim, em, &ne); if (rc) return rc;
+    L->NE = ne;
+    for (int s = 0; s < TN_MAX_STEPS; ++s) { L->emap[s][0] = (int16_t)em[2 * s]; L->emap[s][1] = (int16_t)em[2 * s + 1]; }
+    const int NT = L->NT, NE = L->NE, H = d->hidden;
+    // flat parameters, state_dict order
+    int64_t off = 0; int fan = d->in_dim;
+    for (int l = 0; l < d->depth; ++l) {
+        L->fan_in[l] = fan; L->p_w[l] = off; off += (int64_t)H * fan; L->p_b[l] = off; off += H;
+        fan = (d->skip_at > 0 && l == d->skip_at - 1) ? H + d->in_dim : H;
+    }
+    L->p_ws = off; off += H; L->p_bs = off; off += 1; L->p_wc = off; off += 3 * (int64_t)H; L->p_bc = off; off += 3;
+    L->n_params = off;
+    // packed segments
+    int64_t po = 0;
+    for (int l = 0; l < d->depth; ++l) {
+        L->fw_bias[l] = po; po += NT * 32;
+        const bool enc = (l == 0) || (d->skip_at > 0 && l == d->skip_at);
+        L->fw_enc[l] = enc ? po : -1; if (enc) po += (int64_t)NT * NE * 64;
+        L->fw_hid[l] = (l > 0) ? po : -1; if (l > 0) po += (int64_t)NT * NT * 1024;
+    }
+    L->fw_head_bias = po; po += 32;
+    L->fw_head = po; po += (int64_t)NT * 1024;
+    for (int l = 0; l < d->depth; ++l) { L->bw_hid[l] = (l > 0) ? po : -1; if (l > 0) po += (int64_t)NT * NT * 1024; }
+    L->bw_head = po; po += (int64_t)NT * 256;
+    L->packed_floats = po;
+    // stash rows
+    int row = 0;
+    L->enc_row0 = row; row += 2 * NE;
+    for (int l = 0; l < d->depth; ++l) { L->h_row0[l] = row; row += H; }
+    L->out_row0 = row; row += 4;
+    for (int l = 0; l < d->depth; ++l) { L->dz_row0[l] = row; row += H; }
+    L->dzh_row0 = row; row += 4;
+    L->stash_rows = row;
+    return TNERF_OK;
+}
+
+extern "C" int64_t tnerf_param_count(const tnerf_mlp_desc* d) {
+    MlpLayout L; if (tn_build_layout(d, &L)) return -1;
+    return L.n_params;
+}
+
+extern "C" int tnerf_param_layout(const tnerf_mlp_desc* d, int64_t* offsets, int64_t* rows, int64_t* cols) {
+    MlpLayout L; int rc = tn_build_layout(d, &L); if (rc) return rc;
+    if (!offsets || !rows || !cols) { tn_set_error("tnerf_param_layout: NULL output"); return TNERF_EINVAL; }
+    int k = 0;
+    for (int l = 0; l < d->depth; ++l) {
+        offsets[k] = L.p_w[l]; rows[k] = d->hidden; cols[k] = L.fan_in[l]; ++k;
+        offsets[k] = L.p_b[l]; rows[k] = d->hidden; cols[k] = 1; ++k;
+    }
+    offsets[k] = L.p_ws; rows[k] = 1; cols[k] = d->hidden; ++k;
+    offsets[k] = L.p_bs; rows[k] = 1; cols[k] = 1; ++k;
+    offsets[k] = L.p_wc; rows[k] = 3; cols[k] = d->hidden; ++k;
+    offsets[k] = L.p_bc; rows[k] = 3; cols[k] = 1; ++k;
+    return TNERF_OK;
+}
+
+// ------------------------------------------------------------------------------- wgrad plan
+namespace {
+struct JobClass {
+    int a_row0, a_rows, b_row0, b_rows, n_at, n_bt, wa, has_bias;
+    int cost;              // max 32x32 tiles per wave
+    int chunks;            // workgroups
+    int64_t slab0;         // float offset of chunk 0
+    int64_t slab_stride;   // floats per chunk
+};
+
+static void pick_split(int n_at, int n_bt, int* wa_out, int* cost_out) {
+    int best_wa = 1, best_cost = 1 << 30, best_ld = 1 << 30;
+    for (int wa = 1; wa <= 4; wa *= 2) {
+        const int wb = 4 / wa;
+        const int ta = (n_at + wa - 1) / wa, tb = (n_bt + wb - 1) / wb;
+        if (ta > 4 || tb > 4) continue;
+        const int cost = ta * tb, ld = ta + tb;
+        if (cost < best_cost || (cost == best_cost && ld < best_ld)) { best_cost = cost; best_ld = ld; best_wa = wa; }
+    }
+    *wa_out = best_wa; *cost_out = best_cost;
+}
+
+static int build_classes(const MlpLayout& L, int64_t M, int n_cu, std::vector<JobClass>& cls, int64_t* slab_total) {
+    const int H = L.hidden, NT = L.NT, encT = (2 * L.NE + 31) / 32;
+    bool bad_split = false;
+    auto add = [&](int a0, int ar, int b0, int br, int nat, int nbt, int bias) {
+        JobClass c{}; c.a_row0 = a0; c.a_rows = ar; c.b_row0 = b0; c.b_rows = br; c.n_at = nat; c.n_bt = nbt; c.has_bias = bias;
+        pick_split(nat, nbt, &c.wa, &c.cost); cls.push_back(c);
+        if (nat % c.wa != 0 || nbt % (4 / c.wa) != 0) bad_split = true;
+        else {   // per-wave tile shapes instantiated in wgrad.hip
+            const int ta = nat / c.wa, tb = nbt / (4 / c.wa);
+            const bool ok = (ta == 4 && tb == 4) || (ta == 2 && tb == 2) || (ta == 1 && tb == 2) || (ta == 2 && tb == 1) || (ta == 1 && tb == 1);
+            if (!ok) bad_split = true;
+        }
+    };
+    // class index order is what reduce_table refers to:
+    //   [l]            l>=1 : (dZ_l, H_{l-1})     owns b_l
+    //   [0]                 : (dZ_0, ENC)         owns b_0
+    //   [depth]             : (dZ_skip, ENC)      (only if skip)
+    //   [last]              : (dZ_head, H_{depth-1}) owns head biases
+    add(L.dz_row0[0], H, L.enc_row0, 2 * L.NE, NT, encT, 1);
+    for (int l = 1; l < L.depth; ++l) add(L.dz_row0[l], H, L.h_row0[l - 1], H, NT, NT, 1);
+    if (L.skip_at > 0) add(L.dz_row0[L.skip_at], H, L.enc_row0, 2 * L.NE, NT, encT, 0);
+    add(L.dzh_row0, 4, L.h_row0[L.depth - 1], H, 1, NT, 1);
+    if (bad_split) { tn_set_error("wgrad: no kernel for this layer-shape / wave split"); return TNERF_EUNSUPPORTED; }
+    if ((int)cls.size() > TN_RED_MAXCLS) { tn_set_error("too many wgrad job classes"); return TNERF_EUNSUPPORTED; }
+    const int64_t MB = (M + 31) / 32;
+    int64_t cost_sum = 0; for (auto& c : cls) cost_sum += c.cost;
+    int64_t off = 0;
+    for (auto& c : cls) {
+        int64_t ch = ((int64_t)n_cu * c.cost + cost_sum / 2) / cost_sum;
+        ch = std::max<int64_t>(1, std::min<int64_t>(ch, MB));
+        // make every chunk non-empty
+        const int64_t per = (MB + ch - 1) / ch;
+        ch = (MB + per - 1) / per;
+        c.chunks = (int)ch;
+        c.slab_stride = (int64_t)c.n_at * 32 * (c.n_bt * 32) + (int64_t)c.n_at * 32;
+        c.slab0 = off; off += c.slab_stride * ch;
+    }
+    if (off >= (int64_t)1 << 31) { tn_set_error("slab workspace exceeds int32 offsets"); return TNERF_EUNSUPPORTED; }
+    *slab_total = off;
+    return TNERF_OK;
+}
+}  // namespace
+
+extern "C" int tnerf_plan_sizes_query(const tnerf_mlp_desc* d, int64_t M, int32_t n_cu, tnerf_plan_sizes* out) {
+    MlpLayout L; int rc = tn_build_layout(d, &L); if (rc) return rc;
+    if (!out || M < 1 || n_cu < 1) { tn_set_error("tnerf_plan_sizes_query: M=%lld n_cu=%d", (long long)M, n_cu); return TNERF_EINVAL; }
+    std::vector<JobClass> cls; int64_t slab = 0;
+    rc = build_classes(L, M, n_cu, cls, &slab); if (rc) return rc;
+    int64_t jobs = 0; for (auto& c : cls) jobs += c.chunks;
+    const int64_t Mp = (M + 63) / 64 * 64;
+    out->n_params = L.n_params;
+    out->packed_floats = L.packed_floats;
+    out->stash_floats = (int64_t)L.stash_rows * Mp;
+    out->slab_floats = slab;
+    out->job_ints = jobs * TN_JOB_INTS;
+    out->reduce_ints = TN_RED_HDR + 2 * L.n_params;
+    out->n_jobs = jobs;
+    out->stash_row_stride = Mp;
+    return TNERF_OK;
+}
+
+static void fill_pack_table(const MlpLayout& L, int32_t* T) {
+    const int NT = L.NT, NE = L.NE, H = L.hidden;
+    for (int64_t i = 0; i < L.packed_floats; ++i) T[i] = -1;
+    auto head_w = [&](int n, int k) -> int32_t {         // head row order: r,g,b,sigma
+        if (n < 3) return (int32_t)(L.p_wc + (int64_t)n * H + k);
+        if (n == 3) return (int32_t)(L.p_ws + k);
+        return -1;
+    };
+    auto head_b = [&](int n) -> int32_t { return n < 3 ? (int32_t)(L.p_bc + n) : (n == 3 ? (int32_t)L.p_bs : -1); };
+    for (int l = 0; l < L.depth; ++l) {
+        const int fan = L.fan_in[l];
+        for (int t = 0; t < NT; ++t)
+            for (int h = 0; h < 2; ++h)
+                for (int r = 0; r < 16; ++r)
+                    T[L.fw_bias[l] + (t * 2 + h) * 16 + r] = (int32_t)(L.p_b[l] + 32 * t + TN_ACC_ROW(r, h));
+        if (L.fw_enc[l] >= 0) {
+            const int coloff = (l == 0) ? 0 : H;
+            for (int t = 0; t < NT; ++t)
+                for (int g = 0; g < NE / 4; ++g)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int p = 0; p < 4; ++p) {
+                            const int c = L.emap[4 * g + p][lane >> 5];
+                            if (c < 0) continue;
+                            T[L.fw_enc[l] + (((int64_t)t * (NE / 4) + g) * 64 + lane) * 4 + p] =
+                                (int32_t)(L.p_w[l] + (int64_t)(32 * t + (lane & 31)) * fan + coloff + c);
+                        }
+        }
+        if (L.fw_hid[l] >= 0) {
+            for (int t = 0; t < NT; ++t) for (int kb = 0; kb < NT; ++kb) for (int q = 0; q < 4; ++q)
+                for (int lane = 0; lane < 64; ++lane) for (int p = 0; p < 4; ++p) {
+                    const int n = 32 * t + (lane & 31), k = 32 * kb + 8 * q + 4 * (lane >> 5) + p;
+                    T[L.fw_hid[l] + ((((int64_t)t * NT + kb) * 4 + q) * 64 + lane) * 4 + p] = (int32_t)(L.p_w[l] + (int64_t)n * fan + k);
+                    // transposed copy for dgrad: out row = k-tile index (t here), reduction over n-block (kb here)
+                    const int kk = 32 * t + (lane & 31), nn = 32 * kb + 8 * q + 4 * (lane >> 5) + p;
+                    T[L.bw_hid[l] + ((((int64_t)t * NT + kb) * 4 + q) * 64 + lane) * 4 + p] = (int32_t)(L.p_w[l] + (int64_t)nn * fan + kk);
+                }
+        }
+    }
+    for (int h = 0; h < 2; ++h) for (int r = 0; r < 16; ++r) T[L.fw_head_bias + h * 16 + r] = head_b(TN_ACC_ROW(r, h));
+    for (int kb = 0; kb < NT; ++kb) for (int q = 0; q < 4; ++q) for (int lane = 0; lane < 64; ++lane) for (int p = 0; p < 4; ++p)
+        T[L.fw_head + (((int64_t)kb * 4 + q) * 64 + lane) * 4 + p] = head_w(lane & 31, 32 * kb + 8 * q + 4 * (lane >> 5) + p);
+    for (int kt = 0; kt < NT; ++kt) for (int lane = 0; lane < 64; ++lane) for (int p = 0; p < 4; ++p)
+        T[L.bw_head + ((int64_t)kt * 64 + lane) * 4 + p] = head_w(4 * (lane >> 5) + p, 32 * kt + (lane & 31));
+}
+
+extern "C" int tnerf_plan_fill(const tnerf_mlp_desc* d, int64_t M, int32_t n_cu,
+                               int32_t* pack_table, int32_t* job_table, int32_t* reduce_table) {
+    MlpLayout L; int rc = tn_build_layout(d, &L); if (rc) return rc;
+    if (M < 1 || n_cu < 1) { tn_set_error("tnerf_plan_fill: M=%lld n_cu=%d", (long long)M, n_cu); return TNERF_EINVAL; }
+    std::vector<JobClass> cls; int64_t slab = 0;
+    rc = build_classes(L, M, n_cu, cls, &slab); if (rc) return rc;
+    if (pack_table) fill_pack_table(L, pack_table);
+    const int64_t MB = (M + 31) / 32;
+    if (job_table) {
+        // interleave classes so that heavy and light workgroups are spread over the dispatch order
+        int64_t j = 0;
+        int maxch = 0; for (auto& c : cls) maxch = std::max(maxch, c.chunks);
+        for (int ch = 0; ch < maxch; ++ch)
+            for (size_t ci = 0; ci < cls.size(); ++ci) {
+                const JobClass& c = cls[ci];
+                if (ch >= c.chunks) continue;
+                const int64_t per = (MB + c.chunks - 1) / c.chunks;
+                int32_t* r = job_table + j * TN_JOB_INTS;
+                memset(r, 0, sizeof(int32_t) * TN_JOB_INTS);
+                r[JOB_A_ROW0] = c.a_row0; r[JOB_A_ROWS] = c.a_rows; r[JOB_B_ROW0] = c.b_row0; r[JOB_B_ROWS] = c.b_rows;
+                r[JOB_N_AT] = c.n_at; r[JOB_N_BT] = c.n_bt; r[JOB_WA] = c.wa;
+                r[JOB_MBLK0] = (int32_t)(ch * per);
+                r[JOB_MBLKN] = (int32_t)std::max<int64_t>(0, std::min<int64_t>(per, MB - ch * per));
+                r[JOB_SLAB_OFF] = (int32_t)(c.slab0 + c.slab_stride * ch);
+                r[JOB_CLASS] = (int32_t)ci; r[JOB_HAS_BIAS] = c.has_bias;
+                ++j;
+            }
+    }
+    if (reduce_table) {
+        int32_t* hdr = reduce_table;
+        memset(hdr, 0, sizeof(int32_t) * TN_RED_HDR);
+        hdr[0] = (int32_t)cls.size();
+        for (size_t ci = 0; ci < cls.size(); ++ci) {
+            hdr[1 + 4 * ci + 0] = (int32_t)cls[ci].slab0;
+            hdr[1 + 4 * ci + 1] = (int32_t)cls[ci].slab_stride;
+            hdr[1 + 4 * ci + 2] = cls[ci].chunks;
+        }
+        int32_t* E = reduce_table + TN_RED_HDR;
+        auto put = [&](int64_t param, int cls_id, int64_t elem) { E[2 * param] = (int32_t)elem; E[2 * param + 1] = cls_id; };
+        const int H = L.hidden;
+        const int cls_skip_enc = L.skip_at > 0 ? L.depth : -1;
+        const int cls_head = (int)cls.size() - 1;
+        // inverse of the input pairing: input column -> stash ENC row
+        int inv[64]; for (int c = 0; c < 64; ++c) inv[c] = -1;
+        for (int s = 0; s < L.NE; ++s) for (int h = 0; h < 2; ++h) if (L.emap[s][h] >= 0) inv[L.emap[s][h]] = 2 * s + h;
+        for (int l = 0; l < L.depth; ++l) {
+            const int fan = L.fan_in[l];
+            const JobClass& cm = cls[l];               // class l: (dZ_l, input of layer l) main part
+            const int ldm = cm.n_bt * 32;
+            for (int n = 0; n < H; ++n) {
+                for (int k = 0; k < fan; ++k) {
+                    const int64_t pi = L.p_w[l] + (int64_t)n * fan + k;
+                    if (l == 0) put(pi, 0, (int64_t)n * ldm + inv[k]);
+                    else if (k < H) put(pi, l, (int64_t)n * ldm + k);
+                    else put(pi, cls_skip_enc, (int64_t)n * (cls[cls_skip_enc].n_bt * 32) + inv[k - H]);
+                }
+                put(L.p_b[l] + n, l, (int64_t)cm.n_at * 32 * ldm + n);
+            }
+        }
+        const JobClass& chd = cls[cls_head];
+        const int ldh = chd.n_bt * 32;
+        for (int k = 0; k < H; ++k) {
+            put(L.p_ws + k, cls_head, (int64_t)3 * ldh + k);
+            for (int n = 0; n < 3; ++n) put(L.p_wc + (int64_t)n * H + k, cls_head, (int64_t)n * ldh + k);
+        }
+        put(L.p_bs, cls_head, (int64_t)32 * ldh + 3);
+        for (int n = 0; n < 3; ++n) put(L.p_bc + n, cls_head, (int64_t)32 * ldh + n);
+    }
+    return TNERF_OK;
+}

@@ -1,0 +1,262 @@
+// Forward kernels: TinyNeRF.forward on its own (x from HBM) and the fused
+// ray -> sample -> encode -> MLP -> composite path of render_one / the train step
+// (reference src/nerf.py:29-41, src/train.py:50-56 and :114-121).
+//
+// Launch geometry: 256-thread workgroups = 4 wavefronts = one per SIMD (the kernel uses the whole
+// 512-entry VGPR+AGPR file of a SIMD: HID/2 activation registers + HID/2 accumulators + the
+// weight-fragment ring).  Each wavefront owns one unit of work: a RAY in the fused kernels (its S
+// samples are marched 32 at a time through the register-resident MLP, then alpha-composited in
+// registers with a wave-shuffle exclusive scan), or a 32-row tile of x in the MLP-only kernel.
+#include "mlp_core.hpp"
+#include "mlp_args.hpp"
+
+// The MLP for one 32-sample tile.  enc: network input registers.  m: this lane's sample index in the
+// stash / output (valid if `valid`).  Returns the 4 head outputs (r,g,b after sigmoid; sigma after
+// ReLU) in out4 — meaningful on lane-half 0 only.
+template <int HID, int NE, bool TRAIN>
+__device__ __forceinline__ void tn_mlp_tile(const FwdArgs& a, const float (&enc)[NE], int64_t m, bool valid, int lane,
+                                            float (&out4)[4]) {
+    constexpr int NT = HID / 32;
+    const MlpLayout& L = a.L;
+    const int h = lane >> 5;
+    const float* __restrict__ packed = a.packed;
+    float* __restrict__ stash = a.stash;
+    const int64_t Mp = a.Mp;
+    const int64_t voff = (int64_t)(4 * h) * Mp + m;          // per-lane part of every stash address
+
+    if (TRAIN && valid) {
+        tn_static_for<NE>([&](auto sc_) TN_INLINE_LAMBDA {
+            constexpr int st = decltype(sc_)::value;
+            stash[(int64_t)(L.enc_row0 + 2 * st + h) * Mp + m] = enc[st];
+        });
+    }
+
+    float hcur[HID / 2], hnext[HID / 2];
+    // ---- layer 0: input only
+    {
+        float* __restrict__ srow = TRAIN ? stash + (int64_t)L.h_row0[0] * Mp : nullptr;
+        tn_layer<HID, NE, false, true>(packed, L.fw_bias[0], L.fw_enc[0], 0, hnext, enc, lane,
+            [&](auto tc, const f32x16& acc) TN_INLINE_LAMBDA {
+                constexpr int t = decltype(tc)::value;
+                tn_static_for<16>([&](auto rc) TN_INLINE_LAMBDA {
+                    constexpr int r = decltype(rc)::value;
+                    const float v = fmaxf(acc[r], 0.0f);
+                    hcur[t * 16 + r] = v;
+                    if (TRAIN && valid) srow[(int64_t)(32 * t + (r & 3) + 8 * (r >> 2)) * Mp + voff] = v;
+                });
+            });
+    }
+    // ---- hidden layers
+    for (int l = 1; l < L.depth; ++l) {
+        float* __restrict__ srow = TRAIN ? stash + (int64_t)L.h_row0[l] * Mp : nullptr;
+        auto fin = [&](auto tc, const f32x16& acc) TN_INLINE_LAMBDA {
+            constexpr int t = decltype(tc)::value;
+            tn_static_for<16>([&](auto rc) TN_INLINE_LAMBDA {
+                constexpr int r = decltype(rc)::value;
+                const float v = fmaxf(acc[r], 0.0f);
+                hnext[t * 16 + r] = v;
+                if (TRAIN && valid) srow[(int64_t)(32 * t + (r & 3) + 8 * (r >> 2)) * Mp + voff] = v;
+            });
+        };
+        if (l == L.skip_at) tn_layer<HID, NE, true, true>(packed, L.fw_bias[l], L.fw_enc[l], L.fw_hid[l], hcur, enc, lane, fin);
+        else                tn_layer<HID, NE, true, false>(packed, L.fw_bias[l], 0, L.fw_hid[l], hcur, enc, lane, fin);
+        tn_static_for<HID / 2>([&](auto ic) TN_INLINE_LAMBDA { hcur[decltype(ic)::value] = hnext[decltype(ic)::value]; });
+    }
+    // ---- heads: one n-tile whose rows 0..2 are rgb.0 and row 3 is sigma.0 (rows 4..31 are zero)
+    {
+        constexpr int GT = NT * 4;
+        const f32x4* __restrict__ Wh = reinterpret_cast<const f32x4*>(packed + L.fw_head) + lane;
+        const f32x4* __restrict__ Bf = reinterpret_cast<const f32x4*>(packed + L.fw_head_bias) + h * 4;
+        f32x16 acc;
+        const f32x4 b0 = Bf[0];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = r < 4 ? b0[r] : 0.0f;
+        tn_static_for<GT>([&](auto gc) TN_INLINE_LAMBDA {
+            constexpr int g = decltype(gc)::value;
+            const f32x4 a4 = Wh[g * 64];
+            acc = TN_MFMA(a4[0], hcur[g * 4 + 0], acc); acc = TN_MFMA(a4[1], hcur[g * 4 + 1], acc);
+            acc = TN_MFMA(a4[2], hcur[g * 4 + 2], acc); acc = TN_MFMA(a4[3], hcur[g * 4 + 3], acc);
+        });
+#pragma unroll
+        for (int i = 0; i < 3; ++i) out4[i] = 1.0f / (1.0f + expf(-acc[i]));   // torch.sigmoid   nerf.py:27,39
+        out4[3] = fmaxf(acc[3], 0.0f);                                          // ReLU            nerf.py:26,40
+    }
+}
+
+// ------------------------------------------------------------------------------ MLP only
+template <int HID, int NE, bool TRAIN>
+__global__ __launch_bounds__(256, 1) void k_mlp_fwd(FwdArgs a) {
+    const int lane = tn_lane();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t m0 = tile * 32;
+    if (m0 >= a.M) return;
+    const int j = lane & 31, h = lane >> 5;
+    const int64_t m = m0 + j;
+    const bool valid = m < a.M;
+    float enc[NE];
+    tn_load_input<NE>(a.x, m, valid, a.L, h, enc);
+    float out4[4];
+    tn_mlp_tile<HID, NE, TRAIN>(a, enc, m, valid, lane, out4);
+    if (valid && h == 0) {
+        a.rgb_out[3 * m + 0] = out4[0]; a.rgb_out[3 * m + 1] = out4[1]; a.rgb_out[3 * m + 2] = out4[2];
+        a.sigma_out[m] = out4[3];
+        if (TRAIN) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a.stash[(int64_t)(a.L.out_row0 + i) * a.Mp + m] = out4[i];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------ fused rays
+template <int HID, int NE, bool TRAIN>
+__global__ __launch_bounds__(256, 1) void k_render_fused(FwdArgs a) {
+    const int lane = tn_lane();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t ray = (int64_t)blockIdx.x * 4 + wave;
+    if (ray >= a.R) return;
+    const int j = lane & 31, h = lane >> 5;
+    const int S = a.sa.S;
+    const int Lf = (a.L.in_dim - 3) / 6;
+    const float ox = a.rays_o[3 * ray], oy = a.rays_o[3 * ray + 1], oz = a.rays_o[3 * ray + 2];
+    const float dx = a.rays_d[3 * ray], dy = a.rays_d[3 * ray + 1], dz = a.rays_d[3 * ray + 2];
+    const float dn = tn_norm3(dx, dy, dz);
+    float T_in = 1.0f, cr = 0.f, cg = 0.f, cb = 0.f, cd = 0.f, ca = 0.f;
+
+    // March the ray 32 samples at a time (ONE inlined copy of the MLP body); every second tile (or the
+    // last one) the 64 lanes composite a segment: lane l <- sample s0 + l.
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int sb = 0; sb < S; sb += 32) {
+        {
+            const int s = sb + j;
+            const bool valid = s < S;
+            const int sc = valid ? s : S - 1;
+            const float z = tn_depth(a.sa, ray, sc);
+            const float px = tn_point(ox, dx, z), py = tn_point(oy, dy, z), pz = tn_point(oz, dz, z);
+            float enc[NE];
+            tn_encode_point<NE>(px, py, pz, Lf, h, enc);
+            float res[4];
+            tn_mlp_tile<HID, NE, TRAIN>(a, enc, ray * S + sc, valid, lane, res);
+            const bool upper = (sb & 32) != 0;                            // wave-uniform
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float mv = __shfl(res[i], lane & 31, 64);           // lanes 32..63 <- lanes 0..31
+                v[i] = upper ? (h ? mv : v[i]) : res[i];
+            }
+        }
+        if ((sb & 32) == 0 && sb + 32 < S) continue;                      // wait for the upper half
+        const int s0 = sb & ~63;
+        const int s = s0 + lane;
+        const bool ok = s < S && (s - s0) < ((sb & 32) ? 64 : 32);
+        const int sc = s < S ? s : S - 1;
+        const float z = tn_depth(a.sa, ray, sc);
+        const float zn = (s + 1 < S) ? tn_depth(a.sa, ray, s + 1) : z;
+        const CompTerms t = tn_comp_terms(ok ? v[3] : 0.0f, z, zn, s == S - 1, dn);       // volume.py:18-31
+        const float om = ok ? t.om : 1.0f;
+        const float incl = tn_wave_scan_mul(om, lane);
+        float excl = __shfl_up(incl, 1, 64);
+        if (lane == 0) excl = 1.0f;
+        const float T = T_in * excl;
+        const float w = ok ? t.alpha * T : 0.0f;                                             // volume.py:34
+        cr += w * v[0]; cg += w * v[1]; cb += w * v[2]; cd += w * z; ca += w;                // volume.py:36-38
+        T_in *= __shfl(incl, 63, 64);
+        if (TRAIN && ok) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a.stash[(int64_t)(a.L.out_row0 + i) * a.Mp + ray * S + s] = v[i];
+        }
+    }
+    cr = tn_wave_sum(cr); cg = tn_wave_sum(cg); cb = tn_wave_sum(cb); cd = tn_wave_sum(cd); ca = tn_wave_sum(ca);
+    if (lane == 0) {
+        const float bg = a.white ? (1.0f - ca) : 0.0f;                                       // volume.py:42
+        a.comp[3 * ray] = cr + bg; a.comp[3 * ray + 1] = cg + bg; a.comp[3 * ray + 2] = cb + bg;
+        if (a.depth) a.depth[ray] = cd;
+        if (a.acc) a.acc[ray] = ca;
+    }
+}
+
+// ----------------------------------------------------------------------------------- dispatch
+template <bool FUSED, bool TRAIN>
+static int launch_fwd(const FwdArgs& a, int64_t units, hipStream_t stream, const char* who) {
+    const dim3 grid((unsigned)((units + 3) / 4)), block(256);
+    const int hid = a.L.hidden, ne = a.L.NE;
+#define TN_CASE(H_, N_)                                                                                     \
+    if (hid == H_ && ne == N_) {                                                                            \
+        if (FUSED) hipLaunchKernelGGL((k_render_fused<H_, N_, TRAIN>), grid, block, 0, stream, a);          \
+        else       hipLaunchKernelGGL((k_mlp_fwd<H_, N_, TRAIN>), grid, block, 0, stream, a);               \
+        TN_HIP_CHECK_LAUNCH(who);                                                                           \
+        return TNERF_OK;                                                                                    \
+    }
+    TN_CASE(256, 20) TN_CASE(256, 32) TN_CASE(128, 20) TN_CASE(128, 32)
+#undef TN_CASE
+    tn_set_error("%s: no kernel for hidden=%d, input steps=%d", who, hid, ne);
+    return TNERF_EUNSUPPORTED;
+}
+
+int tn_launch_fwd(const FwdArgs& a, bool fused, bool train, int64_t units, hipStream_t stream, const char* who) {
+    if (fused) return train ? launch_fwd<true, true>(a, units, stream, who) : launch_fwd<true, false>(a, units, stream, who);
+    return train ? launch_fwd<false, true>(a, units, stream, who) : launch_fwd<false, false>(a, units, stream, who);
+}
+
+extern "C" int tnerf_mlp_fwd(const tnerf_mlp_desc* d, const float* packed, const float* x, int64_t M, float* rgb, float* sigma,
+                             float* stash, int64_t Mp, tnerf_stream_t stream) {
+    FwdArgs a{};
+    int rc = tn_build_layout(d, &a.L); if (rc) return rc;
+    if (M < 0 || !packed || !x || !rgb || !sigma || (stash && Mp < M)) {
+        tn_set_error("tnerf_mlp_fwd: M=%lld packed=%p x=%p rgb=%p sigma=%p Mp=%lld", (long long)M, (const void*)packed,
+                     (const void*)x, (void*)rgb, (void*)sigma, (long long)Mp);
+        return TNERF_EINVAL;
+    }
+    if (M == 0) return TNERF_OK;
+    a.packed = packed; a.x = x; a.M = M; a.rgb_out = rgb; a.sigma_out = sigma; a.stash = stash; a.Mp = Mp;
+    const int64_t tiles = (M + 31) / 32;
+    return stash ? launch_fwd<false, true>(a, tiles, (hipStream_t)stream, "tnerf_mlp_fwd")
+                 : launch_fwd<false, false>(a, tiles, (hipStream_t)stream, "tnerf_mlp_fwd");
+}
+
+int tn_fused_args(const char* who, FwdArgs& a, const tnerf_mlp_desc* d, const float* packed, const float* rays_o,
+                      const float* rays_d, int64_t R, int32_t S, const float* ztab, int32_t randomized, const float* t_rand,
+                      uint64_t seed, uint64_t offset, int32_t white) {
+    int rc = tn_build_layout(d, &a.L); if (rc) return rc;
+    if (a.L.in_dim < 9 || (a.L.in_dim - 3) % 6 != 0) {
+        tn_set_error("%s: the fused path needs in_dim = 6L+3 (PositionalEncoding with include_input); got %d", who, a.L.in_dim);
+        return TNERF_EUNSUPPORTED;
+    }
+    if (R < 0 || S < 1 || S > 4096 || !packed || !rays_o || !rays_d || !ztab) {
+        tn_set_error("%s: R=%lld S=%d (1..4096) packed=%p rays_o=%p rays_d=%p ztab=%p", who, (long long)R, S, (const void*)packed,
+                     (const void*)rays_o, (const void*)rays_d, (const void*)ztab);
+        return TNERF_EINVAL;
+    }
+    a.packed = packed; a.rays_o = rays_o; a.rays_d = rays_d; a.R = R;
+    a.sa = SampleArgs{ztab, t_rand, seed, offset, S, randomized ? 1 : 0};
+    a.white = white;
+    return TNERF_OK;
+}
+
+extern "C" int tnerf_render_fused(const tnerf_mlp_desc* d, const float* packed, const float* rays_o, const float* rays_d,
+                                  int64_t R, int32_t S, const float* ztab, int32_t randomized, const float* t_rand,
+                                  uint64_t seed, uint64_t offset, int32_t white, float* comp, float* depth, float* acc,
+                                  tnerf_stream_t stream) {
+    FwdArgs a{};
+    int rc = tn_fused_args("tnerf_render_fused", a, d, packed, rays_o, rays_d, R, S, ztab, randomized, t_rand, seed, offset, white);
+    if (rc) return rc;
+    if (!comp) { tn_set_error("tnerf_render_fused: comp_rgb is NULL"); return TNERF_EINVAL; }
+    if (R == 0) return TNERF_OK;
+    a.comp = comp; a.depth = depth; a.acc = acc;
+    return launch_fwd<true, false>(a, R, (hipStream_t)stream, "tnerf_render_fused");
+}
+
+extern "C" int tnerf_train_fwd_fused(const tnerf_mlp_desc* d, const float* packed, const float* rays_o, const float* rays_d,
+                                     int64_t R, int32_t S, const float* ztab, int32_t randomized, const float* t_rand,
+                                     uint64_t seed, uint64_t offset, int32_t white, float* comp, float* stash, int64_t Mp,
+                                     tnerf_stream_t stream) {
+    FwdArgs a{};
+    int rc = tn_fused_args("tnerf_train_fwd_fused", a, d, packed, rays_o, rays_d, R, S, ztab, randomized, t_rand, seed, offset, white);
+    if (rc) return rc;
+    if (!comp || !stash || Mp < R * S) {
+        tn_set_error("tnerf_train_fwd_fused: comp=%p stash=%p Mp=%lld < R*S=%lld", (void*)comp, (void*)stash, (long long)Mp, (long long)(R * S));
+        return TNERF_EINVAL;
+    }
+    if (R == 0) return TNERF_OK;
+    a.comp = comp; a.stash = stash; a.Mp = Mp;
+    return launch_fwd<true, true>(a, R, (hipStream_t)stream, "tnerf_train_fwd_fused");
+}

@@ -1,0 +1,282 @@
+// Stage kernels: ray generation, stratified sampling, positional encoding and alpha compositing as
+// stand-alone HBM-bound kernels behind the reference's per-function call surface.  (The fused
+// render/train kernels in mlp_fwd.hip / mlp_bwd.hip re-use the same per-lane arithmetic from
+// dev_common.hpp without the HBM intermediates.)
+#include "dev_common.hpp"
+
+// ------------------------------------------------------------------------------------ get_rays
+// reference src/rays.py:15-32.  One thread per pixel, flat index p = row*W + col (meshgrid "xy").
+// Arithmetic order follows what ATen executes on CPU: true fp32 division by focal, the K=3 matmul
+// as mul + 2 fma, F.normalize as x / max(sqrt(sum sq), 1e-12).
+__global__ __launch_bounds__(256) void k_get_rays(int H, int W, float focal, const float* __restrict__ c2w,
+                                                  float* __restrict__ rays_o, float* __restrict__ rays_d) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= (int64_t)H * W) return;
+    const int col = (int)(p % W), row = (int)(p / W);
+    const float cx = __fdiv_rn(__fsub_rn((float)col, (float)(W * 0.5)), focal);
+    const float cy = __fdiv_rn(-__fsub_rn((float)row, (float)(H * 0.5)), focal);
+    const float cz = -1.0f;
+    float w[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float acc = __fmul_rn(cx, c2w[4 * c + 0]);
+        acc = fmaf(cy, c2w[4 * c + 1], acc);
+        acc = fmaf(cz, c2w[4 * c + 2], acc);
+        w[c] = acc;
+    }
+    float s = __fmul_rn(w[0], w[0]);
+    s = fmaf(w[1], w[1], s);
+    s = fmaf(w[2], w[2], s);
+    const float n = fmaxf(sqrtf(s), 1e-12f);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        rays_d[3 * p + c] = __fdiv_rn(w[c], n);
+        if (rays_o) rays_o[3 * p + c] = c2w[4 * c + 3];
+    }
+}
+
+extern "C" int tnerf_get_rays(int32_t H, int32_t W, float focal, const float* c2w, float* rays_o, float* rays_d,
+                              tnerf_stream_t stream) {
+    if (H < 1 || W < 1 || !c2w || !rays_d || !(focal != 0.0f)) {
+        tn_set_error("tnerf_get_rays: H=%d W=%d focal=%g c2w=%p rays_d=%p", H, W, focal, (const void*)c2w, (void*)rays_d);
+        return TNERF_EINVAL;
+    }
+    const int64_t n = (int64_t)H * W;
+    hipLaunchKernelGGL(k_get_rays, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, H, W, focal, c2w, rays_o, rays_d);
+    TN_HIP_CHECK_LAUNCH("tnerf_get_rays");
+    return TNERF_OK;
+}
+
+// ---------------------------------------------------------------------------- sampling (+encode)
+// reference src/sampling.py:16-27.  One thread per sample writes z and the point.
+__global__ __launch_bounds__(256) void k_sample(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                int64_t R, SampleArgs sa, float* __restrict__ z_vals, float* __restrict__ pts) {
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= R * sa.S) return;
+    const int64_t r = m / sa.S; const int s = (int)(m % sa.S);
+    const float z = tn_depth(sa, r, s);
+    if (z_vals) z_vals[m] = z;
+    if (pts) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) pts[3 * m + c] = tn_point(rays_o[3 * r + c], rays_d[3 * r + c], z);
+    }
+}
+
+// reference src/encoding.py:27-33: column order [x | sin(2^k x) cos(2^k x)]_k, xyz innermost.
+// 2^k * x is exact in fp32; sin/cos: tn_sincos (dev_common.hpp), <= 1.5 ulp.
+__device__ __forceinline__ float tn_enc_value(float px, float py, float pz, int e, int include_input) {
+    int f = e;
+    if (include_input) {
+        if (e < 3) return e == 0 ? px : (e == 1 ? py : pz);
+        f = e - 3;
+    }
+    const int k = f / 6, w = f % 6, c = w % 3;
+    float sn, cs;
+    tn_sincos((c == 0 ? px : (c == 1 ? py : pz)) * (float)(1u << k), sn, cs);
+    return w < 3 ? sn : cs;
+}
+
+// One thread per OUTPUT element (coalesced 4-byte stores); the point is recomputed per element.
+__global__ __launch_bounds__(256) void k_encode_rays(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                     int64_t R, SampleArgs sa, int L, int include_input, float* __restrict__ enc) {
+    const int D = 6 * L + (include_input ? 3 : 0);
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R * sa.S * D) return;
+    const int64_t m = i / D; const int e = (int)(i % D);
+    const int64_t r = m / sa.S; const int s = (int)(m % sa.S);
+    const float z = tn_depth(sa, r, s);
+    const float px = tn_point(rays_o[3 * r + 0], rays_d[3 * r + 0], z);
+    const float py = tn_point(rays_o[3 * r + 1], rays_d[3 * r + 1], z);
+    const float pz = tn_point(rays_o[3 * r + 2], rays_d[3 * r + 2], z);
+    enc[i] = tn_enc_value(px, py, pz, e, include_input);
+}
+
+__global__ __launch_bounds__(256) void k_posenc(const float* __restrict__ x, int64_t n, int L, int include_input, float* __restrict__ out) {
+    const int D = 6 * L + (include_input ? 3 : 0);
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * D) return;
+    const int64_t m = i / D; const int e = (int)(i % D);
+    out[i] = tn_enc_value(x[3 * m], x[3 * m + 1], x[3 * m + 2], e, include_input);
+}
+
+extern "C" int tnerf_sample_encode_fwd(const float* rays_o, const float* rays_d, int64_t R, int32_t S,
+                                       const float* ztab, int32_t randomized, const float* t_rand,
+                                       uint64_t seed, uint64_t offset, float* z_vals, float* pts,
+                                       float* enc, int32_t L, int32_t include_input, tnerf_stream_t stream) {
+    if (R < 0 || S < 1 || !rays_o || !rays_d || !ztab) {
+        tn_set_error("tnerf_sample_encode_fwd: R=%lld S=%d rays_o=%p rays_d=%p ztab=%p", (long long)R, S,
+                     (const void*)rays_o, (const void*)rays_d, (const void*)ztab);
+        return TNERF_EINVAL;
+    }
+    if (enc && (L < 0 || L > 16 || 6 * L + (include_input ? 3 : 0) < 1)) { tn_set_error("tnerf_sample_encode_fwd: num_freqs=%d", L); return TNERF_EINVAL; }
+    if (R == 0) return TNERF_OK;
+    SampleArgs sa{ztab, t_rand, seed, offset, S, randomized ? 1 : 0};
+    const int64_t M = R * S;
+    if (z_vals || pts) {
+        hipLaunchKernelGGL(k_sample, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rays_o, rays_d, R, sa, z_vals, pts);
+        TN_HIP_CHECK_LAUNCH("tnerf_sample_encode_fwd/sample");
+    }
+    if (enc) {
+        const int64_t n = M * (6 * L + (include_input ? 3 : 0));
+        hipLaunchKernelGGL(k_encode_rays, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rays_o, rays_d, R, sa, L, include_input, enc);
+        TN_HIP_CHECK_LAUNCH("tnerf_sample_encode_fwd/encode");
+    }
+    return TNERF_OK;
+}
+
+extern "C" int tnerf_posenc_fwd(const float* x, int64_t n, int32_t L, int32_t include_input, float* out, tnerf_stream_t stream) {
+    if (n < 0 || !x || !out || L < 0 || L > 16 || 6 * L + (include_input ? 3 : 0) < 1) {
+        tn_set_error("tnerf_posenc_fwd: n=%lld L=%d x=%p out=%p", (long long)n, L, (const void*)x, (void*)out);
+        return TNERF_EINVAL;
+    }
+    if (n == 0) return TNERF_OK;
+    const int64_t tot = n * (6 * L + (include_input ? 3 : 0));
+    hipLaunchKernelGGL(k_posenc, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, n, L, include_input, out);
+    TN_HIP_CHECK_LAUNCH("tnerf_posenc_fwd");
+    return TNERF_OK;
+}
+
+// ------------------------------------------------------------------------------------ composite
+// reference src/volume.py:18-44.  One ray per wavefront; the S samples are marched in segments of
+// 64 (one per lane) with the transmittance carried in a register between segments; the exclusive
+// cumprod is a wave-shuffle scan.
+__global__ __launch_bounds__(256) void k_composite_fwd(const float* __restrict__ rgb, const float* __restrict__ sigma,
+                                                       const float* __restrict__ z_vals, const float* __restrict__ rays_d,
+                                                       int64_t R, int S, int white, float* __restrict__ comp,
+                                                       float* __restrict__ depth, float* __restrict__ acc, float* __restrict__ weights) {
+    const int lane = tn_lane();
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t r = wave; r < R; r += nwaves) {
+        const float dn = tn_norm3(rays_d[3 * r], rays_d[3 * r + 1], rays_d[3 * r + 2]);
+        float T_in = 1.0f, cr = 0.f, cg = 0.f, cb = 0.f, cd = 0.f, ca = 0.f;
+        for (int s0 = 0; s0 < S; s0 += 64) {
+            const int s = s0 + lane; const bool ok = s < S;
+            const int64_t m = r * S + (ok ? s : S - 1);
+            const float sg = ok ? sigma[m] : 0.0f;
+            const float z = z_vals[m];
+            const float zn = (ok && s + 1 < S) ? z_vals[m + 1] : z;
+            const CompTerms t = tn_comp_terms(sg, z, zn, s == S - 1, dn);
+            const float om = ok ? t.om : 1.0f;
+            const float incl = tn_wave_scan_mul(om, lane);
+            float excl = __shfl_up(incl, 1, 64);
+            if (lane == 0) excl = 1.0f;
+            const float T = T_in * excl;
+            const float w = ok ? t.alpha * T : 0.0f;
+            if (ok) {
+                if (weights) weights[m] = w;
+                cr += w * rgb[3 * m]; cg += w * rgb[3 * m + 1]; cb += w * rgb[3 * m + 2];
+                cd += w * z; ca += w;
+            }
+            T_in *= __shfl(incl, 63, 64);
+        }
+        cr = tn_wave_sum(cr); cg = tn_wave_sum(cg); cb = tn_wave_sum(cb); cd = tn_wave_sum(cd); ca = tn_wave_sum(ca);
+        if (lane == 0) {
+            const float bg = white ? (1.0f - ca) : 0.0f;
+            comp[3 * r] = cr + bg; comp[3 * r + 1] = cg + bg; comp[3 * r + 2] = cb + bg;
+            if (depth) depth[r] = cd;
+            if (acc) acc[r] = ca;
+        }
+    }
+}
+
+// Backward of the above w.r.t. rgb and sigma (closed form of what autograd derives):
+//   dL/dw_i   = g_C.c_i + g_depth z_i + g_acc + g_w_i - [white] sum(g_C)
+//   dL/dc_i   = w_i g_C
+//   dL/da_i   = T_i dL/dw_i - (sum_{k>i} w_k dL/dw_k) / om_i
+//   dL/dsig_i = dL/da_i * delta_i * exp(-sig_i delta_i)
+__global__ __launch_bounds__(256) void k_composite_bwd(const float* __restrict__ rgb, const float* __restrict__ sigma,
+                                                       const float* __restrict__ z_vals, const float* __restrict__ rays_d,
+                                                       int64_t R, int S, int white,
+                                                       const float* __restrict__ g_comp, const float* __restrict__ g_depth,
+                                                       const float* __restrict__ g_acc, const float* __restrict__ g_w,
+                                                       float* __restrict__ d_rgb, float* __restrict__ d_sigma) {
+    const int lane = tn_lane();
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int nseg = (S + 63) / 64;
+    for (int64_t r = wave; r < R; r += nwaves) {
+        const float dn = tn_norm3(rays_d[3 * r], rays_d[3 * r + 1], rays_d[3 * r + 2]);
+        const float gr = g_comp ? g_comp[3 * r] : 0.f, gg = g_comp ? g_comp[3 * r + 1] : 0.f, gb = g_comp ? g_comp[3 * r + 2] : 0.f;
+        const float gd = g_depth ? g_depth[r] : 0.f, ga = g_acc ? g_acc[r] : 0.f;
+        const float gbg = white ? (gr + gg + gb) : 0.f;
+        // transmittance entering each segment: lane g keeps the product of segment g, then an exclusive scan
+        float segprod = 1.0f;
+        if (nseg > 1) {
+            for (int g = 0; g < nseg; ++g) {
+                const int s = g * 64 + lane; const bool ok = s < S;
+                const int64_t m = r * S + (ok ? s : S - 1);
+                const float z = z_vals[m];
+                const float zn = (ok && s + 1 < S) ? z_vals[m + 1] : z;
+                const CompTerms t = tn_comp_terms(ok ? sigma[m] : 0.f, z, zn, s == S - 1, dn);
+                const float p = tn_wave_prod(ok ? t.om : 1.0f);
+                if (lane == g) segprod = p;
+            }
+        }
+        const float seg_incl = tn_wave_scan_mul(segprod, lane);
+        float seg_T = __shfl_up(seg_incl, 1, 64);
+        if (lane == 0) seg_T = 1.0f;
+        float tail = 0.0f;                                   // sum of w_k dL/dw_k over later segments
+        for (int g = nseg - 1; g >= 0; --g) {
+            const int s = g * 64 + lane; const bool ok = s < S;
+            const int64_t m = r * S + (ok ? s : S - 1);
+            const float sg = ok ? sigma[m] : 0.f;
+            const float z = z_vals[m];
+            const float zn = (ok && s + 1 < S) ? z_vals[m + 1] : z;
+            const CompTerms t = tn_comp_terms(sg, z, zn, s == S - 1, dn);
+            const float om = ok ? t.om : 1.0f;
+            const float incl = tn_wave_scan_mul(om, lane);
+            float excl = __shfl_up(incl, 1, 64);
+            if (lane == 0) excl = 1.0f;
+            const float T = __shfl(seg_T, g, 64) * excl;
+            const float w = ok ? t.alpha * T : 0.f;
+            const float c0 = rgb[3 * m], c1 = rgb[3 * m + 1], c2 = rgb[3 * m + 2];
+            float dw = gr * c0 + gg * c1 + gb * c2 + gd * z + ga - gbg;
+            if (g_w && ok) dw += g_w[m];
+            const float v = ok ? w * dw : 0.f;
+            const float suf_incl = tn_wave_suffix_sum(v, lane);
+            const float after = (suf_incl - v) + tail;
+            if (ok) {
+                const float da = T * dw - after / om;
+                d_sigma[m] = (da * t.e) * t.delta;          // autograd's order: exp-backward, then * delta
+                d_rgb[3 * m] = w * gr; d_rgb[3 * m + 1] = w * gg; d_rgb[3 * m + 2] = w * gb;
+            }
+            tail += __shfl(suf_incl, 0, 64);
+        }
+    }
+}
+
+static int composite_check(const char* who, const float* rgb, const float* sigma, const float* z, const float* rd, int64_t R, int S) {
+    if (R < 0 || S < 1 || S > 4096 || !rgb || !sigma || !z || !rd) {
+        tn_set_error("%s: R=%lld S=%d (S<=4096) rgb=%p sigma=%p z=%p rays_d=%p", who, (long long)R, S, (const void*)rgb,
+                     (const void*)sigma, (const void*)z, (const void*)rd);
+        return TNERF_EINVAL;
+    }
+    return TNERF_OK;
+}
+
+static unsigned ray_grid(int64_t R) { const int64_t b = (R + 3) / 4; return (unsigned)(b < 1 ? 1 : (b > 8192 ? 8192 : b)); }
+
+extern "C" int tnerf_composite_fwd(const float* rgb, const float* sigma, const float* z_vals, const float* rays_d,
+                                   int64_t R, int32_t S, int32_t white, float* comp, float* depth, float* acc, float* weights,
+                                   tnerf_stream_t stream) {
+    int rc = composite_check("tnerf_composite_fwd", rgb, sigma, z_vals, rays_d, R, S); if (rc) return rc;
+    if (!comp) { tn_set_error("tnerf_composite_fwd: comp_rgb is NULL"); return TNERF_EINVAL; }
+    if (R == 0) return TNERF_OK;
+    hipLaunchKernelGGL(k_composite_fwd, dim3(ray_grid(R)), dim3(256), 0, (hipStream_t)stream, rgb, sigma, z_vals, rays_d, R, S, white,
+                       comp, depth, acc, weights);
+    TN_HIP_CHECK_LAUNCH("tnerf_composite_fwd");
+    return TNERF_OK;
+}
+
+extern "C" int tnerf_composite_bwd(const float* rgb, const float* sigma, const float* z_vals, const float* rays_d,
+                                   int64_t R, int32_t S, int32_t white, const float* g_comp, const float* g_depth,
+                                   const float* g_acc, const float* g_w, float* d_rgb, float* d_sigma, tnerf_stream_t stream) {
+    int rc = composite_check("tnerf_composite_bwd", rgb, sigma, z_vals, rays_d, R, S); if (rc) return rc;
+    if (!d_rgb || !d_sigma) { tn_set_error("tnerf_composite_bwd: NULL output"); return TNERF_EINVAL; }
+    if (R == 0) return TNERF_OK;
+    hipLaunchKernelGGL(k_composite_bwd, dim3(ray_grid(R)), dim3(256), 0, (hipStream_t)stream, rgb, sigma, z_vals, rays_d, R, S, white,
+                       g_comp, g_depth, g_acc, g_w, d_rgb, d_sigma);
+    TN_HIP_CHECK_LAUNCH("tnerf_composite_bwd");
+    return TNERF_OK;
+}

@@ -1,0 +1,48 @@
+// Internal definitions shared by the host planner and the HIP kernels of libtnerf_hip.so.
+#pragma once
+#include <stdint.h>
+#include "../../include/tnerf.h"
+
+#define TN_MAXD 16          // max hidden layers
+#define TN_MAX_STEPS 32     // max input k-steps (pairs of input columns)
+#define TN_JOB_INTS 16      // int32 per wgrad job record
+#define TN_RED_HDR 260      // int32 header of the reduce table (1 + 64 classes * 4, padded)
+#define TN_RED_MAXCLS 64
+
+// Record layout of one wgrad job (one workgroup).
+enum {
+    JOB_A_ROW0 = 0, JOB_A_ROWS, JOB_B_ROW0, JOB_B_ROWS, JOB_N_AT, JOB_N_BT, JOB_WA,
+    JOB_MBLK0, JOB_MBLKN, JOB_SLAB_OFF, JOB_CLASS, JOB_HAS_BIAS
+};
+
+// Everything the kernels need to know about one model; passed by value as a kernel argument.
+struct MlpLayout {
+    int32_t in_dim, hidden, depth, skip_at;
+    int32_t NE;                 // input k-steps (20 or 32)
+    int32_t NT;                 // hidden/32
+    int16_t emap[TN_MAX_STEPS][2];
+    // packed-weight segment offsets (floats); -1 = absent
+    int64_t fw_bias[TN_MAXD], fw_enc[TN_MAXD], fw_hid[TN_MAXD];
+    int64_t fw_head_bias, fw_head;
+    int64_t bw_hid[TN_MAXD], bw_head;
+    int64_t packed_floats;
+    // flat parameter offsets
+    int64_t p_w[TN_MAXD], p_b[TN_MAXD];
+    int32_t fan_in[TN_MAXD];
+    int64_t p_ws, p_bs, p_wc, p_bc, n_params;
+    // stash rows (feature-major matrices, row stride Mp floats)
+    int32_t enc_row0, h_row0[TN_MAXD], out_row0, dz_row0[TN_MAXD], dzh_row0, stash_rows;
+};
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+// host_plan.cpp
+int  tn_build_layout(const tnerf_mlp_desc* d, MlpLayout* L);   // 0 or TNERF_E*
+void tn_set_error(const char* fmt, ...);
+#ifdef __cplusplus
+}
+#endif
+
+// row of a 32x32 MFMA accumulator register r (0..15) for lane-half h (0/1)
+#define TN_ACC_ROW(r, h) (((r) & 3) + 8 * ((r) >> 2) + 4 * (h))

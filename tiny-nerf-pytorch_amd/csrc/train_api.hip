@@ -1,0 +1,130 @@
+// C-ABI entry points that chain several kernels: backward passes, the whole train step, RCCL.
+#include <dlfcn.h>
+#include <cstring>
+#include "mlp_args.hpp"
+
+static int bwd_common_check(const char* who, const float* packed, float* stash, int64_t Mp, int64_t M, const int32_t* job_table,
+                            int64_t n_jobs, float* slabs, const int32_t* reduce_table, float* grads) {
+    if (!packed || !stash || Mp < M || !job_table || n_jobs < 1 || !slabs || !reduce_table || !grads) {
+        tn_set_error("%s: packed=%p stash=%p Mp=%lld M=%lld jobs=%p n_jobs=%lld slabs=%p reduce=%p grads=%p", who, (const void*)packed,
+                     (void*)stash, (long long)Mp, (long long)M, (const void*)job_table, (long long)n_jobs, (void*)slabs,
+                     (const void*)reduce_table, (void*)grads);
+        return TNERF_EINVAL;
+    }
+    return TNERF_OK;
+}
+
+extern "C" int tnerf_mlp_bwd(const tnerf_mlp_desc* d, const float* packed, int64_t M, const float* d_rgb, const float* d_sigma,
+                             float* stash, int64_t Mp, const int32_t* job_table, int64_t n_jobs, float* slabs,
+                             const int32_t* reduce_table, float* grads, tnerf_stream_t stream) {
+    BwdArgs a{};
+    int rc = tn_build_layout(d, &a.L); if (rc) return rc;
+    if (M < 1 || !d_rgb || !d_sigma) { tn_set_error("tnerf_mlp_bwd: M=%lld d_rgb=%p d_sigma=%p", (long long)M, (const void*)d_rgb, (const void*)d_sigma); return TNERF_EINVAL; }
+    rc = bwd_common_check("tnerf_mlp_bwd", packed, stash, Mp, M, job_table, n_jobs, slabs, reduce_table, grads); if (rc) return rc;
+    a.packed = packed; a.stash = stash; a.Mp = Mp; a.M = M; a.d_rgb = d_rgb; a.d_sigma = d_sigma;
+    hipStream_t s = (hipStream_t)stream;
+    if ((rc = tn_launch_mlp_bwd(a, s))) return rc;
+    if ((rc = tn_launch_wgrad(stash, Mp, M, job_table, n_jobs, slabs, s))) return rc;
+    return tn_launch_reduce(slabs, reduce_table, a.L.n_params, grads, s);
+}
+
+static int train_bwd_impl(const char* who, const tnerf_mlp_desc* d, const float* packed, const float* rays_o, const float* rays_d,
+                          int64_t R, int32_t S, const float* ztab, int32_t randomized, const float* t_rand, uint64_t seed,
+                          uint64_t offset, int32_t white, const float* g_comp, float* stash, int64_t Mp, const int32_t* job_table,
+                          int64_t n_jobs, float* slabs, const int32_t* reduce_table, float* grads, hipStream_t s) {
+    FwdArgs f{};
+    int rc = tn_fused_args(who, f, d, packed, rays_o, rays_d, R, S, ztab, randomized, t_rand, seed, offset, white); if (rc) return rc;
+    if (R < 1 || !g_comp) { tn_set_error("%s: R=%lld g_comp=%p", who, (long long)R, (const void*)g_comp); return TNERF_EINVAL; }
+    rc = bwd_common_check(who, packed, stash, Mp, R * S, job_table, n_jobs, slabs, reduce_table, grads); if (rc) return rc;
+    BwdArgs a{};
+    a.L = f.L; a.packed = packed; a.stash = stash; a.Mp = Mp; a.rays_o = rays_o; a.rays_d = rays_d; a.R = R; a.sa = f.sa;
+    a.white = white; a.g_comp = g_comp;
+    if ((rc = tn_launch_train_bwd(a, s))) return rc;
+    if ((rc = tn_launch_wgrad(stash, Mp, R * S, job_table, n_jobs, slabs, s))) return rc;
+    return tn_launch_reduce(slabs, reduce_table, a.L.n_params, grads, s);
+}
+
+extern "C" int tnerf_train_bwd_fused(const tnerf_mlp_desc* d, const float* packed, const float* rays_o, const float* rays_d,
+                                     int64_t R, int32_t S, const float* ztab, int32_t randomized, const float* t_rand,
+                                     uint64_t seed, uint64_t offset, int32_t white, const float* g_comp, float* stash, int64_t Mp,
+                                     const int32_t* job_table, int64_t n_jobs, float* slabs, const int32_t* reduce_table,
+                                     float* grads, tnerf_stream_t stream) {
+    return train_bwd_impl("tnerf_train_bwd_fused", d, packed, rays_o, rays_d, R, S, ztab, randomized, t_rand, seed, offset, white,
+                          g_comp, stash, Mp, job_table, n_jobs, slabs, reduce_table, grads, (hipStream_t)stream);
+}
+
+extern "C" int tnerf_train_step_fused(const tnerf_mlp_desc* d, const float* packed, const float* rays_o, const float* rays_d,
+                                      const float* target, int64_t R, int32_t S, const float* ztab, int32_t randomized,
+                                      const float* t_rand, uint64_t seed, uint64_t offset, int32_t white, double loss_denominator,
+                                      float* comp_rgb, float* g_comp_ws, float* loss_out, float* stash, int64_t Mp,
+                                      const int32_t* job_table, int64_t n_jobs, float* slabs, const int32_t* reduce_table,
+                                      float* grads, tnerf_stream_t stream) {
+    if (!target || !comp_rgb || !g_comp_ws || !loss_out || !(loss_denominator > 0.0) || R < 1) {
+        tn_set_error("tnerf_train_step_fused: target=%p comp=%p g_ws=%p loss=%p denom=%g R=%lld", (const void*)target, (void*)comp_rgb,
+                     (void*)g_comp_ws, (void*)loss_out, loss_denominator, (long long)R);
+        return TNERF_EINVAL;
+    }
+    int rc = tnerf_train_fwd_fused(d, packed, rays_o, rays_d, R, S, ztab, randomized, t_rand, seed, offset, white, comp_rgb, stash, Mp, stream);
+    if (rc) return rc;
+    if ((rc = tn_launch_loss_grad(comp_rgb, target, R, loss_denominator, g_comp_ws, loss_out, (hipStream_t)stream))) return rc;
+    return train_bwd_impl("tnerf_train_step_fused", d, packed, rays_o, rays_d, R, S, ztab, randomized, t_rand, seed, offset, white,
+                          g_comp_ws, stash, Mp, job_table, n_jobs, slabs, reduce_table, grads, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------ RCCL
+// librccl.so is loaded lazily so that single-GPU users (and the CPU-only symbol test) never need it.
+namespace {
+typedef struct { char internal[128]; } nccl_uid;
+typedef int (*fn_get_uid)(nccl_uid*);
+typedef int (*fn_init_rank)(void**, int, nccl_uid, int);
+typedef int (*fn_destroy)(void*);
+typedef int (*fn_allreduce)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef const char* (*fn_errstr)(int);
+struct Rccl { void* h; fn_get_uid get_uid; fn_init_rank init_rank; fn_destroy destroy; fn_allreduce allreduce; fn_errstr errstr; };
+
+static Rccl* rccl() {
+    static Rccl r{};
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+        for (const char* n : names) { r.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (r.h) break; }
+        if (r.h) {
+            r.get_uid = (fn_get_uid)dlsym(r.h, "ncclGetUniqueId");
+            r.init_rank = (fn_init_rank)dlsym(r.h, "ncclCommInitRank");
+            r.destroy = (fn_destroy)dlsym(r.h, "ncclCommDestroy");
+            r.allreduce = (fn_allreduce)dlsym(r.h, "ncclAllReduce");
+            r.errstr = (fn_errstr)dlsym(r.h, "ncclGetErrorString");
+        }
+    }
+    if (!r.h || !r.get_uid || !r.init_rank || !r.destroy || !r.allreduce) { tn_set_error("RCCL (librccl.so) could not be loaded: %s", dlerror()); return nullptr; }
+    return &r;
+}
+static int rccl_rc(Rccl* r, int code, const char* who) {
+    if (code == 0) return TNERF_OK;
+    tn_set_error("%s: RCCL error %d (%s)", who, code, r->errstr ? r->errstr(code) : "?");
+    return 10000 + code;
+}
+}  // namespace
+
+extern "C" int tnerf_comm_unique_id(void* id128) {
+    if (!id128) { tn_set_error("tnerf_comm_unique_id: NULL"); return TNERF_EINVAL; }
+    Rccl* r = rccl(); if (!r) return TNERF_EUNSUPPORTED;
+    return rccl_rc(r, r->get_uid((nccl_uid*)id128), "ncclGetUniqueId");
+}
+extern "C" int tnerf_comm_init_rank(const void* id128, int32_t n_ranks, int32_t rank, void** comm_out) {
+    if (!id128 || !comm_out || n_ranks < 1 || rank < 0 || rank >= n_ranks) { tn_set_error("tnerf_comm_init_rank: bad arguments"); return TNERF_EINVAL; }
+    Rccl* r = rccl(); if (!r) return TNERF_EUNSUPPORTED;
+    nccl_uid u; memcpy(&u, id128, sizeof(u));
+    return rccl_rc(r, r->init_rank(comm_out, n_ranks, u, rank), "ncclCommInitRank");
+}
+extern "C" int tnerf_comm_destroy(void* comm) {
+    if (!comm) return TNERF_OK;
+    Rccl* r = rccl(); if (!r) return TNERF_EUNSUPPORTED;
+    return rccl_rc(r, r->destroy(comm), "ncclCommDestroy");
+}
+extern "C" int tnerf_allreduce_grads(void* comm, float* grads, int64_t n, tnerf_stream_t stream) {
+    if (!comm || !grads || n < 1) { tn_set_error("tnerf_allreduce_grads: comm=%p grads=%p n=%lld", comm, (void*)grads, (long long)n); return TNERF_EINVAL; }
+    Rccl* r = rccl(); if (!r) return TNERF_EUNSUPPORTED;
+    return rccl_rc(r, r->allreduce(grads, grads, (size_t)n, /*ncclFloat32*/ 7, /*ncclSum*/ 0, comm, (hipStream_t)stream), "ncclAllReduce");
+}

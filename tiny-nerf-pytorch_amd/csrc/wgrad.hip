@@ -1,0 +1,266 @@
+// Weight-gradient GEMMs, slab reduction, weight packing, loss gradient and Adam.
+//
+// wgrad: for every layer  dW[n][k] = sum_m dZ^T[n][m] * X^T[k][m]   (X = the layer's input)
+// Both operands are rows of the feature-major stash ([row][sample], row stride Mp), so an MFMA
+// fragment "lane = row, 4 consecutive samples" is one 16-byte piece of a row.  A workgroup
+// (4 waves, one per SIMD) owns one (A rows x B rows) block of up to 256x256 outputs for one chunk
+// of samples: the 4 waves split it 2x2 / 4x1 / 1x4 (<= 4x4 tiles of 32x32 = 256 accumulator
+// registers per wave).  Per 32-sample step the workgroup stages [rows][32] of A and B through LDS
+// in whole 128-byte lines (global -> registers -> LDS, next block in flight during the MFMAs),
+// XOR-swizzled so that the ds_read_b128 fragment reads are bank-conflict free.  Each workgroup
+// writes its partial block to its own slab; a gather-reduce kernel sums the slabs in a fixed
+// order into the flat gradient (deterministic: no float atomics).
+#include "mlp_core.hpp"
+#include "mlp_args.hpp"
+
+#define WG_LDS_ROWS 256                       // per operand
+#define WG_LDS_FLOATS (2 * 2 * WG_LDS_ROWS * 32)
+
+// LDS image of one operand block: row r holds its 8 16-byte chunks permuted by (r>>1)&7.
+__device__ __forceinline__ int wg_lds_off(int row, int chunk) { return row * 32 + ((chunk ^ ((row >> 1) & 7)) << 2); }
+
+template <int TA, int TB>
+__device__ __forceinline__ void wgrad_body(const float* __restrict__ stash, int64_t Mp, int64_t M, const int32_t* __restrict__ job,
+                                           float* __restrict__ slabs, float* lds) {
+    const int tid = (int)threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_at = job[JOB_N_AT], n_bt = job[JOB_N_BT], WA = job[JOB_WA];
+    const int a_rows = job[JOB_A_ROWS], b_rows = job[JOB_B_ROWS];
+    const int64_t a_row0 = job[JOB_A_ROW0], b_row0 = job[JOB_B_ROW0];
+    const int blk0 = job[JOB_MBLK0], nblk = job[JOB_MBLKN];
+    const int wa = wave % WA, wb = wave / WA;
+    const int a_t0 = wa * TA, b_t0 = wb * TB;                  // first tile of this wave
+    const int rows_a = n_at * 32, rows_b = n_bt * 32, rows = rows_a + rows_b;
+    constexpr int MAXLD = (2 * WG_LDS_ROWS) / 32;              // 16 row-groups of 32 rows
+
+    f32x16 acc[TA][TB];
+#pragma unroll
+    for (int i = 0; i < TA; ++i)
+#pragma unroll
+        for (int j = 0; j < TB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    float bsum[TA];
+#pragma unroll
+    for (int i = 0; i < TA; ++i) bsum[i] = 0.0f;
+
+    // staging: thread -> (row within a 32-row group = tid>>3, 16-byte chunk = tid&7)
+    const int srow = tid >> 3, schunk = tid & 7;
+    f32x4 stage[MAXLD];
+    auto stage_load = [&](int blk) TN_INLINE_LAMBDA {
+        const int64_t m0 = (int64_t)blk * 32 + schunk * 4;
+        tn_static_for<MAXLD>([&](auto gc) TN_INLINE_LAMBDA {
+            constexpr int g = decltype(gc)::value;
+            const int row = g * 32 + srow;                                   // combined A|B row index
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (row < rows) {
+                const bool isA = row < rows_a;
+                const int lr = isA ? row : row - rows_a;
+                const bool live = lr < (isA ? a_rows : b_rows);
+                if (live) {
+                    const float* src = stash + ((isA ? a_row0 : b_row0) + lr) * Mp + m0;
+                    v = *reinterpret_cast<const f32x4*>(src);
+                    if (m0 + 3 >= M) {                                       // tail: the pad of the stash is not zeroed
+                        if (m0 + 0 >= M) v[0] = 0.f;
+                        if (m0 + 1 >= M) v[1] = 0.f;
+                        if (m0 + 2 >= M) v[2] = 0.f;
+                        if (m0 + 3 >= M) v[3] = 0.f;
+                    }
+                }
+            }
+            stage[g] = v;
+        });
+    };
+    auto stage_store = [&](int buf) TN_INLINE_LAMBDA {
+        float* base = lds + buf * (2 * WG_LDS_ROWS * 32);
+        tn_static_for<MAXLD>([&](auto gc) TN_INLINE_LAMBDA {
+            constexpr int g = decltype(gc)::value;
+            const int row = g * 32 + srow;
+            if (row < rows) {
+                const bool isA = row < rows_a;
+                const int lr = isA ? row : row - rows_a;
+                float* dst = base + (isA ? 0 : WG_LDS_ROWS * 32) + wg_lds_off(lr, schunk);
+                *reinterpret_cast<f32x4*>(dst) = stage[g];
+            }
+        });
+    };
+
+    const int frow = lane & 31, fh = lane >> 5;
+    const bool active = (a_t0 < n_at) && (b_t0 < n_bt);
+    const bool do_bias = job[JOB_HAS_BIAS] && wb == 0;
+
+    if (nblk > 0) { stage_load(blk0); stage_store(0); }
+    __syncthreads();
+    for (int b = 0; b < nblk; ++b) {
+        const bool more = b + 1 < nblk;
+        if (more) stage_load(blk0 + b + 1);
+        if (active) {
+            const float* A = lds + (b & 1) * (2 * WG_LDS_ROWS * 32);
+            const float* B = A + WG_LDS_ROWS * 32;
+#pragma unroll 1
+            for (int q = 0; q < 4; ++q) {
+                f32x4 fa[TA], fb[TB];
+#pragma unroll
+                for (int i = 0; i < TA; ++i) fa[i] = *reinterpret_cast<const f32x4*>(A + wg_lds_off((a_t0 + i) * 32 + frow, 2 * q + fh));
+#pragma unroll
+                for (int j = 0; j < TB; ++j) fb[j] = *reinterpret_cast<const f32x4*>(B + wg_lds_off((b_t0 + j) * 32 + frow, 2 * q + fh));
+#pragma unroll
+                for (int i = 0; i < TA; ++i) {
+                    if (do_bias) bsum[i] += (fa[i][0] + fa[i][1]) + (fa[i][2] + fa[i][3]);
+#pragma unroll
+                    for (int j = 0; j < TB; ++j) {
+                        acc[i][j] = TN_MFMA(fa[i][0], fb[j][0], acc[i][j]); acc[i][j] = TN_MFMA(fa[i][1], fb[j][1], acc[i][j]);
+                        acc[i][j] = TN_MFMA(fa[i][2], fb[j][2], acc[i][j]); acc[i][j] = TN_MFMA(fa[i][3], fb[j][3], acc[i][j]);
+                    }
+                }
+            }
+        }
+        if (more) stage_store((b + 1) & 1);
+        __syncthreads();
+    }
+
+    // epilogue: partial block -> this workgroup's slab  [n_at*32][n_bt*32] then bias [n_at*32]
+    if (active) {
+        float* slab = slabs + job[JOB_SLAB_OFF];
+        const int ld = n_bt * 32;
+#pragma unroll
+        for (int i = 0; i < TA; ++i)
+#pragma unroll
+            for (int j = 0; j < TB; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    slab[(int64_t)((a_t0 + i) * 32 + TN_ACC_ROW(r, fh)) * ld + (b_t0 + j) * 32 + frow] = acc[i][j][r];
+        if (do_bias) {
+#pragma unroll
+            for (int i = 0; i < TA; ++i) {
+                const float tot = bsum[i] + __shfl_xor(bsum[i], 32, 64);
+                if (fh == 0) slab[(int64_t)n_at * 32 * ld + (a_t0 + i) * 32 + frow] = tot;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void k_wgrad(const float* __restrict__ stash, int64_t Mp, int64_t M,
+                                                  const int32_t* __restrict__ jobs, float* __restrict__ slabs) {
+    __shared__ __attribute__((aligned(16))) float lds[WG_LDS_FLOATS];
+    const int32_t* job = jobs + (int64_t)blockIdx.x * TN_JOB_INTS;
+    const int n_at = job[JOB_N_AT], n_bt = job[JOB_N_BT], WA = job[JOB_WA], WB = 4 / WA;
+    const int ta = n_at / WA, tb = n_bt / WB;               // host plan guarantees exact division (or a 1-tile remainder wave)
+    const int key = (ta > 0 ? ta : 1) * 8 + (tb > 0 ? tb : 1);
+    switch (key) {
+        case 4 * 8 + 4: wgrad_body<4, 4>(stash, Mp, M, job, slabs, lds); break;
+        case 2 * 8 + 2: wgrad_body<2, 2>(stash, Mp, M, job, slabs, lds); break;
+        case 1 * 8 + 2: wgrad_body<1, 2>(stash, Mp, M, job, slabs, lds); break;
+        case 2 * 8 + 1: wgrad_body<2, 1>(stash, Mp, M, job, slabs, lds); break;
+        case 1 * 8 + 1: wgrad_body<1, 1>(stash, Mp, M, job, slabs, lds); break;
+        default: break;   // unreachable: shapes are validated on the host (tnerf_plan_fill)
+    }
+}
+
+int tn_launch_wgrad(const float* stash, int64_t Mp, int64_t M, const int32_t* jobs, int64_t n_jobs, float* slabs, hipStream_t stream) {
+    hipLaunchKernelGGL(k_wgrad, dim3((unsigned)n_jobs), dim3(256), 0, stream, stash, Mp, M, jobs, slabs);
+    TN_HIP_CHECK_LAUNCH("wgrad");
+    return TNERF_OK;
+}
+
+// grads[i] = sum over the chunks of its job class of slab[off + c * stride]   (fixed order)
+__global__ __launch_bounds__(256) void k_reduce(const float* __restrict__ slabs, const int32_t* __restrict__ table,
+                                                int64_t n_params, float* __restrict__ grads) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_params) return;
+    const int32_t off = table[TN_RED_HDR + 2 * i], cls = table[TN_RED_HDR + 2 * i + 1];
+    const int64_t base = (int64_t)table[1 + 4 * cls] + off;
+    const int64_t stride = table[1 + 4 * cls + 1];
+    const int n = table[1 + 4 * cls + 2];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int c = 0;
+    for (; c + 3 < n; c += 4) {
+        s0 += slabs[base + (int64_t)c * stride];       s1 += slabs[base + (int64_t)(c + 1) * stride];
+        s2 += slabs[base + (int64_t)(c + 2) * stride]; s3 += slabs[base + (int64_t)(c + 3) * stride];
+    }
+    for (; c < n; ++c) s0 += slabs[base + (int64_t)c * stride];
+    grads[i] = (s0 + s1) + (s2 + s3);
+}
+
+int tn_launch_reduce(const float* slabs, const int32_t* table, int64_t n_params, float* grads, hipStream_t stream) {
+    hipLaunchKernelGGL(k_reduce, dim3((unsigned)((n_params + 255) / 256)), dim3(256), 0, stream, slabs, table, n_params, grads);
+    TN_HIP_CHECK_LAUNCH("wgrad/reduce");
+    return TNERF_OK;
+}
+
+// ------------------------------------------------------------------------------- pack
+__global__ __launch_bounds__(256) void k_pack(const float* __restrict__ params, const int32_t* __restrict__ table, int64_t n,
+                                              float* __restrict__ packed) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t s = table[i];
+    packed[i] = s >= 0 ? params[s] : 0.0f;
+}
+
+extern "C" int tnerf_mlp_pack(const float* params, const int32_t* pack_table, int64_t packed_floats, float* packed, tnerf_stream_t stream) {
+    if (!params || !pack_table || !packed || packed_floats < 1) {
+        tn_set_error("tnerf_mlp_pack: params=%p table=%p packed=%p n=%lld", (const void*)params, (const void*)pack_table, (void*)packed, (long long)packed_floats);
+        return TNERF_EINVAL;
+    }
+    hipLaunchKernelGGL(k_pack, dim3((unsigned)((packed_floats + 255) / 256)), dim3(256), 0, (hipStream_t)stream, params, pack_table, packed_floats, packed);
+    TN_HIP_CHECK_LAUNCH("tnerf_mlp_pack");
+    return TNERF_OK;
+}
+
+// ------------------------------------------------------------------------------- loss
+// loss = sum((comp - target)^2) / denom ; g = 2 (comp - target) / denom      [reference src/train.py:122]
+// One workgroup, fixed summation order (deterministic).
+__global__ __launch_bounds__(1024) void k_loss_grad(const float* __restrict__ comp, const float* __restrict__ target, int64_t n,
+                                                    float inv_denom, float* __restrict__ g, float* __restrict__ loss_out) {
+    __shared__ float part[16];
+    float s = 0.0f;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) {
+        const float d = comp[i] - target[i];
+        s += d * d;
+        g[i] = (2.0f * d) * inv_denom;
+    }
+    s = tn_wave_sum(s);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.0f;
+        for (int w = 0; w < 16; ++w) t += part[w];
+        loss_out[0] = t * inv_denom;
+    }
+}
+
+int tn_launch_loss_grad(const float* comp, const float* target, int64_t R, double denom, float* g_comp, float* loss_out, hipStream_t stream) {
+    hipLaunchKernelGGL(k_loss_grad, dim3(1), dim3(1024), 0, stream, comp, target, R * 3, (float)(1.0 / denom), g_comp, loss_out);
+    TN_HIP_CHECK_LAUNCH("train_step/loss");
+    return TNERF_OK;
+}
+
+// ------------------------------------------------------------------------------- Adam
+// torch.optim.Adam (no amsgrad, no weight decay, maximize=False), single-tensor formulation:
+//   m = lerp(m, g, 1-b1); v = b2 v + (1-b2) g^2; p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
+__global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                              float* __restrict__ v, int64_t n, float b1, float b2, float eps,
+                                              float step_size, float inv_sqrt_bc2, float gscale) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float gi = g[i] * gscale;
+    const float mi = m[i] + (gi - m[i]) * (1.0f - b1);
+    const float vi = v[i] * b2 + (gi * gi) * (1.0f - b2);
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+    p[i] = p[i] - step_size * (mi / denom);
+}
+
+extern "C" int tnerf_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                               float beta1, float beta2, float eps, int64_t step, float grad_scale, tnerf_stream_t stream) {
+    if (!params || !grads || !exp_avg || !exp_avg_sq || n < 1 || step < 1) {
+        tn_set_error("tnerf_adam_step: n=%lld step=%lld or NULL buffer", (long long)n, (long long)step);
+        return TNERF_EINVAL;
+    }
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipLaunchKernelGGL(k_adam, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, n,
+                       beta1, beta2, eps, (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), grad_scale);
+    TN_HIP_CHECK_LAUNCH("tnerf_adam_step");
+    return TNERF_OK;
+}

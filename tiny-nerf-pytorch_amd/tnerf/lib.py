@@ -1,0 +1,95 @@
+"""ctypes binding of libtnerf_hip.so (include/tnerf.h).  There is NO fallback: if the library is
+missing or a call fails, a RuntimeError is raised."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtnerf_hip.so")
+
+OK, EINVAL, EUNSUPPORTED, ESMALL = 0, -1, -2, -3
+
+
+class MlpDesc(C.Structure):
+    _fields_ = [("in_dim", C.c_int32), ("hidden", C.c_int32), ("depth", C.c_int32), ("skip_at", C.c_int32)]
+
+
+class PlanSizes(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("n_params", "packed_floats", "stash_floats", "slab_floats", "job_ints",
+                                         "reduce_ints", "n_jobs", "stash_row_stride")]
+
+
+_P = C.c_void_p           # device pointers travel as integers (tensor.data_ptr())
+_I32, _I64, _U64, _F, _D = C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_double
+_DESC = C.POINTER(MlpDesc)
+
+# name -> (restype, argtypes); mirrors include/tnerf.h one to one
+SIGNATURES = {
+    "tnerf_version": (C.c_int, []),
+    "tnerf_last_error_string": (C.c_char_p, []),
+    "tnerf_sample_tables": (C.c_int, [_F, _F, _I32, _P, _P]),
+    "tnerf_param_count": (_I64, [_DESC]),
+    "tnerf_param_layout": (C.c_int, [_DESC, _P, _P, _P]),
+    "tnerf_input_pairing": (C.c_int, [_I32, _P, _P]),
+    "tnerf_plan_sizes_query": (C.c_int, [_DESC, _I64, _I32, C.POINTER(PlanSizes)]),
+    "tnerf_plan_fill": (C.c_int, [_DESC, _I64, _I32, _P, _P, _P]),
+    "tnerf_get_rays": (C.c_int, [_I32, _I32, _F, _P, _P, _P, _P]),
+    "tnerf_sample_encode_fwd": (C.c_int, [_P, _P, _I64, _I32, _P, _I32, _P, _U64, _U64, _P, _P, _P, _I32, _I32, _P]),
+    "tnerf_posenc_fwd": (C.c_int, [_P, _I64, _I32, _I32, _P, _P]),
+    "tnerf_composite_fwd": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _I32, _P, _P, _P, _P, _P]),
+    "tnerf_composite_bwd": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _I32, _P, _P, _P, _P, _P, _P, _P]),
+    "tnerf_mlp_pack": (C.c_int, [_P, _P, _I64, _P, _P]),
+    "tnerf_mlp_fwd": (C.c_int, [_DESC, _P, _P, _I64, _P, _P, _P, _I64, _P]),
+    "tnerf_mlp_bwd": (C.c_int, [_DESC, _P, _I64, _P, _P, _P, _I64, _P, _I64, _P, _P, _P, _P]),
+    "tnerf_render_fused": (C.c_int, [_DESC, _P, _P, _P, _I64, _I32, _P, _I32, _P, _U64, _U64, _I32, _P, _P, _P, _P]),
+    "tnerf_train_fwd_fused": (C.c_int, [_DESC, _P, _P, _P, _I64, _I32, _P, _I32, _P, _U64, _U64, _I32, _P, _P, _I64, _P]),
+    "tnerf_train_bwd_fused": (C.c_int, [_DESC, _P, _P, _P, _I64, _I32, _P, _I32, _P, _U64, _U64, _I32, _P, _P, _I64,
+                                        _P, _I64, _P, _P, _P, _P]),
+    "tnerf_train_step_fused": (C.c_int, [_DESC, _P, _P, _P, _P, _I64, _I32, _P, _I32, _P, _U64, _U64, _I32, _D,
+                                         _P, _P, _P, _P, _I64, _P, _I64, _P, _P, _P, _P]),
+    "tnerf_adam_step": (C.c_int, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _I64, _F, _P]),
+    "tnerf_comm_unique_id": (C.c_int, [_P]),
+    "tnerf_comm_init_rank": (C.c_int, [_P, _I32, _I32, C.POINTER(C.c_void_p)]),
+    "tnerf_comm_destroy": (C.c_int, [_P]),
+    "tnerf_allreduce_grads": (C.c_int, [_P, _P, _I64, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libtnerf_hip.so once; raise (never fall back) if it is not there."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python __graft_entry__.py build` "
+                "(tiny-nerf-pytorch_amd/csrc/build.sh).  The HIP path has no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)          # AttributeError if the .so does not export it
+            fn.restype, fn.argtypes = res, args
+        if lib.tnerf_version() != 1:
+            raise RuntimeError(f"libtnerf_hip.so ABI version {lib.tnerf_version()} != 1")
+        _lib = lib
+    return _lib
+
+
+def last_error() -> str:
+    return load().tnerf_last_error_string().decode()
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc == 0:
+        return
+    msg = last_error()
+    if rc == EUNSUPPORTED:
+        raise NotImplementedError(f"{what}: {msg}")
+    if rc < 0:
+        raise ValueError(f"{what}: {msg} (code {rc})")
+    raise RuntimeError(f"{what}: HIP/RCCL error {rc}: {msg}")
+
+
+def call(name: str, *args) -> None:
+    check(getattr(load(), name)(*args), name)
