@@ -182,6 +182,20 @@ int tnerf_train_bwd_fused(const tnerf_mlp_desc* d, const float* packed,
                           const int32_t* job_table, int64_t n_jobs, float* slabs,
                           const int32_t* reduce_table, float* grads, tnerf_stream_t stream);
 
+/* The three stages of tnerf_train_bwd_fused as separate calls (same arguments; used to time each kernel):
+ *   dgrad : composite backward + register-resident dgrad chain, fills the dZ rows of the stash
+ *   wgrad : per-layer weight-gradient GEMMs over the stash, one partial slab per workgroup
+ *   reduce: fixed-order sum of the slabs into grads [n_params] (overwritten) */
+int tnerf_train_dgrad_fused(const tnerf_mlp_desc* d, const float* packed,
+                            const float* rays_o, const float* rays_d, int64_t n_rays, int32_t n_samples,
+                            const float* ztab, int32_t randomized, const float* t_rand,
+                            uint64_t seed, uint64_t offset, int32_t white_bkgd,
+                            const float* g_comp, float* stash, int64_t stash_row_stride, tnerf_stream_t stream);
+int tnerf_wgrad(const float* stash, int64_t stash_row_stride, int64_t n_samples_total,
+                const int32_t* job_table, int64_t n_jobs, float* slabs, tnerf_stream_t stream);
+int tnerf_wgrad_reduce(const float* slabs, const int32_t* reduce_table, int64_t n_params, float* grads,
+                       tnerf_stream_t stream);
+
 /* One whole minibatch step up to (not including) the optimizer (train.py:114-126):
  * forward, loss = sum((comp-target)^2)/loss_denominator, backward -> grads (overwritten),
  * loss_out[0] = this batch's loss contribution (device scalar), comp_rgb [R,3].

@@ -1,0 +1,327 @@
+"""Parity of the HIP path (through the C ABI, via the drop-in modules) against the CPU oracle and the
+reference-generated golden fixtures.  Needs a MI355X: `pytest -m gpu`.
+
+Tolerances (BASELINE.json north_star): ray indices / sample bins bit-exact; rendered RGB and PSNR within
+1e-4 (fp32).  Gradients: relative to the largest entry of each tensor (GEMM summation order differs)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, golden_params
+from oracle import tnerf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+RGB_TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def mods():
+    import rays, sampling, encoding, nerf, volume, utils, train   # drop-in call surface (tiny-nerf-pytorch_amd/src)
+    from tnerf import ops, trainer, lib
+    lib.load()
+    return dict(rays=rays, sampling=sampling, encoding=encoding, nerf=nerf, volume=volume, utils=utils, train=train,
+                ops=ops, trainer=trainer, lib=lib)
+
+
+def make_model(mods, cfg, params, dev):
+    m = mods["nerf"].TinyNeRF(cfg["in_dim"], cfg["hidden"], cfg["depth"], cfg["skip_at"]).to(dev)
+    with torch.no_grad():
+        for p, v in zip(m.parameters(), params):
+            p.copy_(v.to(dev))
+    return m
+
+
+def relmax(a, b):
+    return float((a - b).abs().max()) / (float(b.abs().max()) + 1e-30)
+
+
+# ------------------------------------------------------------------------------------- rays
+def test_get_rays(mods, dev):
+    g = load_golden("rays")
+    exact = total = 0
+    for pi in range(3):
+        for (H, W, key) in ((5, 7, "5x7"), (100, 100, "100")):
+            ro, rd = mods["rays"].get_rays(H, W, g["focal"], g["poses"][pi].to(dev))
+            assert ro.shape == (H * W, 3) and rd.shape == (H * W, 3) and rd.dtype == torch.float32
+            assert ro.stride(0) == 0                                      # expand view like the reference
+            ro, rd = ro.cpu(), rd.cpu()
+            if key == "100":
+                idx = g[f"idx_100_{pi}"]; ro, rd = ro[idx], rd[idx]
+            assert torch.equal(ro, g[f"o_{key}_{pi}"])
+            want = g[f"d_{key}_{pi}"]
+            assert float((rd - want).abs().max()) <= 1.2e-7
+            exact += int((rd == want).sum()); total += want.numel()
+    assert exact / total > 0.9, f"only {exact}/{total} direction components bit-identical"
+
+
+# --------------------------------------------------------------------------------- sampling
+@pytest.mark.parametrize("S", [64, 128, 256])
+def test_sample_bins_bit_exact(mods, dev, S):
+    g = load_golden("sampling")
+    ro, rd = g["rays_o"].to(dev), g["rays_d"].to(dev)
+    z, pts, _ = mods["ops"].sample_along_rays(2.0, 6.0, S, ro, rd, False)
+    assert z.stride(0) == 0
+    assert torch.equal(z[:4].cpu(), g[f"z_det_{S}"]) and torch.equal(pts[:4].cpu(), g[f"pts_det_{S}"])
+    z, pts, _ = mods["ops"].sample_along_rays(2.0, 6.0, S, ro, rd, True, t_rand=g[f"u_{S}"].to(dev))
+    assert torch.equal(z.cpu(), g[f"z_rand_{S}"])
+    n = g[f"pts_rand_{S}"].shape[0]
+    assert torch.equal(pts[:n].cpu(), g[f"pts_rand_{S}"])
+
+
+def test_sample_bins_odd_range_and_dropin_signature(mods, dev):
+    g = load_golden("sampling")
+    ro, rd = g["rays_o"].to(dev), g["rays_d"].to(dev)
+    z, pts, _ = mods["ops"].sample_along_rays(0.5, 3.25, 64, ro, rd, True, t_rand=g["u_odd"].to(dev))
+    assert torch.equal(z.cpu(), g["z_odd"]) and torch.equal(pts[:32].cpu(), g["pts_odd"])
+    # drop-in: draws torch.rand on the device like the reference's rand_like
+    torch.manual_seed(3)
+    z1, p1 = mods["sampling"].stratified_samples(2.0, 6.0, 64, ro, rd, randomized=True)
+    torch.manual_seed(3)
+    u = torch.rand(ro.shape[0], 64, device=dev)
+    zo, po = O.stratified(2.0, 6.0, 64, ro.cpu(), rd.cpu(), u.cpu())
+    assert torch.equal(z1.cpu(), zo) and torch.equal(p1.cpu(), po)
+    # in-kernel Philox jitter stays inside each bin
+    z2, _, _ = mods["ops"].sample_along_rays(2.0, 6.0, 64, ro, rd, True, philox=(123, 0))
+    zt = torch.from_numpy(np.array(O.depth_bins(2.0, 6.0, 64)))
+    lo = torch.cat([zt[:1], 0.5 * (zt[1:] + zt[:-1])]); hi = torch.cat([0.5 * (zt[1:] + zt[:-1]), zt[-1:]])
+    z2 = z2.cpu()
+    assert bool(((z2 >= lo) & (z2 <= hi)).all()) and float(z2.std()) > 0.5
+    assert not torch.equal(z2[0], z2[1])
+
+
+# --------------------------------------------------------------------------------- encoding
+@pytest.mark.parametrize("L,inc", [(6, True), (6, False), (10, True), (10, False)])
+def test_encoding(mods, dev, L, inc):
+    g = load_golden("encoding")
+    enc = mods["encoding"].PositionalEncoding(L, inc).to(dev)
+    assert enc.out_dim == O.posenc_dim(L, inc) and tuple(enc.freq_bands.shape) == (L,)
+    want = g[f"enc_L{L}_{int(inc)}"]
+    got = enc(g["x"].to(dev))[: want.shape[0]].cpu()
+    assert got.shape == want.shape
+    assert float((got - want).abs().max()) <= 2.5e-7              # sin/cos within ~2 ulp of ATen's
+    if inc:
+        assert torch.equal(got[:, :3], want[:, :3])
+    with pytest.raises(AssertionError):
+        enc(torch.zeros(4, 2, device=dev))
+    assert enc(g["x"][:10].to(dev).reshape(2, 5, 3)).shape == (2, 5, enc.out_dim)
+
+
+# -------------------------------------------------------------------------------- composite
+@pytest.mark.parametrize("S", [64, 128])
+@pytest.mark.parametrize("white", [True, False])
+def test_composite_fwd_bwd(mods, dev, S, white):
+    g = load_golden("composite")
+    tag = f"{S}_{int(white)}"
+    rgb = g[f"rgb_{S}"].to(dev).requires_grad_(True)
+    sig = g[f"sigma_{S}"].to(dev).requires_grad_(True)
+    comp, depth, acc, w = mods["volume"].volume_render(rgb, sig, g[f"z_{S}"].to(dev), g[f"rd_{S}"].to(dev), white_bkgd=white)
+    assert comp.shape == (96, 3) and depth.shape == (96, 1) and acc.shape == (96, 1) and w.shape == (96, S)
+    for got, key, tol in ((comp, "comp", 2e-6), (acc, "acc", 2e-6), (w, "w", 1e-6), (depth, "depth", 2e-5)):
+        assert float((got.detach().cpu() - g[f"{key}_{tag}"]).abs().max()) <= tol, key
+    (comp * g[f"gC_{tag}"].to(dev)).sum().backward()
+    assert relmax(rgb.grad.cpu(), g[f"drgb_{tag}"]) <= 2e-6
+    ds, want = sig.grad.cpu(), g[f"dsigma_{tag}"]
+    assert ds.shape == want.shape
+    # the 1e10 tail sample makes |d sigma| span 20 orders of magnitude: compare relatively
+    err = (ds - want).abs() / (want.abs() + 1e-4 * float(want.abs().median()) + 1e-30)
+    assert float(err.max()) <= 2e-3, float(err.max())
+    assert bool(((want == 0) == (ds == 0)).all())                  # ReLU / sigma==0 masks identical
+
+
+def test_composite_all_outputs_receive_grad(mods, dev):
+    g = load_golden("composite")
+    S = 64
+    rgb = g[f"rgb_{S}"].to(dev).requires_grad_(True); sig = g[f"sigma_{S}"].to(dev).requires_grad_(True)
+    comp, depth, acc, w = mods["volume"].volume_render(rgb, sig, g[f"z_{S}"].to(dev), g[f"rd_{S}"].to(dev))
+    ((comp * g[f"all_gC_{S}"].to(dev)).sum() + (depth * g[f"all_gD_{S}"].to(dev)).sum()
+     + (acc * g[f"all_gA_{S}"].to(dev)).sum() + (w * g[f"all_gW_{S}"].to(dev)).sum()).backward()
+    assert relmax(rgb.grad.cpu(), g[f"all_drgb_{S}"]) <= 2e-6
+    want = g[f"all_dsigma_{S}"]
+    err = (sig.grad.cpu() - want).abs() / (want.abs() + 1e-4 * float(want.abs().median()) + 1e-30)
+    assert float(err.max()) <= 2e-3
+
+
+def test_psnr(mods, dev):
+    g = load_golden("composite")
+    assert torch.allclose(mods["utils"].mse2psnr(g["psnr_in"].to(dev)).cpu(), g["psnr_out"], rtol=0, atol=1e-5)
+
+
+# -------------------------------------------------------------------------------------- MLP
+@pytest.mark.parametrize("tag", ["4x128", "8x256"])
+def test_mlp_forward_backward(mods, dev, tag):
+    cfg, params = golden_params(tag)
+    g = load_golden(f"mlp_{tag}")
+    model = make_model(mods, cfg, params, dev)
+    assert list(model.state_dict().keys())[:2] == ["layers.0.weight", "layers.0.bias"]
+    assert "sigma.0.weight" in model.state_dict() and "rgb.0.bias" in model.state_dict()
+    rgb, sigma = model(g["x"].to(dev))
+    assert rgb.shape == g["rgb"].shape and sigma.shape == g["sigma"].shape
+    assert float((rgb.cpu() - g["rgb"]).abs().max()) <= 2e-6
+    assert float((sigma.cpu() - g["sigma"]).abs().max()) <= 1e-5 * max(1.0, float(g["sigma"].abs().max()))
+    ((rgb * g["g_rgb"].to(dev)).sum() + (sigma * g["g_sigma"].to(dev)).sum()).backward()
+    for i, p in enumerate(model.parameters()):
+        assert p.grad is not None and relmax(p.grad.cpu(), g[f"g{i:02d}"]) <= 2e-5, (i, relmax(p.grad.cpu(), g[f"g{i:02d}"]))
+    # ragged row count (not a multiple of 32) and no-grad inference agree with the training forward
+    with torch.no_grad():
+        r2, s2 = model(g["x"][:1001].to(dev))
+    assert torch.equal(r2, rgb[:1001].detach()) and torch.equal(s2, sigma[:1001].detach())
+
+
+def test_mlp_rejects_what_it_cannot_do(mods, dev):
+    m = mods["nerf"].TinyNeRF(39, 256, 8, 4)
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(4, 39))                                        # CPU: no fallback
+    m = m.to(dev)
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(4, 40, device=dev))
+    with pytest.raises(NotImplementedError):
+        mods["nerf"].TinyNeRF(39, 200, 8, 4).to(dev)(torch.zeros(4, 39, device=dev))
+
+
+# -------------------------------------------------------------------------- fused render / train
+@pytest.mark.parametrize("tag", ["4x128", "8x256"])
+def test_render_one_matches_reference_image(mods, dev, tag):
+    cfg, params = golden_params(tag)
+    g = load_golden(f"render_{tag}")
+    model = make_model(mods, cfg, params, dev)
+    enc = mods["encoding"].PositionalEncoding(cfg["L"], True).to(dev)
+    imgs = []
+    for chunk in (8192, 1000, 77):
+        img = mods["train"].render_one(model, enc, g["H"], g["W"], g["focal"], g["pose"], dev, 64, 2.0, 6.0, chunk).cpu()
+        assert img.shape == g["img"].shape
+        assert float((img - g["img"]).abs().max()) <= RGB_TOL
+        imgs.append(img)
+    assert torch.equal(imgs[0], imgs[1]) and torch.equal(imgs[0], imgs[2])        # chunk invariance, bitwise
+    psnr = float(O.psnr_from_mse(torch.mean((imgs[0] - g["img"]) ** 2)))
+    assert psnr >= 80.0
+    # unfused composition of the per-function ops gives the same picture
+    class Plain(torch.nn.Module):                                                 # not a PositionalEncoding instance
+        def __init__(s, e): super().__init__(); s.e = e
+        def forward(s, x): return s.e(x)
+    img_u = mods["train"].render_one(model, Plain(enc), g["H"], g["W"], g["focal"], g["pose"], dev, 64, 2.0, 6.0, 4096).cpu()
+    assert float((img_u - imgs[0]).abs().max()) <= 2e-5
+
+
+def _step_inputs(g, cfg, step):
+    images, poses, focal = g["images"], g["poses"], g["focal"]
+    N, H, W, _ = images.shape
+    rays = [O.pinhole_rays(H, W, focal, poses[i]) for i in range(N)]
+    i = step % N
+    inds = g["inds"][step]
+    return rays[i][0][inds].contiguous(), rays[i][1][inds].contiguous(), images.reshape(N, H * W, 3)[i, inds].contiguous()
+
+
+@pytest.mark.parametrize("tag", ["4x128", "8x256"])
+def test_train_gradients_match_oracle(mods, dev, tag):
+    cfg, params = golden_params(tag)
+    g = load_golden(f"step_{tag}")
+    ro, rd, tgt = _step_inputs(g, cfg, 0)
+    u = g["u"][0]
+    S = u.shape[-1]
+    loss_o, psnr_o, grads_o = O.loss_and_grads(params, cfg["skip_at"], cfg["L"], ro, rd, tgt, 2.0, 6.0, S, u)
+    model = make_model(mods, cfg, params, dev)
+    st, plist = model._ensure_packed(), model._param_list()
+    comp, _, _ = mods["ops"].render_rays_fused(st, plist, ro.to(dev), rd.to(dev), 2.0, 6.0, S, True, t_rand=u.to(dev))
+    assert float((comp.detach().cpu() - g["comp0"]).abs().max()) <= RGB_TOL
+    loss = torch.mean((comp - tgt.to(dev)) ** 2)
+    assert abs(float(loss) - g["loss"][0]) <= 1e-4 * g["loss"][0] + 1e-7
+    assert abs(float(mods["utils"].mse2psnr(loss)) - g["psnr"][0]) <= 1e-4 * abs(g["psnr"][0])
+    loss.backward()
+    worst = 0.0
+    for p, go in zip(plist, grads_o):
+        worst = max(worst, relmax(p.grad.cpu(), go))
+    assert worst <= 5e-4, worst
+    gn = torch.stack([p.grad.norm().cpu() for p in plist])
+    torch.testing.assert_close(gn, g["gnorm0"], rtol=5e-4, atol=1e-9)
+    # unfused autograd path (per-function HIP ops) gives the same gradients
+    m2 = make_model(mods, cfg, params, dev)
+    enc = mods["encoding"].PositionalEncoding(cfg["L"], True).to(dev)
+    z, pts, _ = mods["ops"].sample_along_rays(2.0, 6.0, S, ro.to(dev), rd.to(dev), True, t_rand=u.to(dev))
+    rgb, sig = m2(enc(pts.reshape(-1, 3)))
+    c2, _, _, _ = mods["volume"].volume_render(rgb.reshape(-1, S, 3), sig.reshape(-1, S, 1), z, rd.to(dev))
+    assert float((c2 - comp).abs().max()) <= 2e-5
+    torch.mean((c2 - tgt.to(dev)) ** 2).backward()
+    for p, q in zip(plist, m2.parameters()):
+        assert relmax(q.grad, p.grad) <= 2e-4
+
+
+@pytest.mark.parametrize("tag", ["4x128", "8x256"])
+def test_ten_fused_steps_follow_reference_trajectory(mods, dev, tag):
+    cfg, params = golden_params(tag)
+    g = load_golden(f"step_{tag}")
+    model = make_model(mods, cfg, params, dev)
+    S = g["u"].shape[-1]
+    opt = mods["trainer"].FlatAdam(model, lr=5e-4)
+    tr = mods["trainer"].FusedTrainer(model, opt, 2.0, 6.0, S)
+    for step in range(10):
+        ro, rd, tgt = _step_inputs(g, cfg, step)
+        loss, _ = tr.step(ro.to(dev), rd.to(dev), tgt.to(dev), t_rand=g["u"][step].to(dev))
+        assert math.isclose(float(loss), g["loss"][step], rel_tol=3e-4), (step, float(loss), g["loss"][step])
+    final = [p.detach().cpu() for p in model.parameters()]
+    head = torch.cat([p.reshape(-1)[:64] for p in final])
+    torch.testing.assert_close(head, g["final_head"], rtol=0, atol=5e-5)
+    sums = torch.stack([p.double().sum() for p in final])
+    torch.testing.assert_close(sums, g["final_sum"], rtol=0, atol=1e-2)
+    sd = opt.state_dict()                                     # torch.optim.Adam-shaped state
+    assert set(sd["state"][0].keys()) == {"step", "exp_avg", "exp_avg_sq"} and float(sd["state"][0]["step"]) == 10.0
+
+
+def test_adam_kernel_matches_oracle(mods, dev):
+    cfg, params = golden_params("4x128")
+    model = make_model(mods, cfg, params, dev)
+    opt = mods["trainer"].FlatAdam(model, lr=5e-4)
+    ref = [p.clone() for p in params]
+    ost = O.AdamState(ref, lr=5e-4)
+    gen = torch.Generator().manual_seed(0)
+    for _ in range(5):
+        grads = [torch.randn(p.shape, generator=gen) * 1e-2 for p in ref]
+        for p, gg in zip(model.parameters(), grads):
+            p.grad = gg.to(dev)
+        opt.step()
+        ost.step(ref, grads)
+    for p, r in zip(model.parameters(), ref):
+        assert float((p.detach().cpu() - r).abs().max()) <= 2e-7
+
+
+# ------------------------------------------------------ BASELINE-size properties (no oracle at this size)
+def test_full_size_properties(mods, dev):
+    """cfg 2 shapes: 4096 rays x 64 samples, L=6, 8x256.  Determinism (bitwise), shard additivity of the
+    gradient (what the multi-GPU all-reduce relies on), linearity in dL/dcomp, Philox == explicit jitter."""
+    torch.manual_seed(0)
+    enc_L, R, S = 6, 4096, 64
+    model = mods["nerf"].TinyNeRF(39, 256, 8, 4).to(dev)
+    with torch.no_grad():
+        model.sigma[0].bias += 0.5
+    st, plist = model._ensure_packed(), model._param_list()
+    gen = torch.Generator().manual_seed(1)
+    d = torch.nn.functional.normalize(torch.randn(R, 3, generator=gen), dim=-1)
+    o = (-4.0 * d + 0.3 * torch.randn(R, 3, generator=gen)).to(dev); d = d.to(dev)
+    tgt = torch.rand(R, 3, generator=gen).to(dev); u = torch.rand(R, S, generator=gen).to(dev)
+
+    def grads(lo, hi, scale=1.0):
+        comp, _, _ = mods["ops"].render_rays_fused(st, plist, o[lo:hi], d[lo:hi], 2.0, 6.0, S, True, t_rand=u[lo:hi])
+        loss = scale * ((comp - tgt[lo:hi]) ** 2).sum() / (3.0 * R)
+        gs = torch.autograd.grad(loss, plist)
+        return comp.detach(), torch.cat([x.reshape(-1) for x in gs])
+
+    c1, g1 = grads(0, R); c2, g2 = grads(0, R)
+    assert torch.equal(c1, c2) and torch.equal(g1, g2)                           # deterministic, bit for bit
+    assert bool(torch.isfinite(g1).all()) and float(g1.abs().max()) > 0
+    ca, ga = grads(0, R // 2); cb, gb = grads(R // 2, R)
+    assert torch.equal(torch.cat([ca, cb]), c1)                                  # rays are independent
+    assert float((ga + gb - g1).abs().max()) <= 2e-5 * float(g1.abs().max())    # shard gradients add up
+    _, g3 = grads(0, R, scale=3.0)
+    assert float((g3 - 3.0 * g1).abs().max()) <= 2e-5 * float(g3.abs().max())  # linear in the upstream gradient
+    with torch.no_grad():
+        cp, dp, ap = mods["ops"].render_rays_fused(st, plist, o, d, 2.0, 6.0, S, False)
+        cq, _, _ = mods["ops"].render_rays_fused(st, plist, o, d, 2.0, 6.0, S, False, white_bkgd=False)
+    assert float((cp - (cq + (1.0 - ap))).abs().max()) <= 1e-6                  # white background identity
+    assert bool(((ap >= 0) & (ap <= 1.0 + 1e-5)).all()) and bool(((dp >= 0) & (dp <= 6.0 * 1.0001)).all())

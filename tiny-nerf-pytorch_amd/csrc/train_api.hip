@@ -53,6 +53,31 @@ extern "C" int tnerf_train_bwd_fused(const tnerf_mlp_desc* d, const float* packe
                           g_comp, stash, Mp, job_table, n_jobs, slabs, reduce_table, grads, (hipStream_t)stream);
 }
 
+extern "C" int tnerf_train_dgrad_fused(const tnerf_mlp_desc* d, const float* packed, const float* rays_o, const float* rays_d,
+                                       int64_t R, int32_t S, const float* ztab, int32_t randomized, const float* t_rand,
+                                       uint64_t seed, uint64_t offset, int32_t white, const float* g_comp, float* stash, int64_t Mp,
+                                       tnerf_stream_t stream) {
+    FwdArgs f{};
+    int rc = tn_fused_args("tnerf_train_dgrad_fused", f, d, packed, rays_o, rays_d, R, S, ztab, randomized, t_rand, seed, offset, white);
+    if (rc) return rc;
+    if (R < 1 || !g_comp || !stash || Mp < R * S) { tn_set_error("tnerf_train_dgrad_fused: R=%lld g_comp=%p stash=%p Mp=%lld", (long long)R, (const void*)g_comp, (void*)stash, (long long)Mp); return TNERF_EINVAL; }
+    BwdArgs a{};
+    a.L = f.L; a.packed = packed; a.stash = stash; a.Mp = Mp; a.rays_o = rays_o; a.rays_d = rays_d; a.R = R; a.sa = f.sa;
+    a.white = white; a.g_comp = g_comp;
+    return tn_launch_train_bwd(a, (hipStream_t)stream);
+}
+
+extern "C" int tnerf_wgrad(const float* stash, int64_t Mp, int64_t M, const int32_t* job_table, int64_t n_jobs, float* slabs,
+                           tnerf_stream_t stream) {
+    if (!stash || Mp < M || M < 1 || !job_table || n_jobs < 1 || !slabs) { tn_set_error("tnerf_wgrad: bad arguments"); return TNERF_EINVAL; }
+    return tn_launch_wgrad(stash, Mp, M, job_table, n_jobs, slabs, (hipStream_t)stream);
+}
+
+extern "C" int tnerf_wgrad_reduce(const float* slabs, const int32_t* reduce_table, int64_t n_params, float* grads, tnerf_stream_t stream) {
+    if (!slabs || !reduce_table || n_params < 1 || !grads) { tn_set_error("tnerf_wgrad_reduce: bad arguments"); return TNERF_EINVAL; }
+    return tn_launch_reduce(slabs, reduce_table, n_params, grads, (hipStream_t)stream);
+}
+
 extern "C" int tnerf_train_step_fused(const tnerf_mlp_desc* d, const float* packed, const float* rays_o, const float* rays_d,
                                       const float* target, int64_t R, int32_t S, const float* ztab, int32_t randomized,
                                       const float* t_rand, uint64_t seed, uint64_t offset, int32_t white, double loss_denominator,

@@ -1,0 +1,204 @@
+"""Drop-in for the reference's src/train.py: same Config fields / flags, same render_one signature, same
+loop (round-robin image, randint pixels, gather, sample -> encode -> MLP -> composite, MSE, Adam,
+preview / checkpoint cadence and checkpoint dict keys), with the hot path in libtnerf_hip.so.
+
+Differences that are deliberate: fp32 end to end (the reference switches to fp16 autocast on a
+GPU; the parity target is its fp32 path); `Config.fused` selects the single-call fused step
+(tnerf_train_step_fused + flat Adam) instead of autograd over the per-function ops; tyro / imageio / tqdm
+are optional (absent in the build image): argparse and a built-in PNG writer stand in.
+"""
+import os
+import struct
+import sys
+import time
+import zlib
+from dataclasses import dataclass, fields
+from typing import Optional
+
+import numpy as np
+import torch
+from torch import nn
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _hip import ops, trainer as _trainer, dist as _dist   # noqa: E402
+from data import load_scene                                 # noqa: E402
+from encoding import PositionalEncoding                     # noqa: E402
+from nerf import TinyNeRF                                   # noqa: E402
+from rays import get_rays                                   # noqa: E402
+from sampling import stratified_samples                     # noqa: E402
+from volume import volume_render                            # noqa: E402
+from utils import mse2psnr                                  # noqa: E402
+
+
+@dataclass
+class Config:
+    iters: int = 20000
+    n_rand: int = 2048
+    n_samples: int = 64
+    lr: float = 5e-4
+    near: float = 2.0
+    far: float = 6.0
+    log_every: int = 50
+    preview_every: int = 500
+    ckpt_every: int = 1000
+    ckpt_path: str = "checkpoints/tinynerf_latest.pth"
+    out_dir: str = "outputs"
+    resume: bool = True
+    preview_pose: Optional[int] = None
+    # --- additions (not in the reference) ---
+    fused: bool = True          # fused train step + flat Adam; False = autograd over the per-function HIP ops
+    num_freqs: int = 10         # the reference hard-codes L=10, 4x128, skip 2 (train.py:78-79)
+    hidden: int = 128
+    depth: int = 4
+    skip_at: int = 2
+    data_path: str = "data/tiny_nerf_data.npz"
+
+
+def write_png(path: str, img_u8: np.ndarray) -> None:
+    """Minimal RGB8 PNG writer (imageio is optional)."""
+    h, w, _ = img_u8.shape
+    raw = b"".join(b"\x00" + img_u8[r].tobytes() for r in range(h))
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 0))
+                + chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
+
+
+def _fusable(model, encoder) -> bool:
+    return (isinstance(model, TinyNeRF) and isinstance(encoder, PositionalEncoding) and encoder.include_input
+            and encoder.out_dim == model.in_dim and encoder.num_freqs <= 10)
+
+
+@torch.no_grad()
+def render_one(model: nn.Module, encoder: nn.Module, H: int, W: int, focal: float, pose: torch.Tensor,
+               device: torch.device, n_samples: int = 64, near: float = 2.0, far: float = 6.0,
+               chunk: int = 8192) -> torch.Tensor:
+    """Full image for one pose, chunked over rays, clamped to [0,1].   [reference src/train.py:36-59]
+    Each chunk is ONE fused kernel (rays in, colours out) when model/encoder are this package's."""
+    model.eval()
+    rays_o, rays_d = get_rays(H, W, focal, pose.to(device), device=device)
+    parts = []
+    fused = _fusable(model, encoder)
+    if fused:
+        st, params = model._ensure_packed(), model._param_list()
+    for i in range(0, rays_o.shape[0], chunk):
+        ro, rd = rays_o[i:i + chunk], rays_d[i:i + chunk]
+        if fused:
+            comp, _, _ = ops.render_rays_fused(st, params, ro, rd, near, far, n_samples, randomized=False)
+        else:
+            z_vals, pts = stratified_samples(near, far, n_samples, ro, rd, randomized=False)
+            rgb, sigma = model(encoder(pts.reshape(-1, 3)))
+            comp, _, _, _ = volume_render(rgb.reshape(pts.shape[0], n_samples, 3), sigma.reshape(pts.shape[0], n_samples, 1), z_vals, rd)
+        parts.append(comp)
+    return torch.cat(parts, dim=0).reshape(H, W, 3).clamp(0.0, 1.0)
+
+
+def _save_ckpt(cfg, model, optimizer, step, in_dim):
+    torch.save({"model": model.state_dict(), "opt": optimizer.state_dict(), "step": step, "in_dim": in_dim,
+                "cfg": dict(hidden=cfg.hidden, depth=cfg.depth, skip_at=cfg.skip_at)}, cfg.ckpt_path)
+
+
+def main(cfg: Config):
+    torch.manual_seed(0); np.random.seed(0)                                   # train.py:63
+    if not torch.cuda.is_available():
+        raise RuntimeError("train.py (HIP): no ROCm GPU visible; this package has no CPU path")
+    device = torch.device("cuda")
+    os.makedirs(cfg.out_dir, exist_ok=True)
+    os.makedirs(os.path.dirname(cfg.ckpt_path) or ".", exist_ok=True)
+    print(f"[device] {device} torch={torch.__version__}")
+
+    d = load_scene(cfg.data_path)
+    images = torch.from_numpy(d["images"]).to(device)
+    poses = torch.from_numpy(d["poses"]).to(device)
+    focal = float(d["focal"])
+    N, H, W, _ = images.shape
+    print(f"[data] N={N} H={H} W={W} focal={focal:.2f}" + (" (synthetic stand-in)" if d.get("synthetic") else ""))
+
+    encoder = PositionalEncoding(num_freqs=cfg.num_freqs, include_input=True).to(device)
+    model = TinyNeRF(in_dim=encoder.out_dim, hidden=cfg.hidden, depth=cfg.depth, skip_at=cfg.skip_at).to(device)
+    if cfg.fused:
+        optimizer = _trainer.FlatAdam(model, lr=cfg.lr)
+        step_fn = _trainer.FusedTrainer(model, optimizer, cfg.near, cfg.far, cfg.n_samples)
+    else:
+        optimizer = torch.optim.Adam(model.parameters(), lr=cfg.lr)
+
+    start_step = 0
+    if cfg.resume and os.path.exists(cfg.ckpt_path):                            # train.py:83-92
+        ckpt = torch.load(cfg.ckpt_path, map_location=device)
+        model.load_state_dict(ckpt["model"])
+        if "opt" in ckpt:
+            optimizer.load_state_dict(ckpt["opt"])
+        start_step = int(ckpt.get("step", 0))
+        print(f"[resume] loaded {cfg.ckpt_path} from step {start_step}")
+
+    rays = [get_rays(H, W, focal, poses[i], device=device) for i in range(N)]   # train.py:94-101
+    all_rays_o = torch.stack([r[0] for r in rays], dim=0)
+    all_rays_d = torch.stack([r[1] for r in rays], dim=0)
+    pixels = images.view(N, H * W, 3)
+
+    try:
+        from tqdm import tqdm
+        pbar = tqdm(range(start_step, cfg.iters), desc="train")
+    except ImportError:
+        pbar = range(start_step, cfg.iters)
+    t0 = time.time()
+    for step in pbar:
+        model.train()
+        img_i = step % N
+        inds = torch.randint(0, H * W, (cfg.n_rand,), device=device)             # train.py:109
+        ro, rd, target = all_rays_o[img_i, inds], all_rays_d[img_i, inds], pixels[img_i, inds]
+        if cfg.fused:
+            t_rand = torch.rand(cfg.n_rand, cfg.n_samples, device=device)        # the draw of sampling.py:24
+            loss, _ = step_fn.step(ro, rd, target, t_rand=t_rand)
+            psnr = mse2psnr(loss)
+        else:
+            z_vals, pts = stratified_samples(cfg.near, cfg.far, cfg.n_samples, ro, rd, randomized=True)
+            rgb, sigma = model(encoder(pts.reshape(-1, 3)))
+            comp_rgb, _, _, _ = volume_render(rgb.reshape(cfg.n_rand, cfg.n_samples, 3),
+                                              sigma.reshape(cfg.n_rand, cfg.n_samples, 1), z_vals, rd)
+            loss = torch.mean((comp_rgb - target) ** 2)
+            psnr = mse2psnr(loss)
+            optimizer.zero_grad(set_to_none=True)
+            loss.backward()
+            optimizer.step()
+
+        if (step + 1) % cfg.log_every == 0:
+            msg = dict(loss=float(loss.item()), psnr=float(psnr.item()))
+            pbar.set_postfix(**msg) if hasattr(pbar, "set_postfix") else print(f"[{step + 1}] {msg}")
+        if (step + 1) % cfg.preview_every == 0:
+            pose_idx = (img_i + 1 if cfg.preview_pose is None else cfg.preview_pose) % N
+            img = render_one(model, encoder, H, W, focal, poses[pose_idx], device, n_samples=cfg.n_samples, near=cfg.near, far=cfg.far)
+            write_png(f"{cfg.out_dir}/preview_{step + 1:06d}.png", (img.cpu().numpy() * 255).astype(np.uint8))
+        if (step + 1) % cfg.ckpt_every == 0:
+            _save_ckpt(cfg, model, optimizer, step + 1, encoder.out_dim)
+
+    dt = time.time() - t0
+    _save_ckpt(cfg, model, optimizer, cfg.iters, encoder.out_dim)
+    img = render_one(model, encoder, H, W, focal, poses[-1], device, n_samples=cfg.n_samples, near=cfg.near, far=cfg.far)
+    write_png(f"{cfg.out_dir}/final.png", (img.cpu().numpy() * 255).astype(np.uint8))
+    print(f"[done] {cfg.iters} iters in {dt / 60:.2f} min | saved {cfg.ckpt_path} and {cfg.out_dir}/final.png")
+
+
+def _parse_cli() -> Config:
+    try:
+        import tyro
+        return tyro.cli(Config)
+    except ImportError:
+        import argparse
+        ap = argparse.ArgumentParser()
+        for f in fields(Config):
+            flag = "--" + f.name.replace("_", "-")
+            if f.type is bool:
+                ap.add_argument(flag, action=argparse.BooleanOptionalAction, default=f.default)
+            elif f.name == "preview_pose":
+                ap.add_argument(flag, type=int, default=None)
+            else:
+                ap.add_argument(flag, type=type(f.default), default=f.default)
+        return Config(**vars(ap.parse_args()))
+
+
+if __name__ == "__main__":
+    main(_parse_cli())

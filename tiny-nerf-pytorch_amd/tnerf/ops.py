@@ -1,0 +1,339 @@
+"""Host side of the HIP hot path: torch tensors in, torch tensors out, every FLOP in libtnerf_hip.so.
+
+PyTorch is used here only as plumbing (device memory, the current HIP stream, autograd bookkeeping,
+the random draws the reference takes from torch's generator).  Nothing in this module computes the
+path's arithmetic with torch ops, and nothing falls back to a CPU implementation: CPU tensors or a
+missing library raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import lib as _l
+
+_NULL = None
+
+
+def _stream(dev: torch.device) -> int:
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+def _need_cuda(*ts: torch.Tensor) -> torch.device:
+    dev = None
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("tnerf HIP path: expected tensors on a ROCm GPU (device 'cuda'), got a CPU tensor; "
+                               "there is no CPU fallback in this package")
+        dev = dev or t.device
+        if t.device != dev:
+            raise RuntimeError(f"tnerf HIP path: tensors on different devices ({dev} vs {t.device})")
+    return dev
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+# --------------------------------------------------------------------------------- depth tables
+_ZTAB: Dict[Tuple, torch.Tensor] = {}
+
+
+def depth_table(near: float, far: float, n_samples: int, dev: torch.device) -> torch.Tensor:
+    """Device copy of tnerf_sample_tables(near, far, S): [z | lo | hi], 3*S floats (bit-exact bins)."""
+    key = (float(near), float(far), int(n_samples), str(dev))
+    t = _ZTAB.get(key)
+    if t is None:
+        host = np.empty(3 * n_samples, np.float32)
+        _l.call("tnerf_sample_tables", float(near), float(far), int(n_samples), host.ctypes.data_as(C.c_void_p), None)
+        t = torch.from_numpy(host).to(dev)
+        if len(_ZTAB) > 64:
+            _ZTAB.clear()
+        _ZTAB[key] = t
+    return t
+
+
+# ----------------------------------------------------------------------------------- stage ops
+def get_rays(H: int, W: int, focal: float, c2w: torch.Tensor, want_origin_copy: bool = False):
+    dev = _need_cuda(c2w)
+    c2w = _f32c(c2w)
+    if c2w.shape != (4, 4):
+        raise ValueError(f"c2w must be (4,4), got {tuple(c2w.shape)}")
+    rays_d = torch.empty(H * W, 3, dtype=torch.float32, device=dev)
+    rays_o = torch.empty(H * W, 3, dtype=torch.float32, device=dev) if want_origin_copy else None
+    _l.call("tnerf_get_rays", int(H), int(W), float(focal), c2w.data_ptr(), _ptr(rays_o), rays_d.data_ptr(), _stream(dev))
+    if rays_o is None:
+        rays_o = c2w[:3, 3].expand(H * W, 3)          # stride-0 view, as the reference returns
+    return rays_o, rays_d
+
+
+def _rng_args(randomized: bool, t_rand: Optional[torch.Tensor], philox: Optional[Tuple[int, int]]):
+    if not randomized:
+        return 0, None, 0, 0
+    if t_rand is not None:
+        return 1, t_rand, 0, 0
+    if philox is None:
+        raise ValueError("randomized sampling needs t_rand or a (seed, offset) pair")
+    return 1, None, int(philox[0]), int(philox[1])
+
+
+def sample_along_rays(near: float, far: float, n_samples: int, rays_o: torch.Tensor, rays_d: torch.Tensor,
+                      randomized: bool, t_rand: Optional[torch.Tensor] = None, philox=None,
+                      want_pts: bool = True, encode: Optional[Tuple[int, bool]] = None):
+    dev = _need_cuda(rays_o, rays_d, t_rand)
+    rays_o, rays_d = _f32c(rays_o), _f32c(rays_d)
+    R, S = rays_o.shape[0], int(n_samples)
+    ztab = depth_table(near, far, S, dev)
+    rnd, tr, seed, off = _rng_args(randomized, t_rand, philox)
+    if tr is not None:
+        tr = _f32c(tr)
+        if tr.shape != (R, S):
+            raise ValueError(f"t_rand must be ({R},{S})")
+    z = torch.empty(R, S, dtype=torch.float32, device=dev) if (randomized or want_pts) else None
+    pts = torch.empty(R, S, 3, dtype=torch.float32, device=dev) if want_pts else None
+    enc = None
+    L, inc = (0, 1)
+    if encode is not None:
+        L, inc = int(encode[0]), int(bool(encode[1]))
+        enc = torch.empty(R * S, 6 * L + 3 * inc, dtype=torch.float32, device=dev)
+    _l.call("tnerf_sample_encode_fwd", rays_o.data_ptr(), rays_d.data_ptr(), R, S, ztab.data_ptr(), rnd, _ptr(tr), seed, off,
+            _ptr(z), _ptr(pts), _ptr(enc), L, inc, _stream(dev))
+    if not randomized:
+        z = ztab[:S].expand(R, S)                      # stride-0 view, as the reference returns
+    return z, pts, enc
+
+
+def posenc(x: torch.Tensor, num_freqs: int, include_input: bool) -> torch.Tensor:
+    dev = _need_cuda(x)
+    lead = x.shape[:-1]
+    xf = _f32c(x).reshape(-1, 3)
+    D = 6 * num_freqs + (3 if include_input else 0)
+    out = torch.empty(xf.shape[0], D, dtype=torch.float32, device=dev)
+    _l.call("tnerf_posenc_fwd", xf.data_ptr(), xf.shape[0], int(num_freqs), int(bool(include_input)), out.data_ptr(), _stream(dev))
+    return out.reshape(*lead, D)
+
+
+class _Composite(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rgb, sigma, z_vals, rays_d, white_bkgd):
+        dev = _need_cuda(rgb, sigma, z_vals, rays_d)
+        rgb, sigma, z_vals, rays_d = _f32c(rgb), _f32c(sigma), _f32c(z_vals), _f32c(rays_d)
+        R, S = z_vals.shape
+        comp = torch.empty(R, 3, dtype=torch.float32, device=dev)
+        depth = torch.empty(R, 1, dtype=torch.float32, device=dev)
+        acc = torch.empty(R, 1, dtype=torch.float32, device=dev)
+        w = torch.empty(R, S, dtype=torch.float32, device=dev)
+        _l.call("tnerf_composite_fwd", rgb.data_ptr(), sigma.data_ptr(), z_vals.data_ptr(), rays_d.data_ptr(), R, S,
+                int(bool(white_bkgd)), comp.data_ptr(), depth.data_ptr(), acc.data_ptr(), w.data_ptr(), _stream(dev))
+        ctx.save_for_backward(rgb, sigma, z_vals, rays_d)
+        ctx.white = int(bool(white_bkgd))
+        ctx.sigma_shape = sigma.shape
+        return comp, depth, acc, w
+
+    @staticmethod
+    def backward(ctx, g_comp, g_depth, g_acc, g_w):
+        rgb, sigma, z_vals, rays_d = ctx.saved_tensors
+        dev = rgb.device
+        R, S = z_vals.shape
+        gs = [None if g is None else _f32c(g) for g in (g_comp, g_depth, g_acc, g_w)]
+        d_rgb = torch.empty_like(rgb)
+        d_sigma = torch.empty(ctx.sigma_shape, dtype=torch.float32, device=dev)
+        _l.call("tnerf_composite_bwd", rgb.data_ptr(), sigma.data_ptr(), z_vals.data_ptr(), rays_d.data_ptr(), R, S, ctx.white,
+                _ptr(gs[0]), _ptr(gs[1]), _ptr(gs[2]), _ptr(gs[3]), d_rgb.data_ptr(), d_sigma.data_ptr(), _stream(dev))
+        return d_rgb, d_sigma, None, None, None
+
+
+def volume_render(rgb, sigma, z_vals, rays_d, white_bkgd=True):
+    if z_vals.requires_grad or rays_d.requires_grad:
+        raise NotImplementedError("volume_render (HIP): gradients w.r.t. z_vals / rays_d are not implemented "
+                                  "(the reference never asks for them)")
+    return _Composite.apply(rgb, sigma, z_vals, rays_d, white_bkgd)
+
+
+# ------------------------------------------------------------------------------- model state
+class _Plan:
+    """Buffers and tables for one (model, sample count): stash, slabs, wgrad jobs, reduce table."""
+
+    def __init__(self, st: "ModelState", M: int):
+        dev = st.device
+        sz = _l.PlanSizes()
+        _l.call("tnerf_plan_sizes_query", C.byref(st.desc), int(M), st.n_cu, C.byref(sz))
+        jobs = np.empty(sz.job_ints, np.int32)
+        red = np.empty(sz.reduce_ints, np.int32)
+        _l.call("tnerf_plan_fill", C.byref(st.desc), int(M), st.n_cu, None, jobs.ctypes.data_as(C.c_void_p),
+                red.ctypes.data_as(C.c_void_p))
+        self.M, self.Mp, self.n_jobs = int(M), int(sz.stash_row_stride), int(sz.n_jobs)
+        self.jobs = torch.from_numpy(jobs).to(dev)
+        self.reduce = torch.from_numpy(red).to(dev)
+        self.stash = torch.empty(sz.stash_floats, dtype=torch.float32, device=dev)
+        self.slabs = torch.empty(sz.slab_floats, dtype=torch.float32, device=dev)
+
+
+class ModelState:
+    """Device-side state of one TinyNeRF: flat fp32 parameters (the nn.Parameters are views into it),
+    the MFMA-fragment-packed copy of the weights and the per-batch-size plans."""
+
+    def __init__(self, in_dim: int, hidden: int, depth: int, skip_at: int, device: torch.device):
+        self.device = device
+        self.desc = _l.MlpDesc(int(in_dim), int(hidden), int(depth), int(skip_at))
+        n = _l.load().tnerf_param_count(C.byref(self.desc))
+        if n < 0:
+            _l.check(_l.EUNSUPPORTED, "TinyNeRF (HIP)")
+        self.n_params = int(n)
+        self.n_cu = torch.cuda.get_device_properties(device).multi_processor_count
+        k = 2 * depth + 4
+        off = np.zeros(k, np.int64); rows = np.zeros(k, np.int64); cols = np.zeros(k, np.int64)
+        _l.call("tnerf_param_layout", C.byref(self.desc), off.ctypes.data_as(C.c_void_p), rows.ctypes.data_as(C.c_void_p),
+                cols.ctypes.data_as(C.c_void_p))
+        self.offsets = [int(v) for v in off]
+        sz = _l.PlanSizes()
+        _l.call("tnerf_plan_sizes_query", C.byref(self.desc), 64, self.n_cu, C.byref(sz))
+        self.packed_floats = int(sz.packed_floats)
+        pack = np.empty(self.packed_floats, np.int32)
+        _l.call("tnerf_plan_fill", C.byref(self.desc), 64, self.n_cu, pack.ctypes.data_as(C.c_void_p), None, None)
+        self.pack_table = torch.from_numpy(pack).to(device)
+        self.flat = torch.zeros(self.n_params, dtype=torch.float32, device=device)
+        self.grad = torch.zeros(self.n_params, dtype=torch.float32, device=device)
+        self.packed = torch.empty(self.packed_floats, dtype=torch.float32, device=device)
+        self.packed_key = None
+        self.plans: Dict[int, _Plan] = {}
+
+    def plan(self, M: int) -> _Plan:
+        p = self.plans.get(M)
+        if p is None:
+            if len(self.plans) >= 4:                      # stashes are large: keep only a few batch shapes alive
+                self.plans.pop(next(iter(self.plans)))
+            p = self.plans[M] = _Plan(self, M)
+        return p
+
+    def adopt(self, params) -> None:
+        """Make the module's parameters views into the flat buffer (values preserved)."""
+        with torch.no_grad():
+            for p, o in zip(params, self.offsets):
+                n = p.numel()
+                view = self.flat[o:o + n].view(p.shape)
+                if p.data_ptr() != view.data_ptr():
+                    view.copy_(p.data)
+                    p.data = view
+        self.packed_key = None
+
+    def repack(self, key=None) -> None:
+        if key is not None and key == self.packed_key:
+            return
+        _l.call("tnerf_mlp_pack", self.flat.data_ptr(), self.pack_table.data_ptr(), self.packed_floats, self.packed.data_ptr(),
+                _stream(self.device))
+        self.packed_key = key
+
+    def grad_views(self, params):
+        return [self.grad[o:o + p.numel()].view(p.shape) for p, o in zip(params, self.offsets)]
+
+
+# ---------------------------------------------------------------------------------- MLP op
+class _MlpFn(torch.autograd.Function):
+    """TinyNeRF.forward on x[M, in_dim] with parameter gradients (no gradient w.r.t. x)."""
+
+    @staticmethod
+    def forward(ctx, st: ModelState, x: torch.Tensor, train: bool, *params):
+        dev = st.device
+        M = x.shape[0]
+        rgb = torch.empty(M, 3, dtype=torch.float32, device=dev)
+        sigma = torch.empty(M, 1, dtype=torch.float32, device=dev)
+        plan = st.plan(M) if train else None
+        _l.call("tnerf_mlp_fwd", C.byref(st.desc), st.packed.data_ptr(), x.data_ptr(), M, rgb.data_ptr(), sigma.data_ptr(),
+                plan.stash.data_ptr() if train else None, plan.Mp if train else 0, _stream(dev))
+        ctx.st, ctx.plan, ctx.M = st, plan, M
+        ctx.shapes = [p.shape for p in params]
+        return rgb, sigma
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_sigma):
+        st, plan, M = ctx.st, ctx.plan, ctx.M
+        if plan is None:
+            raise RuntimeError("TinyNeRF (HIP): backward through a forward that ran without grad enabled")
+        dev = st.device
+        g_rgb = torch.zeros(M, 3, dtype=torch.float32, device=dev) if g_rgb is None else _f32c(g_rgb)
+        g_sigma = torch.zeros(M, 1, dtype=torch.float32, device=dev) if g_sigma is None else _f32c(g_sigma)
+        _l.call("tnerf_mlp_bwd", C.byref(st.desc), st.packed.data_ptr(), M, g_rgb.data_ptr(), g_sigma.data_ptr(),
+                plan.stash.data_ptr(), plan.Mp, plan.jobs.data_ptr(), plan.n_jobs, plan.slabs.data_ptr(), plan.reduce.data_ptr(),
+                st.grad.data_ptr(), _stream(dev))
+        grads = [st.grad[o:o + int(np.prod(s))].view(s).clone() for s, o in zip(ctx.shapes, st.offsets)]
+        return (None, None, None, *grads)
+
+
+def mlp_forward(st: ModelState, x: torch.Tensor, params) -> Tuple[torch.Tensor, torch.Tensor]:
+    _need_cuda(x)
+    if x.requires_grad:
+        raise NotImplementedError("TinyNeRF (HIP): gradient w.r.t. the encoded input is not implemented "
+                                  "(the reference's points carry no grad)")
+    if x.dim() != 2 or x.shape[1] != st.desc.in_dim:
+        raise RuntimeError(f"TinyNeRF (HIP): expected x of shape (N, {st.desc.in_dim}), got {tuple(x.shape)}")
+    train = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+    return _MlpFn.apply(st, _f32c(x), train, *params)
+
+
+# ------------------------------------------------------------------------------- fused rays op
+class _FusedRaysFn(torch.autograd.Function):
+    """sample -> encode -> MLP -> composite for a batch of rays in one kernel (+ backward)."""
+
+    @staticmethod
+    def forward(ctx, st: ModelState, rays_o, rays_d, ztab, S, rnd, t_rand, seed, off, white, train, *params):
+        dev = st.device
+        R = rays_o.shape[0]
+        comp = torch.empty(R, 3, dtype=torch.float32, device=dev)
+        if train:
+            plan = st.plan(R * S)
+            _l.call("tnerf_train_fwd_fused", C.byref(st.desc), st.packed.data_ptr(), rays_o.data_ptr(), rays_d.data_ptr(), R, S,
+                    ztab.data_ptr(), rnd, _ptr(t_rand), seed, off, white, comp.data_ptr(), plan.stash.data_ptr(), plan.Mp,
+                    _stream(dev))
+            ctx.save_for_backward(rays_o, rays_d, ztab, t_rand if t_rand is not None else ztab)
+            ctx.args = (st, plan, R, S, rnd, t_rand is not None, seed, off, white)
+            ctx.shapes = [p.shape for p in params]
+            return comp, None, None
+        depth = torch.empty(R, 1, dtype=torch.float32, device=dev)
+        acc = torch.empty(R, 1, dtype=torch.float32, device=dev)
+        _l.call("tnerf_render_fused", C.byref(st.desc), st.packed.data_ptr(), rays_o.data_ptr(), rays_d.data_ptr(), R, S,
+                ztab.data_ptr(), rnd, _ptr(t_rand), seed, off, white, comp.data_ptr(), depth.data_ptr(), acc.data_ptr(), _stream(dev))
+        ctx.args = None
+        return comp, depth, acc
+
+    @staticmethod
+    def backward(ctx, g_comp, g_depth, g_acc):
+        if ctx.args is None:
+            raise RuntimeError("fused render (HIP): backward through an inference forward")
+        st, plan, R, S, rnd, has_tr, seed, off, white = ctx.args
+        rays_o, rays_d, ztab, t_rand = ctx.saved_tensors
+        dev = st.device
+        g_comp = _f32c(g_comp)
+        _l.call("tnerf_train_bwd_fused", C.byref(st.desc), st.packed.data_ptr(), rays_o.data_ptr(), rays_d.data_ptr(), R, S,
+                ztab.data_ptr(), rnd, t_rand.data_ptr() if has_tr else None, seed, off, white, g_comp.data_ptr(),
+                plan.stash.data_ptr(), plan.Mp, plan.jobs.data_ptr(), plan.n_jobs, plan.slabs.data_ptr(), plan.reduce.data_ptr(),
+                st.grad.data_ptr(), _stream(dev))
+        grads = [st.grad[o:o + int(np.prod(s))].view(s).clone() for s, o in zip(ctx.shapes, st.offsets)]
+        return (None,) * 11 + tuple(grads)
+
+
+def render_rays_fused(st: ModelState, params, rays_o, rays_d, near, far, n_samples, randomized, white_bkgd=True,
+                      t_rand=None, philox=None):
+    """Returns (comp_rgb [R,3], depth [R,1] | None, acc [R,1] | None).  depth/acc only without grad."""
+    dev = _need_cuda(rays_o, rays_d, t_rand)
+    rays_o, rays_d = _f32c(rays_o), _f32c(rays_d)
+    S = int(n_samples)
+    ztab = depth_table(near, far, S, dev)
+    rnd, tr, seed, off = _rng_args(randomized, t_rand, philox)
+    if tr is not None:
+        tr = _f32c(tr)
+        if tuple(tr.shape) != (rays_o.shape[0], S):
+            raise ValueError(f"t_rand must be ({rays_o.shape[0]},{S})")
+    train = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+    return _FusedRaysFn.apply(st, rays_o, rays_d, ztab, S, rnd, tr, seed, off, int(bool(white_bkgd)), train, *params)
