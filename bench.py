@@ -206,7 +206,7 @@ def main():
         calls = {
             "train_fwd": lambda: lib.call("tnerf_train_fwd_fused", *common, comp.data_ptr(), plan.stash.data_ptr(), plan.Mp, sp),
             "dgrad": lambda: lib.call("tnerf_train_dgrad_fused", *common, gws.data_ptr(), plan.stash.data_ptr(), plan.Mp, sp),
-            "wgrad": lambda: lib.call("tnerf_wgrad", plan.stash.data_ptr(), plan.Mp, RAYS * SAMPLES, plan.jobs.data_ptr(), plan.n_jobs, plan.slabs.data_ptr(), sp),
+            "wgrad": lambda: lib.call("tnerf_wgrad", C.byref(st.desc), plan.stash.data_ptr(), plan.Mp, RAYS * SAMPLES, plan.jobs.data_ptr(), plan.n_jobs, plan.slabs.data_ptr(), sp),
             "reduce": lambda: lib.call("tnerf_wgrad_reduce", plan.slabs.data_ptr(), plan.reduce.data_ptr(), st.n_params, st.grad.data_ptr(), sp),
         }
         kern = {}

@@ -50,7 +50,7 @@ typedef struct tnerf_mlp_desc {
 typedef struct tnerf_plan_sizes {
     int64_t n_params;        /* flat fp32 parameter / gradient / Adam-moment buffers          */
     int64_t packed_floats;   /* MFMA-fragment-ordered copy of the weights (fwd + transposed)  */
-    int64_t stash_floats;    /* activations saved by a training forward, feature-major        */
+    int64_t stash_floats;    /* activations saved by a training forward (block-major) + sign bits */
     int64_t slab_floats;     /* weight-gradient partial slabs (one per wgrad workgroup)       */
     int64_t job_ints;        /* wgrad job table (int32)                                       */
     int64_t reduce_ints;     /* slab -> flat-gradient gather table (int32, 2 per parameter)   */
@@ -191,7 +191,7 @@ int tnerf_train_dgrad_fused(const tnerf_mlp_desc* d, const float* packed,
                             const float* ztab, int32_t randomized, const float* t_rand,
                             uint64_t seed, uint64_t offset, int32_t white_bkgd,
                             const float* g_comp, float* stash, int64_t stash_row_stride, tnerf_stream_t stream);
-int tnerf_wgrad(const float* stash, int64_t stash_row_stride, int64_t n_samples_total,
+int tnerf_wgrad(const tnerf_mlp_desc* d, const float* stash, int64_t stash_row_stride, int64_t n_samples_total,
                 const int32_t* job_table, int64_t n_jobs, float* slabs, tnerf_stream_t stream);
 int tnerf_wgrad_reduce(const float* slabs, const int32_t* reduce_table, int64_t n_params, float* grads,
                        tnerf_stream_t stream);

@@ -135,3 +135,11 @@ __device__ __forceinline__ CompTerms tn_comp_terms(float sigma, float z, float z
 __device__ __forceinline__ float tn_norm3(float x, float y, float z) {
     return sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z)));
 }
+
+// Address of (row 0, sample m) in the block-major training stash (layout: tnerf_internal.h).
+__device__ __forceinline__ float* tn_stash_at(float* stash, int64_t rows, int64_t m) {
+    return stash + ((m >> 5) * rows) * 32 + (m & 31);
+}
+__device__ __forceinline__ const float* tn_stash_at(const float* stash, int64_t rows, int64_t m) {
+    return stash + ((m >> 5) * rows) * 32 + (m & 31);
+}

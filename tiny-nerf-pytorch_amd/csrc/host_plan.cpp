@@ -196,17 +196,28 @@ static int build_classes(const MlpLayout& L, int64_t M, int n_cu, std::vector<Jo
     if (bad_split) { tn_set_error("wgrad: no kernel for this layer-shape / wave split"); return TNERF_EUNSUPPORTED; }
     if ((int)cls.size() > TN_RED_MAXCLS) { tn_set_error("too many wgrad job classes"); return TNERF_EUNSUPPORTED; }
     const int64_t MB = (M + 31) / 32;
-    int64_t cost_sum = 0; for (auto& c : cls) cost_sum += c.cost;
+    // One workgroup per CU and never more (a 257th workgroup would run alone in a second round and double
+    // the kernel time): start with one chunk per class, then keep splitting the class whose workgroups are
+    // the longest (cost per sample x samples per chunk) until every CU has one.
+    for (auto& c : cls) c.chunks = 1;
+    int total = (int)cls.size();
+    while (total < n_cu) {
+        int best = -1; double best_t = 0.0;
+        for (size_t i = 0; i < cls.size(); ++i) {
+            if (cls[i].chunks >= MB) continue;
+            const double t = (double)cls[i].cost * (double)((MB + cls[i].chunks - 1) / cls[i].chunks);
+            if (t > best_t) { best_t = t; best = (int)i; }
+        }
+        if (best < 0) break;
+        ++cls[best].chunks; ++total;
+    }
     int64_t off = 0;
     for (auto& c : cls) {
-        int64_t ch = ((int64_t)n_cu * c.cost + cost_sum / 2) / cost_sum;
-        ch = std::max<int64_t>(1, std::min<int64_t>(ch, MB));
         // make every chunk non-empty
-        const int64_t per = (MB + ch - 1) / ch;
-        ch = (MB + per - 1) / per;
-        c.chunks = (int)ch;
+        const int64_t per = (MB + c.chunks - 1) / c.chunks;
+        c.chunks = (int)((MB + per - 1) / per);
         c.slab_stride = (int64_t)c.n_at * 32 * (c.n_bt * 32) + (int64_t)c.n_at * 32;
-        c.slab0 = off; off += c.slab_stride * ch;
+        c.slab0 = off; off += c.slab_stride * c.chunks;
     }
     if (off >= (int64_t)1 << 31) { tn_set_error("slab workspace exceeds int32 offsets"); return TNERF_EUNSUPPORTED; }
     *slab_total = off;
@@ -223,7 +234,7 @@ extern "C" int tnerf_plan_sizes_query(const tnerf_mlp_desc* d, int64_t M, int32_
     const int64_t Mp = (M + 63) / 64 * 64;
     out->n_params = L.n_params;
     out->packed_floats = L.packed_floats;
-    out->stash_floats = (int64_t)L.stash_rows * Mp;
+    out->stash_floats = TN_STASH_BODY_FLOATS(L, Mp) + TN_MASK_FLOATS(L, Mp);
     out->slab_floats = slab;
     out->job_ints = jobs * TN_JOB_INTS;
     out->reduce_ints = TN_RED_HDR + 2 * L.n_params;

@@ -34,6 +34,6 @@ int tn_fused_args(const char* who, FwdArgs& a, const tnerf_mlp_desc* d, const fl
 int tn_launch_mlp_bwd(const BwdArgs& a, hipStream_t stream);
 int tn_launch_train_bwd(const BwdArgs& a, hipStream_t stream);
 // wgrad.hip
-int tn_launch_wgrad(const float* stash, int64_t Mp, int64_t M, const int32_t* jobs, int64_t n_jobs, float* slabs, hipStream_t stream);
+int tn_launch_wgrad(const float* stash, int64_t stash_rows, int64_t M, const int32_t* jobs, int64_t n_jobs, float* slabs, hipStream_t stream);
 int tn_launch_reduce(const float* slabs, const int32_t* reduce_table, int64_t n_params, float* grads, hipStream_t stream);
 int tn_launch_loss_grad(const float* comp, const float* target, int64_t R, double denom, float* g_comp, float* loss_out, hipStream_t stream);

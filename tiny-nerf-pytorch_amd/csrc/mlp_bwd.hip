@@ -20,27 +20,27 @@ __device__ __forceinline__ void tn_bwd_tile(const BwdArgs& a, const float (&dzh)
     const float* __restrict__ packed = a.packed;
     float* __restrict__ stash = a.stash;
     const int64_t Mp = a.Mp;
-    const int64_t voff = (int64_t)(4 * h) * Mp + m;
+    const int64_t ms = valid ? m : Mp + (lane & 31);           // padding lanes use the dump block
+    float* __restrict__ pl = tn_stash_at(stash, L.stash_rows, ms) + 4 * h * 32;      // per-lane: (row 4h, sample ms)
 
-    if (valid && h == 0) {
+    if (h == 0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) stash[(int64_t)(L.dzh_row0 + i) * Mp + m] = dzh[i];
+        for (int i = 0; i < 4; ++i) pl[(L.dzh_row0 + i) * 32] = dzh[i];            // h == 0 here
     }
     float dz[HID / 2], dznext[HID / 2];
+    // ReLU sign bits written by the training forward (layout: tnerf_internal.h)
+    const uint32_t* __restrict__ mrow = reinterpret_cast<const uint32_t*>(stash + TN_STASH_BODY_FLOATS(L, Mp)) + (2 * ms + h) * (NT / 2);
+    uint32_t mb[NT / 2];
     // ---- heads: dH_last[k] = sum_{n<4} W_head[n][k] dZ_head[n]; lane-half 1 supplies zeros (rows 4..7)
     {
         const int l = L.depth - 1;
-        const float* __restrict__ hrow = stash + (int64_t)L.h_row0[l] * Mp;
-        float* __restrict__ zrow = stash + (int64_t)L.dz_row0[l] * Mp;
+#pragma unroll
+        for (int w = 0; w < NT / 2; ++w) mb[w] = mrow[(int64_t)l * (Mp + 32) * NT + w];
+        float* __restrict__ zrow = pl + L.dz_row0[l] * 32;
         const f32x4* __restrict__ Wt = reinterpret_cast<const f32x4*>(packed + L.bw_head) + lane;
         const float b0 = h ? 0.0f : dzh[0], b1 = h ? 0.0f : dzh[1], b2 = h ? 0.0f : dzh[2], b3 = h ? 0.0f : dzh[3];
         tn_static_for<NT>([&](auto tc) TN_INLINE_LAMBDA {
             constexpr int t = decltype(tc)::value;
-            float hv[16];
-            tn_static_for<16>([&](auto rc) TN_INLINE_LAMBDA {
-                constexpr int r = decltype(rc)::value;
-                hv[r] = valid ? hrow[(int64_t)(32 * t + (r & 3) + 8 * (r >> 2)) * Mp + voff] : 0.0f;
-            });
             const f32x4 a4 = Wt[t * 64];
             f32x16 acc;
 #pragma unroll
@@ -49,25 +49,24 @@ __device__ __forceinline__ void tn_bwd_tile(const BwdArgs& a, const float (&dzh)
             acc = TN_MFMA(a4[2], b2, acc); acc = TN_MFMA(a4[3], b3, acc);
             tn_static_for<16>([&](auto rc) TN_INLINE_LAMBDA {
                 constexpr int r = decltype(rc)::value;
-                const float v = hv[r] > 0.0f ? acc[r] : 0.0f;                    // ReLU backward: output > 0
+                const float v = ((mb[t / 2] >> ((t & 1) * 16 + r)) & 1u) ? acc[r] : 0.0f;   // ReLU backward: output > 0
                 dz[t * 16 + r] = v;
-                if (valid) zrow[(int64_t)(32 * t + (r & 3) + 8 * (r >> 2)) * Mp + voff] = v;
+                zrow[(32 * t + (r & 3) + 8 * (r >> 2)) * 32] = v;
             });
         });
     }
     // ---- hidden layers, last to first: dZ_l (in dz) -> dZ_{l-1}
     for (int l = L.depth - 1; l >= 1; --l) {
-        const float* __restrict__ hrow = stash + (int64_t)L.h_row0[l - 1] * Mp;
-        float* __restrict__ zrow = stash + (int64_t)L.dz_row0[l - 1] * Mp;
+#pragma unroll
+        for (int w = 0; w < NT / 2; ++w) mb[w] = mrow[(int64_t)(l - 1) * (Mp + 32) * NT + w];
+        float* __restrict__ zrow = pl + L.dz_row0[l - 1] * 32;
         tn_layer_bwd<HID>(packed, L.bw_hid[l], dz, lane, [&](auto tc, const f32x16& acc) TN_INLINE_LAMBDA {
             constexpr int t = decltype(tc)::value;
             tn_static_for<16>([&](auto rc) TN_INLINE_LAMBDA {
                 constexpr int r = decltype(rc)::value;
-                const int64_t off = (int64_t)(32 * t + (r & 3) + 8 * (r >> 2)) * Mp + voff;
-                const float hv = valid ? hrow[off] : 0.0f;
-                const float v = hv > 0.0f ? acc[r] : 0.0f;
+                const float v = ((mb[t / 2] >> ((t & 1) * 16 + r)) & 1u) ? acc[r] : 0.0f;
                 dznext[t * 16 + r] = v;
-                if (valid) zrow[off] = v;
+                zrow[(32 * t + (r & 3) + 8 * (r >> 2)) * 32] = v;
             });
         });
         tn_static_for<HID / 2>([&](auto ic) TN_INLINE_LAMBDA { dz[decltype(ic)::value] = dznext[decltype(ic)::value]; });
@@ -87,10 +86,10 @@ __global__ __launch_bounds__(256, 1) void k_mlp_bwd(BwdArgs a) {
     float dzh[4];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        const float c = a.stash[(int64_t)(a.L.out_row0 + i) * a.Mp + mc];
+        const float c = tn_stash_at(a.stash, a.L.stash_rows, mc)[(a.L.out_row0 + i) * 32];
         dzh[i] = valid ? a.d_rgb[3 * mc + i] * (c * (1.0f - c)) : 0.0f;            // sigmoid backward
     }
-    const float sg = a.stash[(int64_t)(a.L.out_row0 + 3) * a.Mp + mc];
+    const float sg = tn_stash_at(a.stash, a.L.stash_rows, mc)[(a.L.out_row0 + 3) * 32];
     dzh[3] = (valid && sg > 0.0f) ? a.d_sigma[mc] : 0.0f;                              // ReLU backward
     tn_bwd_tile<HID>(a, dzh, mc, valid, lane);
 }
@@ -110,7 +109,8 @@ __global__ __launch_bounds__(256, 1) void k_train_bwd(BwdArgs a) {
     const float dn = tn_norm3(a.rays_d[3 * ray], a.rays_d[3 * ray + 1], a.rays_d[3 * ray + 2]);
     const float gr = a.g_comp[3 * ray], gg = a.g_comp[3 * ray + 1], gb = a.g_comp[3 * ray + 2];
     const float gbg = a.white ? (gr + gg + gb) : 0.0f;
-    const float* __restrict__ out0 = a.stash + (int64_t)a.L.out_row0 * a.Mp + ray * S;
+    const int64_t mray = ray * S; const int orow = a.L.out_row0 * 32; const int64_t SR = a.L.stash_rows;
+    auto outv = [&](int i, int sc) TN_INLINE_LAMBDA { return tn_stash_at(a.stash, SR, mray + sc)[orow + 32 * i]; };
 
     float segprod = 1.0f;
     if (nseg > 1) {
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256, 1) void k_train_bwd(BwdArgs a) {
             const int s = g * 64 + lane; const bool ok = s < S; const int sc = ok ? s : S - 1;
             const float z = tn_depth(a.sa, ray, sc);
             const float zn = (s + 1 < S) ? tn_depth(a.sa, ray, s + 1) : z;
-            const CompTerms t = tn_comp_terms(ok ? out0[3 * a.Mp + sc] : 0.f, z, zn, s == S - 1, dn);
+            const CompTerms t = tn_comp_terms(ok ? outv(3, sc) : 0.f, z, zn, s == S - 1, dn);
             const float p = tn_wave_prod(ok ? t.om : 1.0f);
             if (lane == g) segprod = p;
         }
@@ -129,8 +129,8 @@ __global__ __launch_bounds__(256, 1) void k_train_bwd(BwdArgs a) {
     float tail = 0.0f;
     for (int g = nseg - 1; g >= 0; --g) {
         const int s = g * 64 + lane; const bool ok = s < S; const int sc = ok ? s : S - 1;
-        const float c0 = out0[sc], c1 = out0[a.Mp + sc], c2 = out0[2 * a.Mp + sc];
-        const float sg = ok ? out0[3 * a.Mp + sc] : 0.f;
+        const float c0 = outv(0, sc), c1 = outv(1, sc), c2 = outv(2, sc);
+        const float sg = ok ? outv(3, sc) : 0.f;
         const float z = tn_depth(a.sa, ray, sc);
         const float zn = (s + 1 < S) ? tn_depth(a.sa, ray, s + 1) : z;
         const CompTerms t = tn_comp_terms(sg, z, zn, s == S - 1, dn);

@@ -85,6 +85,9 @@ __device__ __forceinline__ void tn_layer(const float* __restrict__ packed, int64
                 acc = TN_MFMA(a4[0], enc[e + 0], acc); acc = TN_MFMA(a4[1], enc[e + 1], acc);
                 acc = TN_MFMA(a4[2], enc[e + 2], acc); acc = TN_MFMA(a4[3], enc[e + 3], acc);
             }
+            // Pin the order {fragment load for group i+PF ; 4 MFMAs of group i}: left alone, the scheduler sinks the
+            // loads next to their use (2 in flight, ~300 cycles ahead) and every group stalls on the L2 round trip.
+            __builtin_amdgcn_sched_barrier(0);
         });
         fin(tc, acc);
     });
@@ -114,6 +117,7 @@ __device__ __forceinline__ void tn_layer_bwd(const float* __restrict__ packed, i
             if constexpr (i + PF < TOTAL) ring[i % PF] = Wt[(i + PF) * 64];
             acc = TN_MFMA(a4[0], dz[g * 4 + 0], acc); acc = TN_MFMA(a4[1], dz[g * 4 + 1], acc);
             acc = TN_MFMA(a4[2], dz[g * 4 + 2], acc); acc = TN_MFMA(a4[3], dz[g * 4 + 3], acc);
+            __builtin_amdgcn_sched_barrier(0);
         });
         fin(tc, acc);
     });

@@ -22,45 +22,62 @@ __device__ __forceinline__ void tn_mlp_tile(const FwdArgs& a, const float (&enc)
     const float* __restrict__ packed = a.packed;
     float* __restrict__ stash = a.stash;
     const int64_t Mp = a.Mp;
-    const int64_t voff = (int64_t)(4 * h) * Mp + m;          // per-lane part of every stash address
+    const int64_t ms = valid ? m : Mp + (lane & 31);           // padding lanes write to the dump block: stores need no branch
+    float* __restrict__ pl = TRAIN ? tn_stash_at(stash, L.stash_rows, ms) + 4 * h * 32 : nullptr;   // per-lane: (row 4h, sample ms)
 
-    if (TRAIN && valid) {
+    if (TRAIN) {
         tn_static_for<NE>([&](auto sc_) TN_INLINE_LAMBDA {
             constexpr int st = decltype(sc_)::value;
-            stash[(int64_t)(L.enc_row0 + 2 * st + h) * Mp + m] = enc[st];
+            pl[(L.enc_row0 + 2 * st - 3 * h) * 32] = enc[st];          // row enc_row0 + 2 st + h
         });
     }
 
     float hcur[HID / 2], hnext[HID / 2];
+    // ReLU sign bits of the layer being computed (training only): the backward chain masks with these
+    // instead of re-reading 1 KB of activations per sample and layer.
+    uint32_t mb[NT / 2];
+    uint32_t* __restrict__ mrow = TRAIN ? reinterpret_cast<uint32_t*>(stash + TN_STASH_BODY_FLOATS(L, Mp)) + (2 * ms + h) * (NT / 2) : nullptr;
     // ---- layer 0: input only
     {
-        float* __restrict__ srow = TRAIN ? stash + (int64_t)L.h_row0[0] * Mp : nullptr;
+        float* __restrict__ srow = TRAIN ? pl + L.h_row0[0] * 32 : nullptr;
         tn_layer<HID, NE, false, true>(packed, L.fw_bias[0], L.fw_enc[0], 0, hnext, enc, lane,
             [&](auto tc, const f32x16& acc) TN_INLINE_LAMBDA {
                 constexpr int t = decltype(tc)::value;
+                if (TRAIN && (t & 1) == 0) mb[t / 2] = 0u;
                 tn_static_for<16>([&](auto rc) TN_INLINE_LAMBDA {
                     constexpr int r = decltype(rc)::value;
                     const float v = fmaxf(acc[r], 0.0f);
                     hcur[t * 16 + r] = v;
-                    if (TRAIN && valid) srow[(int64_t)(32 * t + (r & 3) + 8 * (r >> 2)) * Mp + voff] = v;
+                    if (TRAIN) mb[t / 2] |= (v > 0.0f) ? (1u << ((t & 1) * 16 + r)) : 0u;
+                    if (TRAIN) srow[(32 * t + (r & 3) + 8 * (r >> 2)) * 32] = v;
                 });
             });
+        if (TRAIN) {
+#pragma unroll
+            for (int w = 0; w < NT / 2; ++w) mrow[w] = mb[w];
+        }
     }
     // ---- hidden layers
     for (int l = 1; l < L.depth; ++l) {
-        float* __restrict__ srow = TRAIN ? stash + (int64_t)L.h_row0[l] * Mp : nullptr;
+        float* __restrict__ srow = TRAIN ? pl + L.h_row0[l] * 32 : nullptr;
         auto fin = [&](auto tc, const f32x16& acc) TN_INLINE_LAMBDA {
             constexpr int t = decltype(tc)::value;
+            if (TRAIN && (t & 1) == 0) mb[t / 2] = 0u;
             tn_static_for<16>([&](auto rc) TN_INLINE_LAMBDA {
                 constexpr int r = decltype(rc)::value;
                 const float v = fmaxf(acc[r], 0.0f);
                 hnext[t * 16 + r] = v;
-                if (TRAIN && valid) srow[(int64_t)(32 * t + (r & 3) + 8 * (r >> 2)) * Mp + voff] = v;
+                if (TRAIN) mb[t / 2] |= (v > 0.0f) ? (1u << ((t & 1) * 16 + r)) : 0u;
+                if (TRAIN) srow[(32 * t + (r & 3) + 8 * (r >> 2)) * 32] = v;
             });
         };
         if (l == L.skip_at) tn_layer<HID, NE, true, true>(packed, L.fw_bias[l], L.fw_enc[l], L.fw_hid[l], hcur, enc, lane, fin);
         else                tn_layer<HID, NE, true, false>(packed, L.fw_bias[l], 0, L.fw_hid[l], hcur, enc, lane, fin);
         tn_static_for<HID / 2>([&](auto ic) TN_INLINE_LAMBDA { hcur[decltype(ic)::value] = hnext[decltype(ic)::value]; });
+        if (TRAIN) {
+#pragma unroll
+            for (int w = 0; w < NT / 2; ++w) mrow[(int64_t)l * (Mp + 32) * NT + w] = mb[w];   // layer stride = (Mp+32) * 2 halves * NT/2 words
+        }
     }
     // ---- heads: one n-tile whose rows 0..2 are rgb.0 and row 3 is sigma.0 (rows 4..31 are zero)
     {
@@ -103,7 +120,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fwd(FwdArgs a) {
         a.sigma_out[m] = out4[3];
         if (TRAIN) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a.stash[(int64_t)(a.L.out_row0 + i) * a.Mp + m] = out4[i];
+            for (int i = 0; i < 4; ++i) tn_stash_at(a.stash, a.L.stash_rows, m)[(a.L.out_row0 + i) * 32] = out4[i];
         }
     }
 }
@@ -162,7 +179,7 @@ __global__ __launch_bounds__(256, 1) void k_render_fused(FwdArgs a) {
         T_in *= __shfl(incl, 63, 64);
         if (TRAIN && ok) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a.stash[(int64_t)(a.L.out_row0 + i) * a.Mp + ray * S + s] = v[i];
+            for (int i = 0; i < 4; ++i) tn_stash_at(a.stash, a.L.stash_rows, ray * S + s)[(a.L.out_row0 + i) * 32] = v[i];
         }
     }
     cr = tn_wave_sum(cr); cg = tn_wave_sum(cg); cb = tn_wave_sum(cb); cd = tn_wave_sum(cd); ca = tn_wave_sum(ca);

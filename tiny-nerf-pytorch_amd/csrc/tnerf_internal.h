@@ -44,5 +44,17 @@ void tn_set_error(const char* fmt, ...);
 }
 #endif
 
+// The training stash is BLOCK-major: samples are grouped in blocks of 32 consecutive indices and block b holds
+//   stash[(b * stash_rows + row) * 32 + (m & 31)],   b = m >> 5
+// i.e. one 128-byte line per (block, row): a wave's tile of one layer is 32 KB of contiguous HBM for both the
+// writer (forward / dgrad kernels) and the reader (wgrad), instead of 256 lines that are 1 MB apart.
+// After the Mp/32 blocks come the ReLU sign bits of
+// every hidden layer: for layer l, sample m, lane-half h: hidden/64 uint32 words
+//   word index ((l*(Mp+32) + m)*2 + h) * (hidden/64) + t/2,  bit (t&1)*16 + r   <->  feature 32t + TN_ACC_ROW(r,h)
+// One extra ("dump") block / sample slot follows the Mp real ones: lanes that pad a ragged tile store there, so
+// that no store in the hot loops needs a per-lane branch.
+#define TN_STASH_BODY_FLOATS(L, Mp) ((int64_t)(L).stash_rows * ((Mp) + 32))
+#define TN_MASK_FLOATS(L, Mp) ((int64_t)(L).depth * ((Mp) + 32) * ((L).hidden / 32))
+
 // row of a 32x32 MFMA accumulator register r (0..15) for lane-half h (0/1)
 #define TN_ACC_ROW(r, h) (((r) & 3) + 8 * ((r) >> 2) + 4 * (h))

@@ -24,7 +24,7 @@ extern "C" int tnerf_mlp_bwd(const tnerf_mlp_desc* d, const float* packed, int64
     a.packed = packed; a.stash = stash; a.Mp = Mp; a.M = M; a.d_rgb = d_rgb; a.d_sigma = d_sigma;
     hipStream_t s = (hipStream_t)stream;
     if ((rc = tn_launch_mlp_bwd(a, s))) return rc;
-    if ((rc = tn_launch_wgrad(stash, Mp, M, job_table, n_jobs, slabs, s))) return rc;
+    if ((rc = tn_launch_wgrad(stash, a.L.stash_rows, M, job_table, n_jobs, slabs, s))) return rc;
     return tn_launch_reduce(slabs, reduce_table, a.L.n_params, grads, s);
 }
 
@@ -40,7 +40,7 @@ static int train_bwd_impl(const char* who, const tnerf_mlp_desc* d, const float*
     a.L = f.L; a.packed = packed; a.stash = stash; a.Mp = Mp; a.rays_o = rays_o; a.rays_d = rays_d; a.R = R; a.sa = f.sa;
     a.white = white; a.g_comp = g_comp;
     if ((rc = tn_launch_train_bwd(a, s))) return rc;
-    if ((rc = tn_launch_wgrad(stash, Mp, R * S, job_table, n_jobs, slabs, s))) return rc;
+    if ((rc = tn_launch_wgrad(stash, a.L.stash_rows, R * S, job_table, n_jobs, slabs, s))) return rc;
     return tn_launch_reduce(slabs, reduce_table, a.L.n_params, grads, s);
 }
 
@@ -67,10 +67,11 @@ extern "C" int tnerf_train_dgrad_fused(const tnerf_mlp_desc* d, const float* pac
     return tn_launch_train_bwd(a, (hipStream_t)stream);
 }
 
-extern "C" int tnerf_wgrad(const float* stash, int64_t Mp, int64_t M, const int32_t* job_table, int64_t n_jobs, float* slabs,
-                           tnerf_stream_t stream) {
+extern "C" int tnerf_wgrad(const tnerf_mlp_desc* d, const float* stash, int64_t Mp, int64_t M, const int32_t* job_table, int64_t n_jobs,
+                           float* slabs, tnerf_stream_t stream) {
+    MlpLayout L; int rc = tn_build_layout(d, &L); if (rc) return rc;
     if (!stash || Mp < M || M < 1 || !job_table || n_jobs < 1 || !slabs) { tn_set_error("tnerf_wgrad: bad arguments"); return TNERF_EINVAL; }
-    return tn_launch_wgrad(stash, Mp, M, job_table, n_jobs, slabs, (hipStream_t)stream);
+    return tn_launch_wgrad(stash, L.stash_rows, M, job_table, n_jobs, slabs, (hipStream_t)stream);
 }
 
 extern "C" int tnerf_wgrad_reduce(const float* slabs, const int32_t* reduce_table, int64_t n_params, float* grads, tnerf_stream_t stream) {

@@ -1,8 +1,8 @@
 // Weight-gradient GEMMs, slab reduction, weight packing, loss gradient and Adam.
 //
 // wgrad: for every layer  dW[n][k] = sum_m dZ^T[n][m] * X^T[k][m]   (X = the layer's input)
-// Both operands are rows of the feature-major stash ([row][sample], row stride Mp), so an MFMA
-// fragment "lane = row, 4 consecutive samples" is one 16-byte piece of a row.  A workgroup
+// Both operands are rows of the block-major stash ([32-sample block][row][32], tnerf_internal.h), so an MFMA
+// fragment "lane = row, 4 consecutive samples" is one 16-byte piece of a 128-byte line.  A workgroup
 // (4 waves, one per SIMD) owns one (A rows x B rows) block of up to 256x256 outputs for one chunk
 // of samples: the 4 waves split it 2x2 / 4x1 / 1x4 (<= 4x4 tiles of 32x32 = 256 accumulator
 // registers per wave).  Per 32-sample step the workgroup stages [rows][32] of A and B through LDS
@@ -20,7 +20,7 @@
 __device__ __forceinline__ int wg_lds_off(int row, int chunk) { return row * 32 + ((chunk ^ ((row >> 1) & 7)) << 2); }
 
 template <int TA, int TB>
-__device__ __forceinline__ void wgrad_body(const float* __restrict__ stash, int64_t Mp, int64_t M, const int32_t* __restrict__ job,
+__device__ __forceinline__ void wgrad_body(const float* __restrict__ stash, int64_t stash_rows, int64_t M, const int32_t* __restrict__ job,
                                            float* __restrict__ slabs, float* lds) {
     const int tid = (int)threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -47,40 +47,40 @@ __device__ __forceinline__ void wgrad_body(const float* __restrict__ stash, int6
     // staging: thread -> (row within a 32-row group = tid>>3, 16-byte chunk = tid&7)
     const int srow = tid >> 3, schunk = tid & 7;
     f32x4 stage[MAXLD];
+    // Loads are issued unconditionally from a clamped (always valid) address so that all of them stay in
+    // flight behind the MFMAs; rows / samples that do not exist are zeroed when the block is written to LDS.
     auto stage_load = [&](int blk) TN_INLINE_LAMBDA {
-        const int64_t m0 = (int64_t)blk * 32 + schunk * 4;
+        // block-major stash: the A rows (and the B rows) of one 32-sample block are ONE contiguous run of
+        // 128-byte lines, so thread tid reads base + g*4 KB + tid*16 B.
+        const float* blkbase = stash + (int64_t)blk * stash_rows * 32 + tid * 4;
         tn_static_for<MAXLD>([&](auto gc) TN_INLINE_LAMBDA {
             constexpr int g = decltype(gc)::value;
-            const int row = g * 32 + srow;                                   // combined A|B row index
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (row < rows) {
+            if (g * 32 < rows) {                                             // wave-uniform: row groups of this job
+                const bool isA = g * 32 < rows_a;
+                const int lr0 = isA ? g * 32 : g * 32 - rows_a;              // first local row of the group
+                const int lim = (isA ? a_rows : b_rows) - 1;                 // clamp rows that do not exist to a valid one
+                const int lr = lr0 + srow < lim ? lr0 + srow : lim;
+                const float* src = blkbase + ((isA ? a_row0 : b_row0) + lr - srow) * 32;
+                stage[g] = *reinterpret_cast<const f32x4*>(src);
+            }
+        });
+    };
+    auto stage_store = [&](int blk, int buf) TN_INLINE_LAMBDA {
+        float* base = lds + buf * (2 * WG_LDS_ROWS * 32);
+        const int64_t m0 = (int64_t)blk * 32 + schunk * 4;
+        const int nvalid = (int)((M - m0) < 0 ? 0 : ((M - m0) > 4 ? 4 : (M - m0)));   // live samples in this 16-byte piece
+        tn_static_for<MAXLD>([&](auto gc) TN_INLINE_LAMBDA {
+            constexpr int g = decltype(gc)::value;
+            if (g * 32 < rows) {
+                const int row = g * 32 + srow;
                 const bool isA = row < rows_a;
                 const int lr = isA ? row : row - rows_a;
                 const bool live = lr < (isA ? a_rows : b_rows);
-                if (live) {
-                    const float* src = stash + ((isA ? a_row0 : b_row0) + lr) * Mp + m0;
-                    v = *reinterpret_cast<const f32x4*>(src);
-                    if (m0 + 3 >= M) {                                       // tail: the pad of the stash is not zeroed
-                        if (m0 + 0 >= M) v[0] = 0.f;
-                        if (m0 + 1 >= M) v[1] = 0.f;
-                        if (m0 + 2 >= M) v[2] = 0.f;
-                        if (m0 + 3 >= M) v[3] = 0.f;
-                    }
-                }
-            }
-            stage[g] = v;
-        });
-    };
-    auto stage_store = [&](int buf) TN_INLINE_LAMBDA {
-        float* base = lds + buf * (2 * WG_LDS_ROWS * 32);
-        tn_static_for<MAXLD>([&](auto gc) TN_INLINE_LAMBDA {
-            constexpr int g = decltype(gc)::value;
-            const int row = g * 32 + srow;
-            if (row < rows) {
-                const bool isA = row < rows_a;
-                const int lr = isA ? row : row - rows_a;
+                f32x4 v = stage[g];
+                v[0] = (live && nvalid > 0) ? v[0] : 0.f; v[1] = (live && nvalid > 1) ? v[1] : 0.f;
+                v[2] = (live && nvalid > 2) ? v[2] : 0.f; v[3] = (live && nvalid > 3) ? v[3] : 0.f;
                 float* dst = base + (isA ? 0 : WG_LDS_ROWS * 32) + wg_lds_off(lr, schunk);
-                *reinterpret_cast<f32x4*>(dst) = stage[g];
+                *reinterpret_cast<f32x4*>(dst) = v;
             }
         });
     };
@@ -89,7 +89,7 @@ __device__ __forceinline__ void wgrad_body(const float* __restrict__ stash, int6
     const bool active = (a_t0 < n_at) && (b_t0 < n_bt);
     const bool do_bias = job[JOB_HAS_BIAS] && wb == 0;
 
-    if (nblk > 0) { stage_load(blk0); stage_store(0); }
+    if (nblk > 0) { stage_load(blk0); stage_store(blk0, 0); }
     __syncthreads();
     for (int b = 0; b < nblk; ++b) {
         const bool more = b + 1 < nblk;
@@ -115,7 +115,7 @@ __device__ __forceinline__ void wgrad_body(const float* __restrict__ stash, int6
                 }
             }
         }
-        if (more) stage_store((b + 1) & 1);
+        if (more) stage_store(blk0 + b + 1, (b + 1) & 1);
         __syncthreads();
     }
 
@@ -140,7 +140,7 @@ __device__ __forceinline__ void wgrad_body(const float* __restrict__ stash, int6
     }
 }
 
-__global__ __launch_bounds__(256, 1) void k_wgrad(const float* __restrict__ stash, int64_t Mp, int64_t M,
+__global__ __launch_bounds__(256, 1) void k_wgrad(const float* __restrict__ stash, int64_t stash_rows, int64_t M,
                                                   const int32_t* __restrict__ jobs, float* __restrict__ slabs) {
     __shared__ __attribute__((aligned(16))) float lds[WG_LDS_FLOATS];
     const int32_t* job = jobs + (int64_t)blockIdx.x * TN_JOB_INTS;
@@ -148,17 +148,17 @@ __global__ __launch_bounds__(256, 1) void k_wgrad(const float* __restrict__ stas
     const int ta = n_at / WA, tb = n_bt / WB;               // host plan guarantees exact division (or a 1-tile remainder wave)
     const int key = (ta > 0 ? ta : 1) * 8 + (tb > 0 ? tb : 1);
     switch (key) {
-        case 4 * 8 + 4: wgrad_body<4, 4>(stash, Mp, M, job, slabs, lds); break;
-        case 2 * 8 + 2: wgrad_body<2, 2>(stash, Mp, M, job, slabs, lds); break;
-        case 1 * 8 + 2: wgrad_body<1, 2>(stash, Mp, M, job, slabs, lds); break;
-        case 2 * 8 + 1: wgrad_body<2, 1>(stash, Mp, M, job, slabs, lds); break;
-        case 1 * 8 + 1: wgrad_body<1, 1>(stash, Mp, M, job, slabs, lds); break;
+        case 4 * 8 + 4: wgrad_body<4, 4>(stash, stash_rows, M, job, slabs, lds); break;
+        case 2 * 8 + 2: wgrad_body<2, 2>(stash, stash_rows, M, job, slabs, lds); break;
+        case 1 * 8 + 2: wgrad_body<1, 2>(stash, stash_rows, M, job, slabs, lds); break;
+        case 2 * 8 + 1: wgrad_body<2, 1>(stash, stash_rows, M, job, slabs, lds); break;
+        case 1 * 8 + 1: wgrad_body<1, 1>(stash, stash_rows, M, job, slabs, lds); break;
         default: break;   // unreachable: shapes are validated on the host (tnerf_plan_fill)
     }
 }
 
-int tn_launch_wgrad(const float* stash, int64_t Mp, int64_t M, const int32_t* jobs, int64_t n_jobs, float* slabs, hipStream_t stream) {
-    hipLaunchKernelGGL(k_wgrad, dim3((unsigned)n_jobs), dim3(256), 0, stream, stash, Mp, M, jobs, slabs);
+int tn_launch_wgrad(const float* stash, int64_t stash_rows, int64_t M, const int32_t* jobs, int64_t n_jobs, float* slabs, hipStream_t stream) {
+    hipLaunchKernelGGL(k_wgrad, dim3((unsigned)n_jobs), dim3(256), 0, stream, stash, stash_rows, M, jobs, slabs);
     TN_HIP_CHECK_LAUNCH("wgrad");
     return TNERF_OK;
 }
