@@ -205,7 +205,9 @@ static int build_classes(const MlpLayout& L, int64_t M, int n_cu, std::vector<Jo
         int best = -1; double best_t = 0.0;
         for (size_t i = 0; i < cls.size(); ++i) {
             if (cls[i].chunks >= MB) continue;
-            const double t = (double)cls[i].cost * (double)((MB + cls[i].chunks - 1) / cls[i].chunks);
+            // cycles per 32-sample block: 64 per MFMA step (16 steps per tile) + a fixed cost for staging the block
+            // through LDS and the barrier (measured ~3k cycles; it dominates the small enc / head classes)
+            const double t = ((double)cls[i].cost * 1024.0 + 3000.0) * (double)((MB + cls[i].chunks - 1) / cls[i].chunks);
             if (t > best_t) { best_t = t; best = (int)i; }
         }
         if (best < 0) break;

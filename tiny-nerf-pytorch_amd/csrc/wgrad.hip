@@ -47,40 +47,42 @@ __device__ __forceinline__ void wgrad_body(const float* __restrict__ stash, int6
     // staging: thread -> (row within a 32-row group = tid>>3, 16-byte chunk = tid&7)
     const int srow = tid >> 3, schunk = tid & 7;
     f32x4 stage[MAXLD];
-    // Loads are issued unconditionally from a clamped (always valid) address so that all of them stay in
-    // flight behind the MFMAs; rows / samples that do not exist are zeroed when the block is written to LDS.
+    // Per-thread source offsets of the (up to 16) 32-row groups, relative to the start of a block, computed once:
+    // rows that do not exist (head: 4 of 32, enc: 40 of 64) are clamped to a valid row here and zeroed when the
+    // block is written to LDS, so the loads themselves are unconditional and all stay in flight behind the MFMAs.
+    int32_t soff[MAXLD]; bool slive[MAXLD]; int32_t doff[MAXLD];
+    tn_static_for<MAXLD>([&](auto gc) TN_INLINE_LAMBDA {
+        constexpr int g = decltype(gc)::value;
+        const bool isA = g * 32 < rows_a;
+        const int lr = (isA ? g * 32 : g * 32 - rows_a) + srow;
+        const int lim = (isA ? a_rows : b_rows) - 1;
+        soff[g] = (int32_t)(((isA ? a_row0 : b_row0) + (lr < lim ? lr : lim)) * 32 + schunk * 4);
+        slive[g] = lr <= lim;
+        doff[g] = (isA ? 0 : WG_LDS_ROWS * 32) + wg_lds_off(lr, schunk);
+    });
+    const int ngroups = rows / 32;
     auto stage_load = [&](int blk) TN_INLINE_LAMBDA {
-        // block-major stash: the A rows (and the B rows) of one 32-sample block are ONE contiguous run of
-        // 128-byte lines, so thread tid reads base + g*4 KB + tid*16 B.
-        const float* blkbase = stash + (int64_t)blk * stash_rows * 32 + tid * 4;
+        const float* blkbase = stash + (int64_t)blk * stash_rows * 32;
         tn_static_for<MAXLD>([&](auto gc) TN_INLINE_LAMBDA {
             constexpr int g = decltype(gc)::value;
-            if (g * 32 < rows) {                                             // wave-uniform: row groups of this job
-                const bool isA = g * 32 < rows_a;
-                const int lr0 = isA ? g * 32 : g * 32 - rows_a;              // first local row of the group
-                const int lim = (isA ? a_rows : b_rows) - 1;                 // clamp rows that do not exist to a valid one
-                const int lr = lr0 + srow < lim ? lr0 + srow : lim;
-                const float* src = blkbase + ((isA ? a_row0 : b_row0) + lr - srow) * 32;
-                stage[g] = *reinterpret_cast<const f32x4*>(src);
-            }
+            if (g < ngroups) stage[g] = *reinterpret_cast<const f32x4*>(blkbase + soff[g]);     // wave-uniform branch
         });
     };
     auto stage_store = [&](int blk, int buf) TN_INLINE_LAMBDA {
         float* base = lds + buf * (2 * WG_LDS_ROWS * 32);
         const int64_t m0 = (int64_t)blk * 32 + schunk * 4;
-        const int nvalid = (int)((M - m0) < 0 ? 0 : ((M - m0) > 4 ? 4 : (M - m0)));   // live samples in this 16-byte piece
+        const bool tail = (int64_t)blk * 32 + 32 > M;                        // wave-uniform: only the last block can be ragged
+        const int nvalid = (int)((M - m0) < 0 ? 0 : ((M - m0) > 4 ? 4 : (M - m0)));
         tn_static_for<MAXLD>([&](auto gc) TN_INLINE_LAMBDA {
             constexpr int g = decltype(gc)::value;
-            if (g * 32 < rows) {
-                const int row = g * 32 + srow;
-                const bool isA = row < rows_a;
-                const int lr = isA ? row : row - rows_a;
-                const bool live = lr < (isA ? a_rows : b_rows);
+            if (g < ngroups) {
                 f32x4 v = stage[g];
-                v[0] = (live && nvalid > 0) ? v[0] : 0.f; v[1] = (live && nvalid > 1) ? v[1] : 0.f;
-                v[2] = (live && nvalid > 2) ? v[2] : 0.f; v[3] = (live && nvalid > 3) ? v[3] : 0.f;
-                float* dst = base + (isA ? 0 : WG_LDS_ROWS * 32) + wg_lds_off(lr, schunk);
-                *reinterpret_cast<f32x4*>(dst) = v;
+                if (!slive[g]) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (tail) {
+                    v[0] = nvalid > 0 ? v[0] : 0.f; v[1] = nvalid > 1 ? v[1] : 0.f;
+                    v[2] = nvalid > 2 ? v[2] : 0.f; v[3] = nvalid > 3 ? v[3] : 0.f;
+                }
+                *reinterpret_cast<f32x4*>(base + doff[g]) = v;
             }
         });
     };
