@@ -12,6 +12,8 @@ struct FwdArgs {
     const float* x; int64_t M; float* rgb_out; float* sigma_out;
     // training stash (NULL for inference)
     float* stash; int64_t Mp;
+    // diagnostic builds only (-DTN_STAMPS): s_memtime stamps of the first ray of each workgroup
+    unsigned long long* stamps;
 };
 
 struct BwdArgs {

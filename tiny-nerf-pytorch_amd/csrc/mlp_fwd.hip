@@ -10,6 +10,12 @@
 #include "mlp_core.hpp"
 #include "mlp_args.hpp"
 
+#ifdef TN_STAMPS
+#define TN_STAMP(k) do { if (a.stamps && lane == 0) a.stamps[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 32 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TN_STAMP(k) do {} while (0)
+#endif
+
 // The MLP for one 32-sample tile.  enc: network input registers.  m: this lane's sample index in the
 // stash / output (valid if `valid`).  Returns the 4 head outputs (r,g,b after sigmoid; sigma after
 // ReLU) in out4 — meaningful on lane-half 0 only.
@@ -37,6 +43,7 @@ __device__ __forceinline__ void tn_mlp_tile(const FwdArgs& a, const float (&enc)
     // instead of re-reading 1 KB of activations per sample and layer.
     uint32_t mb[NT / 2];
     uint32_t* __restrict__ mrow = TRAIN ? reinterpret_cast<uint32_t*>(stash + TN_STASH_BODY_FLOATS(L, Mp)) + (2 * ms + h) * (NT / 2) : nullptr;
+    TN_STAMP(1);
     // ---- layer 0: input only
     {
         float* __restrict__ srow = TRAIN ? pl + L.h_row0[0] * 32 : nullptr;
@@ -57,6 +64,7 @@ __device__ __forceinline__ void tn_mlp_tile(const FwdArgs& a, const float (&enc)
             for (int w = 0; w < NT / 2; ++w) mrow[w] = mb[w];
         }
     }
+    TN_STAMP(2);
     // ---- hidden layers
     for (int l = 1; l < L.depth; ++l) {
         float* __restrict__ srow = TRAIN ? pl + L.h_row0[l] * 32 : nullptr;
@@ -78,6 +86,7 @@ __device__ __forceinline__ void tn_mlp_tile(const FwdArgs& a, const float (&enc)
 #pragma unroll
             for (int w = 0; w < NT / 2; ++w) mrow[(int64_t)l * (Mp + 32) * NT + w] = mb[w];   // layer stride = (Mp+32) * 2 halves * NT/2 words
         }
+        TN_STAMP(2 + l);
     }
     // ---- heads: one n-tile whose rows 0..2 are rgb.0 and row 3 is sigma.0 (rows 4..31 are zero)
     {
@@ -98,6 +107,7 @@ __device__ __forceinline__ void tn_mlp_tile(const FwdArgs& a, const float (&enc)
         for (int i = 0; i < 3; ++i) out4[i] = 1.0f / (1.0f + expf(-acc[i]));   // torch.sigmoid   nerf.py:27,39
         out4[3] = fmaxf(acc[3], 0.0f);                                          // ReLU            nerf.py:26,40
     }
+    TN_STAMP(12);
 }
 
 // ------------------------------------------------------------------------------ MLP only
@@ -138,6 +148,7 @@ __global__ __launch_bounds__(256, 1) void k_render_fused(FwdArgs a) {
     const float ox = a.rays_o[3 * ray], oy = a.rays_o[3 * ray + 1], oz = a.rays_o[3 * ray + 2];
     const float dx = a.rays_d[3 * ray], dy = a.rays_d[3 * ray + 1], dz = a.rays_d[3 * ray + 2];
     const float dn = tn_norm3(dx, dy, dz);
+    TN_STAMP(0);
     float T_in = 1.0f, cr = 0.f, cg = 0.f, cb = 0.f, cd = 0.f, ca = 0.f;
 
     // March the ray 32 samples at a time (ONE inlined copy of the MLP body); every second tile (or the
@@ -182,6 +193,7 @@ __global__ __launch_bounds__(256, 1) void k_render_fused(FwdArgs a) {
             for (int i = 0; i < 4; ++i) tn_stash_at(a.stash, a.L.stash_rows, ray * S + s)[(a.L.out_row0 + i) * 32] = v[i];
         }
     }
+    TN_STAMP(13);
     cr = tn_wave_sum(cr); cg = tn_wave_sum(cg); cb = tn_wave_sum(cb); cd = tn_wave_sum(cd); ca = tn_wave_sum(ca);
     if (lane == 0) {
         const float bg = a.white ? (1.0f - ca) : 0.0f;                                       // volume.py:42
@@ -189,6 +201,7 @@ __global__ __launch_bounds__(256, 1) void k_render_fused(FwdArgs a) {
         if (a.depth) a.depth[ray] = cd;
         if (a.acc) a.acc[ray] = ca;
     }
+    TN_STAMP(14);
 }
 
 // ----------------------------------------------------------------------------------- dispatch
@@ -277,3 +290,16 @@ extern "C" int tnerf_train_fwd_fused(const tnerf_mlp_desc* d, const float* packe
     a.comp = comp; a.stash = stash; a.Mp = Mp;
     return launch_fwd<true, true>(a, R, (hipStream_t)stream, "tnerf_train_fwd_fused");
 }
+
+#ifdef TN_STAMPS
+// Diagnostic build only (tools/stamp_probe.py): the fused forward kernel with s_memtime stamps per phase.
+extern "C" int tnerf_debug_render_stamps(const tnerf_mlp_desc* d, const float* packed, const float* rays_o, const float* rays_d,
+                                         int64_t R, int32_t S, const float* ztab, float* comp, float* stash, int64_t Mp,
+                                         unsigned long long* stamps, tnerf_stream_t stream) {
+    FwdArgs a{};
+    int rc = tn_fused_args("tnerf_debug_render_stamps", a, d, packed, rays_o, rays_d, R, S, ztab, 0, nullptr, 0, 0, 1);
+    if (rc) return rc;
+    a.comp = comp; a.stamps = stamps; a.stash = stash; a.Mp = Mp;
+    return stash ? launch_fwd<true, true>(a, R, (hipStream_t)stream, "stamps") : launch_fwd<true, false>(a, R, (hipStream_t)stream, "stamps");
+}
+#endif

@@ -106,15 +106,17 @@ __device__ __forceinline__ void wgrad_body(const float* __restrict__ stash, int6
                 for (int i = 0; i < TA; ++i) fa[i] = *reinterpret_cast<const f32x4*>(A + wg_lds_off((a_t0 + i) * 32 + frow, 2 * q + fh));
 #pragma unroll
                 for (int j = 0; j < TB; ++j) fb[j] = *reinterpret_cast<const f32x4*>(B + wg_lds_off((b_t0 + j) * 32 + frow, 2 * q + fh));
+                if (do_bias) {
 #pragma unroll
-                for (int i = 0; i < TA; ++i) {
-                    if (do_bias) bsum[i] += (fa[i][0] + fa[i][1]) + (fa[i][2] + fa[i][3]);
-#pragma unroll
-                    for (int j = 0; j < TB; ++j) {
-                        acc[i][j] = TN_MFMA(fa[i][0], fb[j][0], acc[i][j]); acc[i][j] = TN_MFMA(fa[i][1], fb[j][1], acc[i][j]);
-                        acc[i][j] = TN_MFMA(fa[i][2], fb[j][2], acc[i][j]); acc[i][j] = TN_MFMA(fa[i][3], fb[j][3], acc[i][j]);
-                    }
+                    for (int i = 0; i < TA; ++i) bsum[i] += (fa[i][0] + fa[i][1]) + (fa[i][2] + fa[i][3]);
                 }
+                // k-step outermost: consecutive MFMAs go to different accumulators
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+#pragma unroll
+                    for (int i = 0; i < TA; ++i)
+#pragma unroll
+                        for (int j = 0; j < TB; ++j) acc[i][j] = TN_MFMA(fa[i][p], fb[j][p], acc[i][j]);
             }
         }
         if (more) stage_store(blk0 + b + 1, (b + 1) & 1);
