@@ -348,3 +348,124 @@ def test_full_size_properties(mods, dev):
         cq, _, _ = mods["ops"].render_rays_fused(st, plist, o, d, 2.0, 6.0, S, False, white_bkgd=False)
     assert float((cp - (cq + (1.0 - ap))).abs().max()) <= 1e-6                  # white background identity
     assert bool(((ap >= 0) & (ap <= 1.0 + 1e-5)).all()) and bool(((dp >= 0) & (dp <= 6.0 * 1.0001)).all())
+
+
+# ------------------------------------------------------------- ragged / large-S / generic shapes
+@pytest.mark.parametrize("tag,R,S", [("4x128", 37, 50), ("8x256", 37, 50), ("8x256", 130, 128), ("4x128", 66, 256), ("8x256", 5, 2), ("4x128", 3, 33)])
+def test_fused_ragged_shapes_forward_and_gradients(mods, dev, tag, R, S):
+    """Sample counts that are not multiples of 32 (padding lanes, dump block), ray counts that are not multiples
+    of 4 (idle waves), several 64-sample segments per ray (transmittance carry): RGB/depth/acc and gradients."""
+    cfg, params = golden_params(tag)
+    gen = torch.Generator().manual_seed(R * 1000 + S)
+    d = torch.nn.functional.normalize(torch.randn(R, 3, generator=gen), dim=-1)
+    o = -4.0 * d + 0.3 * torch.randn(R, 3, generator=gen)
+    tgt, u = torch.rand(R, 3, generator=gen), torch.rand(R, S, generator=gen)
+    model = make_model(mods, cfg, params, dev)
+    st, plist = model._ensure_packed(), model._param_list()
+    with torch.no_grad():
+        c_inf, dep, acc = mods["ops"].render_rays_fused(st, plist, o.to(dev), d.to(dev), 2.0, 6.0, S, True, t_rand=u.to(dev))
+    co, do_, ao, _ = O.render_rays(params, cfg["skip_at"], cfg["L"], o, d, 2.0, 6.0, S, u)
+    assert float((c_inf.cpu() - co).abs().max()) <= RGB_TOL
+    assert float((dep.cpu() - do_).abs().max()) <= 1e-3 and float((acc.cpu() - ao).abs().max()) <= RGB_TOL
+    comp, _, _ = mods["ops"].render_rays_fused(st, plist, o.to(dev), d.to(dev), 2.0, 6.0, S, True, t_rand=u.to(dev))
+    assert torch.equal(comp.detach(), c_inf)                       # training forward == inference forward, bitwise
+    torch.mean((comp - tgt.to(dev)) ** 2).backward()
+    _, _, g32 = O.loss_and_grads(params, cfg["skip_at"], cfg["L"], o, d, tgt, 2.0, 6.0, S, u)
+    _, _, g64 = O.loss_and_grads([p.double() for p in params], cfg["skip_at"], cfg["L"], o.double(), d.double(), tgt.double(), 2.0, 6.0, S, u.double())
+    e_hip = max(relmax(p.grad.cpu().double(), gg) for p, gg in zip(plist, g64))
+    e_cpu = max(relmax(a.double(), gg) for a, gg in zip(g32, g64))
+    assert e_hip <= 8.0 * e_cpu + 2e-5, (e_hip, e_cpu)      # fp32 vs fp32, both judged against fp64
+
+
+def test_deterministic_render_of_large_sample_counts(mods, dev):
+    """BASELINE cfg 3/5 shapes per ray (S=128, S=256) without jitter: fused == unfused per-function path."""
+    cfg, params = golden_params("8x256")
+    model = make_model(mods, cfg, params, dev)
+    enc = mods["encoding"].PositionalEncoding(cfg["L"], True).to(dev)
+    g = load_golden("render_8x256")
+    ro, rd = mods["rays"].get_rays(40, 40, 55.0, g["pose"].to(dev))
+    st, plist = model._ensure_packed(), model._param_list()
+    for S in (128, 256):
+        with torch.no_grad():
+            cf, _, _ = mods["ops"].render_rays_fused(st, plist, ro, rd, 2.0, 6.0, S, False)
+            z, pts = mods["sampling"].stratified_samples(2.0, 6.0, S, ro, rd, randomized=False)
+            rgb, sig = model(enc(pts.reshape(-1, 3)))
+            cu, _, _, _ = mods["volume"].volume_render(rgb.reshape(-1, S, 3), sig.reshape(-1, S, 1), z, rd)
+        assert float((cf - cu).abs().max()) <= 2e-5
+        co, _, _, _ = O.render_rays(params, cfg["skip_at"], cfg["L"], ro.cpu().contiguous(), rd.cpu(), 2.0, 6.0, S, None)
+        assert float((cf.cpu() - co).abs().max()) <= RGB_TOL
+
+
+@pytest.mark.parametrize("in_dim,hidden,depth,skip", [(10, 128, 2, 1), (40, 256, 3, 0), (64, 128, 3, 2), (3, 128, 1, 0)])
+def test_mlp_generic_input_width(mods, dev, in_dim, hidden, depth, skip):
+    """TinyNeRF on inputs that are not a positional encoding (generic column pairing), ragged row counts."""
+    gen = torch.Generator().manual_seed(in_dim)
+    params = O.mlp_init(in_dim, hidden, depth, skip, gen)
+    params[2 * depth + 1] += 0.3
+    cfg = dict(in_dim=in_dim, hidden=hidden, depth=depth, skip_at=skip)
+    model = make_model(mods, cfg, params, dev)
+    x = torch.randn(333, in_dim, generator=gen)
+    rgb, sig = model(x.to(dev))
+    ro, so = O.mlp_forward(params, x, skip)
+    assert float((rgb.cpu() - ro).abs().max()) <= 2e-6 and float((sig.cpu() - so).abs().max()) <= 2e-5
+    g1, g2 = torch.randn(333, 3, generator=gen), torch.randn(333, 1, generator=gen)
+    ((rgb * g1.to(dev)).sum() + (sig * g2.to(dev)).sum()).backward()
+    leaves = [p.clone().requires_grad_(True) for p in params]
+    r2, s2 = O.mlp_forward(leaves, x, skip)
+    ((r2 * g1).sum() + (s2 * g2).sum()).backward()
+    for p, q in zip(model.parameters(), leaves):
+        assert relmax(p.grad.cpu(), q.grad) <= 5e-5
+
+
+def test_empty_batches(mods, dev):
+    cfg, params = golden_params("4x128")
+    model = make_model(mods, cfg, params, dev)
+    st, plist = model._ensure_packed(), model._param_list()
+    e3 = torch.zeros(0, 3, device=dev)
+    with torch.no_grad():
+        c, _, _ = mods["ops"].render_rays_fused(st, plist, e3, e3, 2.0, 6.0, 64, False)
+        r, s = model(torch.zeros(0, cfg["in_dim"], device=dev))
+    assert c.shape == (0, 3) and r.shape == (0, 3) and s.shape == (0, 1)
+    z, pts, _ = mods["ops"].sample_along_rays(2.0, 6.0, 64, e3, e3, True, t_rand=torch.zeros(0, 64, device=dev))
+    assert z.shape == (0, 64) and pts.shape == (0, 64, 3)
+
+
+def test_checkpoint_roundtrip_with_torch_adam(mods, dev, tmp_path):
+    """Checkpoint dict of the reference loop (train.py:143-148): our FlatAdam state loads into torch.optim.Adam
+    (and back) and both continue identically."""
+    cfg, params = golden_params("4x128")
+    g = load_golden("step_4x128")
+    S = g["u"].shape[-1]
+    m1 = make_model(mods, cfg, params, dev)
+    o1 = mods["trainer"].FlatAdam(m1, lr=5e-4)
+    t1 = mods["trainer"].FusedTrainer(m1, o1, 2.0, 6.0, S)
+    for step in range(3):
+        ro, rd, tgt = _step_inputs(g, cfg, step)
+        t1.step(ro.to(dev), rd.to(dev), tgt.to(dev), t_rand=g["u"][step].to(dev))
+    path = str(tmp_path / "ck.pth")
+    torch.save({"model": m1.state_dict(), "opt": o1.state_dict(), "step": 3, "in_dim": cfg["in_dim"],
+                "cfg": dict(hidden=cfg["hidden"], depth=cfg["depth"], skip_at=cfg["skip_at"])}, path)
+    ck = torch.load(path, map_location=dev)
+    # (a) into a fresh HIP model + torch.optim.Adam, autograd path
+    m2 = mods["nerf"].TinyNeRF(ck["in_dim"], **ck["cfg"]).to(dev)
+    m2.load_state_dict(ck["model"])
+    o2 = torch.optim.Adam(m2.parameters(), lr=5e-4)
+    o2.load_state_dict(ck["opt"])
+    # (b) into a fresh HIP model + FlatAdam
+    m3 = mods["nerf"].TinyNeRF(ck["in_dim"], **ck["cfg"]).to(dev)
+    m3.load_state_dict(ck["model"])
+    o3 = mods["trainer"].FlatAdam(m3, lr=5e-4)
+    o3.load_state_dict(ck["opt"])
+    t3 = mods["trainer"].FusedTrainer(m3, o3, 2.0, 6.0, S)
+    ro, rd, tgt = _step_inputs(g, cfg, 3)
+    u = g["u"][3].to(dev)
+    t1.step(ro.to(dev), rd.to(dev), tgt.to(dev), t_rand=u)
+    t3.step(ro.to(dev), rd.to(dev), tgt.to(dev), t_rand=u)
+    st2 = m2._ensure_packed()
+    comp, _, _ = mods["ops"].render_rays_fused(st2, m2._param_list(), ro.to(dev), rd.to(dev), 2.0, 6.0, S, True, t_rand=u)
+    o2.zero_grad(set_to_none=True)
+    torch.mean((comp - tgt.to(dev)) ** 2).backward()
+    o2.step()
+    for a, b, c in zip(m1.parameters(), m2.parameters(), m3.parameters()):
+        assert torch.equal(a, c)
+        assert float((a - b).abs().max()) <= 1e-6

@@ -231,6 +231,7 @@ extern "C" int tnerf_mlp_fwd(const tnerf_mlp_desc* d, const float* packed, const
                              float* stash, int64_t Mp, tnerf_stream_t stream) {
     FwdArgs a{};
     int rc = tn_build_layout(d, &a.L); if (rc) return rc;
+    if (M == 0) return TNERF_OK;                                   // empty batch: nothing to read or write
     if (M < 0 || !packed || !x || !rgb || !sigma || (stash && Mp < M)) {
         tn_set_error("tnerf_mlp_fwd: M=%lld packed=%p x=%p rgb=%p sigma=%p Mp=%lld", (long long)M, (const void*)packed,
                      (const void*)x, (void*)rgb, (void*)sigma, (long long)Mp);
@@ -251,7 +252,7 @@ int tn_fused_args(const char* who, FwdArgs& a, const tnerf_mlp_desc* d, const fl
         tn_set_error("%s: the fused path needs in_dim = 6L+3 (PositionalEncoding with include_input); got %d", who, a.L.in_dim);
         return TNERF_EUNSUPPORTED;
     }
-    if (R < 0 || S < 1 || S > 4096 || !packed || !rays_o || !rays_d || !ztab) {
+    if (R < 0 || S < 1 || S > 4096 || (R > 0 && (!packed || !rays_o || !rays_d || !ztab))) {
         tn_set_error("%s: R=%lld S=%d (1..4096) packed=%p rays_o=%p rays_d=%p ztab=%p", who, (long long)R, S, (const void*)packed,
                      (const void*)rays_o, (const void*)rays_d, (const void*)ztab);
         return TNERF_EINVAL;
@@ -269,8 +270,8 @@ extern "C" int tnerf_render_fused(const tnerf_mlp_desc* d, const float* packed, 
     FwdArgs a{};
     int rc = tn_fused_args("tnerf_render_fused", a, d, packed, rays_o, rays_d, R, S, ztab, randomized, t_rand, seed, offset, white);
     if (rc) return rc;
-    if (!comp) { tn_set_error("tnerf_render_fused: comp_rgb is NULL"); return TNERF_EINVAL; }
     if (R == 0) return TNERF_OK;
+    if (!comp) { tn_set_error("tnerf_render_fused: comp_rgb is NULL"); return TNERF_EINVAL; }
     a.comp = comp; a.depth = depth; a.acc = acc;
     return launch_fwd<true, false>(a, R, (hipStream_t)stream, "tnerf_render_fused");
 }
@@ -282,6 +283,7 @@ extern "C" int tnerf_train_fwd_fused(const tnerf_mlp_desc* d, const float* packe
     FwdArgs a{};
     int rc = tn_fused_args("tnerf_train_fwd_fused", a, d, packed, rays_o, rays_d, R, S, ztab, randomized, t_rand, seed, offset, white);
     if (rc) return rc;
+    if (R == 0) return TNERF_OK;
     if (!comp || !stash || Mp < R * S) {
         tn_set_error("tnerf_train_fwd_fused: comp=%p stash=%p Mp=%lld < R*S=%lld", (void*)comp, (void*)stash, (long long)Mp, (long long)(R * S));
         return TNERF_EINVAL;

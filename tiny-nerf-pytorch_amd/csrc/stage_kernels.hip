@@ -103,6 +103,7 @@ extern "C" int tnerf_sample_encode_fwd(const float* rays_o, const float* rays_d,
                                        const float* ztab, int32_t randomized, const float* t_rand,
                                        uint64_t seed, uint64_t offset, float* z_vals, float* pts,
                                        float* enc, int32_t L, int32_t include_input, tnerf_stream_t stream) {
+    if (R == 0 && S >= 1) return TNERF_OK;
     if (R < 0 || S < 1 || !rays_o || !rays_d || !ztab) {
         tn_set_error("tnerf_sample_encode_fwd: R=%lld S=%d rays_o=%p rays_d=%p ztab=%p", (long long)R, S,
                      (const void*)rays_o, (const void*)rays_d, (const void*)ztab);
@@ -125,6 +126,7 @@ extern "C" int tnerf_sample_encode_fwd(const float* rays_o, const float* rays_d,
 }
 
 extern "C" int tnerf_posenc_fwd(const float* x, int64_t n, int32_t L, int32_t include_input, float* out, tnerf_stream_t stream) {
+    if (n == 0) return TNERF_OK;
     if (n < 0 || !x || !out || L < 0 || L > 16 || 6 * L + (include_input ? 3 : 0) < 1) {
         tn_set_error("tnerf_posenc_fwd: n=%lld L=%d x=%p out=%p", (long long)n, L, (const void*)x, (void*)out);
         return TNERF_EINVAL;
@@ -247,6 +249,7 @@ __global__ __launch_bounds__(256) void k_composite_bwd(const float* __restrict__
 }
 
 static int composite_check(const char* who, const float* rgb, const float* sigma, const float* z, const float* rd, int64_t R, int S) {
+    if (R == 0 && S >= 1) return TNERF_OK;
     if (R < 0 || S < 1 || S > 4096 || !rgb || !sigma || !z || !rd) {
         tn_set_error("%s: R=%lld S=%d (S<=4096) rgb=%p sigma=%p z=%p rays_d=%p", who, (long long)R, S, (const void*)rgb,
                      (const void*)sigma, (const void*)z, (const void*)rd);
@@ -261,8 +264,8 @@ extern "C" int tnerf_composite_fwd(const float* rgb, const float* sigma, const f
                                    int64_t R, int32_t S, int32_t white, float* comp, float* depth, float* acc, float* weights,
                                    tnerf_stream_t stream) {
     int rc = composite_check("tnerf_composite_fwd", rgb, sigma, z_vals, rays_d, R, S); if (rc) return rc;
-    if (!comp) { tn_set_error("tnerf_composite_fwd: comp_rgb is NULL"); return TNERF_EINVAL; }
     if (R == 0) return TNERF_OK;
+    if (!comp) { tn_set_error("tnerf_composite_fwd: comp_rgb is NULL"); return TNERF_EINVAL; }
     hipLaunchKernelGGL(k_composite_fwd, dim3(ray_grid(R)), dim3(256), 0, (hipStream_t)stream, rgb, sigma, z_vals, rays_d, R, S, white,
                        comp, depth, acc, weights);
     TN_HIP_CHECK_LAUNCH("tnerf_composite_fwd");
@@ -273,8 +276,8 @@ extern "C" int tnerf_composite_bwd(const float* rgb, const float* sigma, const f
                                    int64_t R, int32_t S, int32_t white, const float* g_comp, const float* g_depth,
                                    const float* g_acc, const float* g_w, float* d_rgb, float* d_sigma, tnerf_stream_t stream) {
     int rc = composite_check("tnerf_composite_bwd", rgb, sigma, z_vals, rays_d, R, S); if (rc) return rc;
-    if (!d_rgb || !d_sigma) { tn_set_error("tnerf_composite_bwd: NULL output"); return TNERF_EINVAL; }
     if (R == 0) return TNERF_OK;
+    if (!d_rgb || !d_sigma) { tn_set_error("tnerf_composite_bwd: NULL output"); return TNERF_EINVAL; }
     hipLaunchKernelGGL(k_composite_bwd, dim3(ray_grid(R)), dim3(256), 0, (hipStream_t)stream, rgb, sigma, z_vals, rays_d, R, S, white,
                        g_comp, g_depth, g_acc, g_w, d_rgb, d_sigma);
     TN_HIP_CHECK_LAUNCH("tnerf_composite_bwd");

@@ -1,0 +1,44 @@
+"""Drop-in for the reference's src/make_gif.py: load the checkpoint, render the 60-pose spiral around the
+first camera, write outputs/novel_views.gif (imageio if present, else numbered PNG frames).
+[reference src/make_gif.py:9-33]"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from camera import spiral_poses                    # noqa: E402
+from data import load_scene                        # noqa: E402
+from encoding import PositionalEncoding            # noqa: E402
+from nerf import TinyNeRF                          # noqa: E402
+from train import render_one, write_png            # noqa: E402
+
+
+def main(ckpt_path="checkpoints/tinynerf_latest.pth", out_dir="outputs"):
+    device = torch.device("cuda")
+    d = load_scene("data/tiny_nerf_data.npz")
+    H, W, focal = d["images"].shape[1], d["images"].shape[2], float(d["focal"])
+    poses = torch.from_numpy(d["poses"]).to(device)
+    ckpt = torch.load(ckpt_path, map_location=device)
+    in_dim = int(ckpt["in_dim"])
+    encoder = PositionalEncoding(num_freqs=(in_dim - 3) // 6, include_input=True).to(device)
+    model = TinyNeRF(in_dim=in_dim, **ckpt["cfg"]).to(device)
+    model.load_state_dict(ckpt["model"])
+    frames = []
+    for pose in spiral_poses(poses[0], n_frames=60, radius=0.3):
+        img = render_one(model, encoder, H, W, focal, pose, device, n_samples=64, near=2.0, far=6.0)
+        frames.append((img.cpu().numpy() * 255).astype(np.uint8))
+    os.makedirs(out_dir, exist_ok=True)
+    try:
+        import imageio.v2 as imageio
+        imageio.mimsave(os.path.join(out_dir, "novel_views.gif"), frames, duration=1 / 24)
+        print(f"[save] {out_dir}/novel_views.gif")
+    except ImportError:
+        for i, f in enumerate(frames):
+            write_png(os.path.join(out_dir, f"novel_view_{i:03d}.png"), f)
+        print(f"[save] {out_dir}/novel_view_000..{len(frames) - 1:03d}.png (imageio not installed: no GIF)")
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:])
