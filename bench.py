@@ -224,8 +224,13 @@ def main():
         step_kernels = ("train_fwd", "dgrad", "wgrad")
         dom = max(step_kernels, key=lambda k: kern[k])
         ach = fl[dom] / (kern[dom] * 1e-3) / 1e12
+        traffic = None
+        try:      # HBM bytes per launch from the committed PMC passes (profiles/r01_traffic.json; see its _note)
+            traffic = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))[dom]["hbm_bytes"]
+        except (OSError, KeyError, ValueError):
+            pass
         out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                           "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                           "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
                            "flops_per_launch": fl[dom], "ms_per_launch": kern[dom]}
         out["kernels"] = {k: {"ms": kern[k], "tflops": (fl[k] / (kern[k] * 1e-3) / 1e12) if k in fl else None} for k in kern}
         step_flops = sum(fl[k] for k in step_kernels)
