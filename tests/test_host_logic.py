@@ -261,7 +261,8 @@ def test_wgrad_jobs_and_reduce_table_reproduce_autograd(cfg, M, n_cu):
     covered = {}
     for jb in jobs:
         a0, ar, b0, br, nat, nbt, wa, blk0, nblk, soff, cls, hasb = (int(v) for v in jb[:12])
-        assert nat % wa == 0 and nbt % (4 // wa) == 0
+        ta, tb = -(-nat // wa), -(-nbt // (8 // wa))          # tiles per wave: every wave is full or idle
+        assert wa in (1, 2, 4, 8) and nat % ta == 0 and nbt % tb == 0 and (ta, tb) in ((2, 4), (1, 2), (2, 1), (1, 1))
         m0, m1 = blk0 * 32, min(M, (blk0 + nblk) * 32)
         assert nblk > 0 and m0 < M
         covered.setdefault(cls, []).append((m0, m1))

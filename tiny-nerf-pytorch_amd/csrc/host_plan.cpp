@@ -159,13 +159,22 @@ struct JobClass {
     int64_t slab_stride;   // floats per chunk
 };
 
+// The 8 waves of a wgrad workgroup form a WA x (8/WA) grid over the (n_at x n_bt) tile grid; every wave gets
+// ta x tb tiles (ta = ceil(n_at/WA), ...) or, if its origin is outside the grid, nothing.  Only the (ta,tb) shapes
+// instantiated in wgrad.hip are eligible, and partially filled waves are not allowed.
+static bool split_ok(int n_at, int n_bt, int wa, int* cost, int* ld) {
+    const int wb = 8 / wa;
+    const int ta = (n_at + wa - 1) / wa, tb = (n_bt + wb - 1) / wb;
+    const bool shape = (ta == 2 && tb == 4) || (ta == 1 && tb == 2) || (ta == 2 && tb == 1) || (ta == 1 && tb == 1);
+    if (!shape || n_at % ta != 0 || n_bt % tb != 0) return false;
+    *cost = ta * tb; *ld = ta + tb;
+    return true;
+}
 static void pick_split(int n_at, int n_bt, int* wa_out, int* cost_out) {
-    int best_wa = 1, best_cost = 1 << 30, best_ld = 1 << 30;
-    for (int wa = 1; wa <= 4; wa *= 2) {
-        const int wb = 4 / wa;
-        const int ta = (n_at + wa - 1) / wa, tb = (n_bt + wb - 1) / wb;
-        if (ta > 4 || tb > 4) continue;
-        const int cost = ta * tb, ld = ta + tb;
+    int best_wa = 0, best_cost = 1 << 30, best_ld = 1 << 30;
+    for (int wa = 1; wa <= 8; wa *= 2) {
+        int cost, ld;
+        if (!split_ok(n_at, n_bt, wa, &cost, &ld)) continue;
         if (cost < best_cost || (cost == best_cost && ld < best_ld)) { best_cost = cost; best_ld = ld; best_wa = wa; }
     }
     *wa_out = best_wa; *cost_out = best_cost;
@@ -177,12 +186,7 @@ static int build_classes(const MlpLayout& L, int64_t M, int n_cu, std::vector<Jo
     auto add = [&](int a0, int ar, int b0, int br, int nat, int nbt, int bias) {
         JobClass c{}; c.a_row0 = a0; c.a_rows = ar; c.b_row0 = b0; c.b_rows = br; c.n_at = nat; c.n_bt = nbt; c.has_bias = bias;
         pick_split(nat, nbt, &c.wa, &c.cost); cls.push_back(c);
-        if (nat % c.wa != 0 || nbt % (4 / c.wa) != 0) bad_split = true;
-        else {   // per-wave tile shapes instantiated in wgrad.hip
-            const int ta = nat / c.wa, tb = nbt / (4 / c.wa);
-            const bool ok = (ta == 4 && tb == 4) || (ta == 2 && tb == 2) || (ta == 1 && tb == 2) || (ta == 2 && tb == 1) || (ta == 1 && tb == 1);
-            if (!ok) bad_split = true;
-        }
+        if (c.wa == 0) bad_split = true;
     };
     // class index order is what reduce_table refers to:
     //   [l]            l>=1 : (dZ_l, H_{l-1})     owns b_l
@@ -207,7 +211,7 @@ static int build_classes(const MlpLayout& L, int64_t M, int n_cu, std::vector<Jo
             if (cls[i].chunks >= MB) continue;
             // cycles per 32-sample block: 64 per MFMA step (16 steps per tile) + a fixed cost for staging the block
             // through LDS and the barrier (measured ~3k cycles; it dominates the small enc / head classes)
-            const double t = ((double)cls[i].cost * 1024.0 + 3000.0) * (double)((MB + cls[i].chunks - 1) / cls[i].chunks);
+            const double t = ((double)cls[i].cost * 2048.0 + 2500.0) * (double)((MB + cls[i].chunks - 1) / cls[i].chunks);   // two waves share each SIMD
             if (t > best_t) { best_t = t; best = (int)i; }
         }
         if (best < 0) break;

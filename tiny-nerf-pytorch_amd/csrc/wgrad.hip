@@ -3,8 +3,8 @@
 // wgrad: for every layer  dW[n][k] = sum_m dZ^T[n][m] * X^T[k][m]   (X = the layer's input)
 // Both operands are rows of the block-major stash ([32-sample block][row][32], tnerf_internal.h), so an MFMA
 // fragment "lane = row, 4 consecutive samples" is one 16-byte piece of a 128-byte line.  A workgroup
-// (4 waves, one per SIMD) owns one (A rows x B rows) block of up to 256x256 outputs for one chunk
-// of samples: the 4 waves split it 2x2 / 4x1 / 1x4 (<= 4x4 tiles of 32x32 = 256 accumulator
+// (8 waves, two per SIMD) owns one (A rows x B rows) block of up to 256x256 outputs for one chunk
+// of samples: the 8 waves split it 4x2 / 8x1 / 1x8 (<= 2x4 tiles of 32x32 = 128 accumulator
 // registers per wave).  Per 32-sample step the workgroup stages [rows][32] of A and B through LDS
 // in whole 128-byte lines (global -> registers -> LDS, next block in flight during the MFMAs),
 // XOR-swizzled so that the ds_read_b128 fragment reads are bank-conflict free.  Each workgroup
@@ -23,7 +23,7 @@ template <int TA, int TB>
 __device__ __forceinline__ void wgrad_body(const float* __restrict__ stash, int64_t stash_rows, int64_t M, const int32_t* __restrict__ job,
                                            float* __restrict__ slabs, float* lds) {
     const int tid = (int)threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // 0..7: two waves per SIMD
     const int n_at = job[JOB_N_AT], n_bt = job[JOB_N_BT], WA = job[JOB_WA];
     const int a_rows = job[JOB_A_ROWS], b_rows = job[JOB_B_ROWS];
     const int64_t a_row0 = job[JOB_A_ROW0], b_row0 = job[JOB_B_ROW0];
@@ -31,7 +31,7 @@ __device__ __forceinline__ void wgrad_body(const float* __restrict__ stash, int6
     const int wa = wave % WA, wb = wave / WA;
     const int a_t0 = wa * TA, b_t0 = wb * TB;                  // first tile of this wave
     const int rows_a = n_at * 32, rows_b = n_bt * 32, rows = rows_a + rows_b;
-    constexpr int MAXLD = (2 * WG_LDS_ROWS) / 32;              // 16 row-groups of 32 rows
+    constexpr int MAXLD = (2 * WG_LDS_ROWS) / 64;              // 8 row-groups of 64 rows (512 threads x 16 B = 64 lines)
 
     f32x16 acc[TA][TB];
 #pragma unroll
@@ -44,28 +44,23 @@ __device__ __forceinline__ void wgrad_body(const float* __restrict__ stash, int6
 #pragma unroll
     for (int i = 0; i < TA; ++i) bsum[i] = 0.0f;
 
-    // staging: thread -> (row within a 32-row group = tid>>3, 16-byte chunk = tid&7)
+    // staging: thread -> (row within a 64-row group = tid>>3, 16-byte chunk = tid&7).  Rows that do not exist
+    // (head: 4 of 32, enc: 40 of 64) are clamped to a valid row for the load and zeroed when the block is written
+    // to LDS, so the loads are unconditional and all stay in flight behind the MFMAs.
     const int srow = tid >> 3, schunk = tid & 7;
+    const int ngroups = (rows + 63) / 64;
     f32x4 stage[MAXLD];
-    // Per-thread source offsets of the (up to 16) 32-row groups, relative to the start of a block, computed once:
-    // rows that do not exist (head: 4 of 32, enc: 40 of 64) are clamped to a valid row here and zeroed when the
-    // block is written to LDS, so the loads themselves are unconditional and all stay in flight behind the MFMAs.
-    int32_t soff[MAXLD]; bool slive[MAXLD]; int32_t doff[MAXLD];
-    tn_static_for<MAXLD>([&](auto gc) TN_INLINE_LAMBDA {
-        constexpr int g = decltype(gc)::value;
-        const bool isA = g * 32 < rows_a;
-        const int lr = (isA ? g * 32 : g * 32 - rows_a) + srow;
-        const int lim = (isA ? a_rows : b_rows) - 1;
-        soff[g] = (int32_t)(((isA ? a_row0 : b_row0) + (lr < lim ? lr : lim)) * 32 + schunk * 4);
-        slive[g] = lr <= lim;
-        doff[g] = (isA ? 0 : WG_LDS_ROWS * 32) + wg_lds_off(lr, schunk);
-    });
-    const int ngroups = rows / 32;
     auto stage_load = [&](int blk) TN_INLINE_LAMBDA {
-        const float* blkbase = stash + (int64_t)blk * stash_rows * 32;
+        const float* blkbase = stash + (int64_t)blk * stash_rows * 32 + schunk * 4;
         tn_static_for<MAXLD>([&](auto gc) TN_INLINE_LAMBDA {
             constexpr int g = decltype(gc)::value;
-            if (g < ngroups) stage[g] = *reinterpret_cast<const f32x4*>(blkbase + soff[g]);     // wave-uniform branch
+            if (g < ngroups) {                                                // wave-uniform
+                const int row = g * 64 + srow;                                // combined A|B row (A and B never share a wave: 32 | rows_a)
+                const bool isA = row < rows_a;
+                const int lr = isA ? row : row - rows_a;
+                const int lim = (isA ? a_rows : b_rows) - 1;
+                stage[g] = *reinterpret_cast<const f32x4*>(blkbase + ((isA ? a_row0 : b_row0) + (lr < lim ? lr : lim)) * 32);
+            }
         });
     };
     auto stage_store = [&](int blk, int buf) TN_INLINE_LAMBDA {
@@ -76,13 +71,18 @@ __device__ __forceinline__ void wgrad_body(const float* __restrict__ stash, int6
         tn_static_for<MAXLD>([&](auto gc) TN_INLINE_LAMBDA {
             constexpr int g = decltype(gc)::value;
             if (g < ngroups) {
-                f32x4 v = stage[g];
-                if (!slive[g]) v = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (tail) {
-                    v[0] = nvalid > 0 ? v[0] : 0.f; v[1] = nvalid > 1 ? v[1] : 0.f;
-                    v[2] = nvalid > 2 ? v[2] : 0.f; v[3] = nvalid > 3 ? v[3] : 0.f;
+                const int row = g * 64 + srow;
+                if (row < rows) {
+                    const bool isA = row < rows_a;
+                    const int lr = isA ? row : row - rows_a;
+                    f32x4 v = stage[g];
+                    if (lr >= (isA ? a_rows : b_rows)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (tail) {
+                        v[0] = nvalid > 0 ? v[0] : 0.f; v[1] = nvalid > 1 ? v[1] : 0.f;
+                        v[2] = nvalid > 2 ? v[2] : 0.f; v[3] = nvalid > 3 ? v[3] : 0.f;
+                    }
+                    *reinterpret_cast<f32x4*>(base + (isA ? 0 : WG_LDS_ROWS * 32) + wg_lds_off(lr, schunk)) = v;
                 }
-                *reinterpret_cast<f32x4*>(base + doff[g]) = v;
             }
         });
     };
@@ -144,16 +144,16 @@ __device__ __forceinline__ void wgrad_body(const float* __restrict__ stash, int6
     }
 }
 
-__global__ __launch_bounds__(256, 1) void k_wgrad(const float* __restrict__ stash, int64_t stash_rows, int64_t M,
+// 512 threads = 8 waves = TWO per SIMD (<= 8 accumulator tiles = 128 registers per wave): while one wave of a SIMD
+// waits for LDS fragments, the staging writes or the barrier, the other one keeps the matrix pipe busy.
+__global__ __launch_bounds__(512, 2) void k_wgrad(const float* __restrict__ stash, int64_t stash_rows, int64_t M,
                                                   const int32_t* __restrict__ jobs, float* __restrict__ slabs) {
     __shared__ __attribute__((aligned(16))) float lds[WG_LDS_FLOATS];
     const int32_t* job = jobs + (int64_t)blockIdx.x * TN_JOB_INTS;
-    const int n_at = job[JOB_N_AT], n_bt = job[JOB_N_BT], WA = job[JOB_WA], WB = 4 / WA;
-    const int ta = n_at / WA, tb = n_bt / WB;               // host plan guarantees exact division (or a 1-tile remainder wave)
-    const int key = (ta > 0 ? ta : 1) * 8 + (tb > 0 ? tb : 1);
-    switch (key) {
-        case 4 * 8 + 4: wgrad_body<4, 4>(stash, stash_rows, M, job, slabs, lds); break;
-        case 2 * 8 + 2: wgrad_body<2, 2>(stash, stash_rows, M, job, slabs, lds); break;
+    const int n_at = job[JOB_N_AT], n_bt = job[JOB_N_BT], WA = job[JOB_WA], WB = 8 / WA;
+    const int ta = (n_at + WA - 1) / WA, tb = (n_bt + WB - 1) / WB;     // the host plan only emits full-or-idle waves
+    switch (ta * 8 + tb) {
+        case 2 * 8 + 4: wgrad_body<2, 4>(stash, stash_rows, M, job, slabs, lds); break;
         case 1 * 8 + 2: wgrad_body<1, 2>(stash, stash_rows, M, job, slabs, lds); break;
         case 2 * 8 + 1: wgrad_body<2, 1>(stash, stash_rows, M, job, slabs, lds); break;
         case 1 * 8 + 1: wgrad_body<1, 1>(stash, stash_rows, M, job, slabs, lds); break;
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256, 1) void k_wgrad(const float* __restrict__ stas
 }
 
 int tn_launch_wgrad(const float* stash, int64_t stash_rows, int64_t M, const int32_t* jobs, int64_t n_jobs, float* slabs, hipStream_t stream) {
-    hipLaunchKernelGGL(k_wgrad, dim3((unsigned)n_jobs), dim3(256), 0, stream, stash, stash_rows, M, jobs, slabs);
+    hipLaunchKernelGGL(k_wgrad, dim3((unsigned)n_jobs), dim3(512), 0, stream, stash, stash_rows, M, jobs, slabs);
     TN_HIP_CHECK_LAUNCH("wgrad");
     return TNERF_OK;
 }
