@@ -17,6 +17,9 @@
 #include <type_traits>
 #include "dev_common.hpp"
 
+#ifndef TN_PFDIST
+#define TN_PFDIST 6
+#endif
 #define TN_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
 // Compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>).  The hot loops
@@ -46,7 +49,7 @@ __device__ __forceinline__ void tn_layer(const float* __restrict__ packed, int64
     constexpr int GE = HAS_ENC ? NE / 4 : 0;   // ... fed by the network input
     constexpr int GT = GH + GE;
     constexpr int TOTAL = NT * GT;
-    constexpr int PF = 6;                       // A-fragment prefetch distance (groups of 4 MFMAs = 256 cycles each)
+    constexpr int PF = TN_PFDIST;               // A-fragment prefetch distance (groups of 4 MFMAs = 256 cycles each)
     const f32x4* __restrict__ Wh = reinterpret_cast<const f32x4*>(packed + (HAS_HID ? off_hid : 0)) + lane;
     const f32x4* __restrict__ We = reinterpret_cast<const f32x4*>(packed + (HAS_ENC ? off_enc : 0)) + lane;
     const f32x4* __restrict__ Bf = reinterpret_cast<const f32x4*>(packed + off_bias) + (lane >> 5) * 4;
@@ -101,7 +104,7 @@ __device__ __forceinline__ void tn_layer_bwd(const float* __restrict__ packed, i
     constexpr int NT = HID / 32;
     constexpr int GT = NT * 4;
     constexpr int TOTAL = NT * GT;
-    constexpr int PF = 6;
+    constexpr int PF = TN_PFDIST;
     const f32x4* __restrict__ Wt = reinterpret_cast<const f32x4*>(packed + off_bw) + lane;
     f32x4 ring[PF];
     tn_static_for<PF>([&](auto ic) TN_INLINE_LAMBDA { constexpr int i = decltype(ic)::value; ring[i] = Wt[i * 64]; });

@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtnerf_hip.so")
+LIB_PATH = os.environ.get("TNERF_LIB") or os.path.join(_HERE, "libtnerf_hip.so")   # TNERF_LIB: A/B a diagnostic build
 
 OK, EINVAL, EUNSUPPORTED, ESMALL = 0, -1, -2, -3
 
