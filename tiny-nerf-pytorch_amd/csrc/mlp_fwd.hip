@@ -10,6 +10,9 @@
 #include "mlp_core.hpp"
 #include "mlp_args.hpp"
 
+#ifndef TN_DEBUG_DYN_LDS
+#define TN_DEBUG_DYN_LDS 0      // diagnostic builds: dynamic LDS bytes requested only to cap residency at 1 workgroup/CU
+#endif
 #ifdef TN_STAMPS
 #define TN_STAMP(k) do { if (a.stamps && lane == 0) a.stamps[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 32 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
@@ -211,8 +214,8 @@ static int launch_fwd(const FwdArgs& a, int64_t units, hipStream_t stream, const
     const int hid = a.L.hidden, ne = a.L.NE;
 #define TN_CASE(H_, N_)                                                                                     \
     if (hid == H_ && ne == N_) {                                                                            \
-        if (FUSED) hipLaunchKernelGGL((k_render_fused<H_, N_, TRAIN>), grid, block, 0, stream, a);          \
-        else       hipLaunchKernelGGL((k_mlp_fwd<H_, N_, TRAIN>), grid, block, 0, stream, a);               \
+        if (FUSED) hipLaunchKernelGGL((k_render_fused<H_, N_, TRAIN>), grid, block, TN_DEBUG_DYN_LDS, stream, a);  \
+        else       hipLaunchKernelGGL((k_mlp_fwd<H_, N_, TRAIN>), grid, block, TN_DEBUG_DYN_LDS, stream, a);      \
         TN_HIP_CHECK_LAUNCH(who);                                                                           \
         return TNERF_OK;                                                                                    \
     }
