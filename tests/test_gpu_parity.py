@@ -261,7 +261,7 @@ def test_train_gradients_match_oracle(mods, dev, tag):
     print(f"[{tag}] grad rel err vs fp64: hip {worst_hip:.2e}, cpu-fp32 oracle {worst_cpu:.2e}")
     assert worst_hip <= 4.0 * worst_cpu + 1e-5, (worst_hip, worst_cpu)
     worst = max(relmax(p.grad.cpu(), go) for p, go in zip(plist, grads_o))
-    assert worst <= 2e-3, worst
+    assert worst <= 1e-2, worst                      # fp32 HIP vs fp32 oracle directly (each ~2e-3 from fp64)
     gn = torch.stack([p.grad.norm().cpu() for p in plist])
     torch.testing.assert_close(gn, g["gnorm0"], rtol=5e-3, atol=1e-9)      # fp32-vs-fp32; both sit ~2e-3 from fp64 (printed above)
     # unfused autograd path (per-function HIP ops) gives the same gradients

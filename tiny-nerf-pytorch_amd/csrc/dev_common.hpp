@@ -43,20 +43,18 @@ __device__ __forceinline__ float tn_philox_uniform(uint64_t seed, uint64_t index
 }
 
 // ------------------------------------------------------------------------------ sin / cos
-// Both sin and cos of the same argument with ONE Cody-Waite reduction (3-term pi/2 split, fma) and
-// minimax polynomials on [-pi/4, pi/4]: <= 1.5 ulp (max abs error 7.1e-8) for |x| < 1e5, checked
-// against fp64 on the host.  The encoder's arguments 2^k * p are exact in fp32 and far
-// inside that range; anything larger (or NaN/Inf) takes the ocml full-range path, kept out of line so
-// the 18-30 call sites per tile stay ~25 instructions each.
-__device__ __attribute__((noinline)) void tn_sincos_slow(float x, float* s, float* c) { sincosf(x, s, c); }
-
+// Both sin and cos of the same argument from ONE range reduction, branch-free and call-free (a call inside the MFMA
+// kernels would spill the live activation registers): the reduction x - j*pi/2 is done in fp64 (2-term pi/2, exact
+// enough for every fp32 argument up to ~1e15), the minimax polynomials on [-pi/4, pi/4] in fp32.
+// <= 1.5 ulp / 7.3e-8 absolute against fp64 on 3e7 points up to |x| = 1e9 (checked on the host);
+// inf / nan give nan like libm.  The encoder's arguments 2^k * p are exact in fp32.
 __device__ __forceinline__ void tn_sincos(float x, float& sn, float& cs) {
-    if (__builtin_expect(!(fabsf(x) < 1.0e5f), 0)) { tn_sincos_slow(x, &sn, &cs); return; }
-    const float j = fmaf(x, 0.636619747f, 12582912.0f) - 12582912.0f;
-    float a = fmaf(j, -1.57079601e+00f, x);
-    a = fmaf(j, -3.13916473e-07f, a);
-    a = fmaf(j, -5.39030253e-15f, a);
-    const int q = (int)j;
+    const double xd = (double)x;
+    const double jd = rint(xd * 0.63661977236758134308);
+    double rd = fma(-jd, 1.57079632679489655800e+00, xd);
+    rd = fma(-jd, 6.12323399573676603587e-17, rd);
+    const float a = (float)rd;
+    const int q = (int)((long long)jd & 3);
     const float s2 = __fmul_rn(a, a);
     float r = 2.86567956e-6f;
     r = fmaf(r, s2, -1.98559923e-4f); r = fmaf(r, s2, 8.33338592e-3f); r = fmaf(r, s2, -1.66666672e-1f);

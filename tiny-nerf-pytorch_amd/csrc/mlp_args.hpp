@@ -32,6 +32,10 @@ int tn_launch_fwd(const FwdArgs& a, bool fused, bool train, int64_t units, hipSt
 int tn_fused_args(const char* who, FwdArgs& a, const tnerf_mlp_desc* d, const float* packed, const float* rays_o,
                   const float* rays_d, int64_t R, int32_t S, const float* ztab, int32_t randomized, const float* t_rand,
                   uint64_t seed, uint64_t offset, int32_t white);
+// mlp_pair.hip: two wavefronts per tile, two waves per SIMD (fused paths only)
+int tn_launch_fwd_pair(const FwdArgs& a, bool train, hipStream_t stream, const char* who);
+int tn_launch_train_bwd_pair(const BwdArgs& a, hipStream_t stream);
+bool tn_use_pair();   // TNERF_PAIR=0 selects the one-wave-per-tile kernels
 // mlp_bwd.hip
 int tn_launch_mlp_bwd(const BwdArgs& a, hipStream_t stream);
 int tn_launch_train_bwd(const BwdArgs& a, hipStream_t stream);

@@ -1,7 +1,14 @@
 // C-ABI entry points that chain several kernels: backward passes, the whole train step, RCCL.
 #include <dlfcn.h>
 #include <cstring>
+#include <cstdlib>
 #include "mlp_args.hpp"
+
+// Kernel family of the fused paths: wave pairs (default) or one wave per tile (TNERF_PAIR=0).  Read once.
+bool tn_use_pair() {
+    static const bool v = [] { const char* e = getenv("TNERF_PAIR"); return e ? (e[0] != '0') : false; }();
+    return v;
+}
 
 static int bwd_common_check(const char* who, const float* packed, float* stash, int64_t Mp, int64_t M, const int32_t* job_table,
                             int64_t n_jobs, float* slabs, const int32_t* reduce_table, float* grads) {
@@ -39,7 +46,7 @@ static int train_bwd_impl(const char* who, const tnerf_mlp_desc* d, const float*
     BwdArgs a{};
     a.L = f.L; a.packed = packed; a.stash = stash; a.Mp = Mp; a.rays_o = rays_o; a.rays_d = rays_d; a.R = R; a.sa = f.sa;
     a.white = white; a.g_comp = g_comp;
-    if ((rc = tn_launch_train_bwd(a, s))) return rc;
+    if ((rc = tn_use_pair() ? tn_launch_train_bwd_pair(a, s) : tn_launch_train_bwd(a, s))) return rc;
     if ((rc = tn_launch_wgrad(stash, a.L.stash_rows, R * S, job_table, n_jobs, slabs, s))) return rc;
     return tn_launch_reduce(slabs, reduce_table, a.L.n_params, grads, s);
 }
@@ -64,7 +71,7 @@ extern "C" int tnerf_train_dgrad_fused(const tnerf_mlp_desc* d, const float* pac
     BwdArgs a{};
     a.L = f.L; a.packed = packed; a.stash = stash; a.Mp = Mp; a.rays_o = rays_o; a.rays_d = rays_d; a.R = R; a.sa = f.sa;
     a.white = white; a.g_comp = g_comp;
-    return tn_launch_train_bwd(a, (hipStream_t)stream);
+    return tn_use_pair() ? tn_launch_train_bwd_pair(a, (hipStream_t)stream) : tn_launch_train_bwd(a, (hipStream_t)stream);
 }
 
 extern "C" int tnerf_wgrad(const tnerf_mlp_desc* d, const float* stash, int64_t Mp, int64_t M, const int32_t* job_table, int64_t n_jobs,
