@@ -114,8 +114,11 @@ def main():
         raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or bool(os.environ.get("TNERF_FORCE_DIST"))      # the env var exercises RCCL init with one rank
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
     from tnerf import ops, trainer, lib
@@ -163,8 +166,8 @@ def main():
         return tr.step(ro, rd, tgt, t_rand=u, global_rays=world * RAYS)
 
     def fence():
-        if world > 1:
-            dist.barrier()
+        if use_dist:
+            dist.barrier(device_ids=[local])
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -175,7 +178,7 @@ def main():
         loss, _ = one_step()
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -254,7 +257,7 @@ def main():
     fence()
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

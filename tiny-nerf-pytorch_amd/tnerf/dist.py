@@ -25,7 +25,9 @@ def shard_bounds(n: int, rank: int, world_size: int) -> Tuple[int, int]:
 
 
 def all_reduce_sum_(flat: torch.Tensor) -> torch.Tensor:
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    """SUM over ranks, in place (a process group of one rank still goes through the collective: that is how the
+    RCCL path is exercised on a single-GPU box)."""
+    if dist.is_available() and dist.is_initialized():
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     return flat
 
