@@ -103,6 +103,9 @@ def main():
     ap.add_argument("--psnr-steps", type=int, default=1000, help="extra untimed steps before reporting PSNR (rank 0 context)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--philox", action="store_true", help="draw the jitter in-kernel (Philox) instead of torch.rand")
+    ap.add_argument("--ray-tables", action="store_true",
+                    help="gather rays/targets from precomputed (N,HW,3) tables like the reference loop (train.py:94-112) "
+                         "instead of generating them in the kernel from pose + pixel index")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -159,11 +162,14 @@ def main():
         s = state["step"]; state["step"] += 1
         img_i = s % N
         inds = torch.randint(0, H * W, (world * RAYS,), device=dev, generator=gen)[rank * RAYS:(rank + 1) * RAYS]
-        ro, rd, tgt = all_o[img_i, inds], all_d[img_i, inds], pixels[img_i, inds]
+        kw = dict(global_rays=world * RAYS)
         if args.philox:
-            return tr.step(ro, rd, tgt, philox=(1234, s * world * RAYS * SAMPLES + rank * RAYS * SAMPLES), global_rays=world * RAYS)
-        u = torch.rand(world * RAYS, SAMPLES, device=dev, generator=gen)[rank * RAYS:(rank + 1) * RAYS]
-        return tr.step(ro, rd, tgt, t_rand=u, global_rays=world * RAYS)
+            kw["philox"] = (1234, s * world * RAYS * SAMPLES + rank * RAYS * SAMPLES)
+        else:
+            kw["t_rand"] = torch.rand(world * RAYS, SAMPLES, device=dev, generator=gen)[rank * RAYS:(rank + 1) * RAYS]
+        if args.ray_tables:
+            return tr.step(all_o[img_i, inds], all_d[img_i, inds], pixels[img_i, inds], **kw)
+        return tr.step_camera(poses[img_i], H, W, focal, inds, pixels[img_i], **kw)
 
     def fence():
         if use_dist:
@@ -190,7 +196,7 @@ def main():
            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": "train step: 100x100 synthetic Lego stand-in, 106 views, L=6 posenc, 8x256 ReLU MLP (skip 4), "
                                   "64 samples/ray, 4096 rays per GPU per step, Adam, fp32 (BASELINE.json configs[1])",
-                      "rays_per_gpu": RAYS, "samples_per_ray": SAMPLES, "jitter": "philox-in-kernel" if args.philox else "torch.rand",
+                      "rays_per_gpu": RAYS, "samples_per_ray": SAMPLES, "jitter": "philox-in-kernel" if args.philox else "torch.rand", "rays": "precomputed tables + gather" if args.ray_tables else "generated in-kernel from pose + pixel index",
                       "parallelism": f"rays sharded x{world}, 1 all-reduce of {opt._st.n_params * 4} B per step" if world > 1 else "single GPU"}}
 
     if rank == 0:

@@ -210,6 +210,35 @@ int tnerf_train_step_fused(const tnerf_mlp_desc* d, const float* packed,
                            const int32_t* job_table, int64_t n_jobs, float* slabs,
                            const int32_t* reduce_table, float* grads, tnerf_stream_t stream);
 
+/* Camera-sourced rays: instead of gathering from the (N,HW,3) tables that the reference
+ * precomputes with get_rays (src/train.py:94-101,110-112), ray r is generated inside the fused kernels from the
+ * pose and the flat pixel index p = pix_index ? pix_index[r] : pix_first + r, with the arithmetic of tnerf_get_rays. */
+typedef struct tnerf_camera {
+    const float*   c2w;        /* device, 16 floats row-major                               */
+    int32_t        H, W;
+    float          focal;
+    const int64_t* pix_index;  /* device [n_rays] flat pixel indices (randint, train.py:109) or NULL */
+    int64_t        pix_first;  /* used when pix_index == NULL: pixels pix_first .. pix_first+n_rays-1 */
+} tnerf_camera;
+
+/* tnerf_render_fused with camera rays (one chunk of render_one, src/train.py:46-56). */
+int tnerf_render_fused_cam(const tnerf_mlp_desc* d, const float* packed, const tnerf_camera* cam,
+                           int64_t n_rays, int32_t n_samples,
+                           const float* ztab, int32_t randomized, const float* t_rand,
+                           uint64_t seed, uint64_t offset, int32_t white_bkgd,
+                           float* comp_rgb, float* depth, float* acc, tnerf_stream_t stream);
+
+/* tnerf_train_step_fused with camera rays; the target colour of ray r is pixels[pix_index[r]] (pixels: [H*W,3] of the
+ * image being trained on, src/train.py:101,112). */
+int tnerf_train_step_fused_cam(const tnerf_mlp_desc* d, const float* packed, const tnerf_camera* cam,
+                               const float* pixels, int64_t n_rays, int32_t n_samples,
+                               const float* ztab, int32_t randomized, const float* t_rand,
+                               uint64_t seed, uint64_t offset, int32_t white_bkgd, double loss_denominator,
+                               float* comp_rgb, float* g_comp_ws, float* loss_out,
+                               float* stash, int64_t stash_row_stride,
+                               const int32_t* job_table, int64_t n_jobs, float* slabs,
+                               const int32_t* reduce_table, float* grads, tnerf_stream_t stream);
+
 /* torch.optim.Adam(lr, betas, eps, weight_decay=0) on the flat buffers   [src/train.py:80,127]
  * step = 1-based step count t used for the bias corrections; grad_scale multiplies the gradient
  * first (1/world_size after an all-reduce SUM of already globally-normalised shards = 1). */

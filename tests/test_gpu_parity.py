@@ -469,3 +469,37 @@ def test_checkpoint_roundtrip_with_torch_adam(mods, dev, tmp_path):
     for a, b, c in zip(m1.parameters(), m2.parameters(), m3.parameters()):
         assert torch.equal(a, c)
         assert float((a - b).abs().max()) <= 1e-6
+
+
+def test_camera_sourced_rays_equal_table_rays_bitwise(mods, dev):
+    """rays generated inside the fused kernels from pose + pixel index give bit-identical
+    images, losses and gradients to get_rays tables + gathers (the reference's plumbing, train.py:94-112)."""
+    cfg, params = golden_params("8x256")
+    g = load_golden("render_8x256")
+    H, W, focal, pose = g["H"], g["W"], g["focal"], g["pose"].to(dev)
+    model = make_model(mods, cfg, params, dev)
+    st, plist = model._ensure_packed(), model._param_list()
+    ro, rd = mods["rays"].get_rays(H, W, focal, pose)
+    with torch.no_grad():
+        a, da, aa = mods["ops"].render_rays_fused(st, plist, ro[1000:3000], rd[1000:3000], 2.0, 6.0, 64, False)
+    b, db, ab = mods["ops"].render_camera_fused(st, pose, H, W, focal, 1000, 2000, 2.0, 6.0, 64)
+    assert torch.equal(a, b) and torch.equal(da, db) and torch.equal(aa, ab)
+    # train step: tables vs camera
+    gen = torch.Generator().manual_seed(5)
+    inds = torch.randint(0, H * W, (512,), generator=gen).to(dev)
+    pix = torch.rand(H * W, 3, generator=gen).to(dev)
+    u = torch.rand(512, 64, generator=gen).to(dev)
+    res = []
+    for mode in ("tables", "camera"):
+        m = make_model(mods, cfg, params, dev)
+        opt = mods["trainer"].FlatAdam(m, lr=5e-4)
+        tr = mods["trainer"].FusedTrainer(m, opt, 2.0, 6.0, 64)
+        if mode == "tables":
+            loss, comp = tr.step(ro[inds], rd[inds], pix[inds], t_rand=u)
+        else:
+            loss, comp = tr.step_camera(pose, H, W, focal, inds, pix, t_rand=u)
+        res.append((loss.clone(), comp.clone(), m.hip_state().grad.clone(), m.hip_state().flat.clone()))
+    for x, y in zip(res[0], res[1]):
+        assert torch.equal(x, y)
+    with pytest.raises(ValueError):
+        mods["ops"].render_camera_fused(st, pose, H, W, focal, H * W - 10, 11, 2.0, 6.0, 64)      # pixel range beyond the image

@@ -4,6 +4,8 @@ set -euo pipefail
 cd "$(dirname "$0")"
 mkdir -p build/stamps
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -DTN_STAMPS"
-hipcc $FLAGS -c mlp_fwd.hip -o build/stamps/mlp_fwd.o
-hipcc --offload-arch=gfx950 -shared -fPIC -o ../tnerf/libtnerf_hip_stamps.so build/stamps/mlp_fwd.o build/host_plan.o -ldl
+hipcc $FLAGS -c mlp_fwd.hip -o build/stamps/mlp_fwd.o &
+hipcc $FLAGS -c wgrad.hip -o build/stamps/wgrad.o &
+wait
+hipcc --offload-arch=gfx950 -shared -fPIC -o ../tnerf/libtnerf_hip_stamps.so build/stage_kernels.o build/stamps/mlp_fwd.o build/mlp_bwd.o build/mlp_pair.o build/stamps/wgrad.o build/train_api.o build/host_plan.o -ldl
 echo built stamps

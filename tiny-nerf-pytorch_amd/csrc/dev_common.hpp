@@ -141,3 +141,45 @@ __device__ __forceinline__ float* tn_stash_at(float* stash, int64_t rows, int64_
 __device__ __forceinline__ const float* tn_stash_at(const float* stash, int64_t rows, int64_t m) {
     return stash + ((m >> 5) * rows) * 32 + (m & 31);
 }
+
+// ------------------------------------------------------------------------------------- ray source
+// Where a fused kernel gets ray r from:
+//   tables : rays_o / rays_d [n,3] (what get_rays precomputed, reference src/train.py:94-101), row = index ? index[r] : r
+//   camera : c2w != NULL -> the ray of flat pixel p = index ? index[r] : first + r is generated in the kernel with
+//            exactly the arithmetic of k_get_rays (reference src/rays.py:15-32): no (N,HW,3) tables, no gathers.
+struct RaySource {
+    const float* rays_o; const float* rays_d; const int64_t* index;
+    const float* c2w; int64_t first; int32_t H, W; float focal;
+};
+
+__device__ __forceinline__ void tn_pixel_ray(const float* __restrict__ c2w, int H, int W, float focal, int64_t p,
+                                             float (&o)[3], float (&d)[3]) {
+    const int col = (int)(p % W), row = (int)(p / W);
+    const float cx = __fdiv_rn(__fsub_rn((float)col, (float)(W * 0.5)), focal);
+    const float cy = __fdiv_rn(-__fsub_rn((float)row, (float)(H * 0.5)), focal);
+    const float cz = -1.0f;
+    float w[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float acc = __fmul_rn(cx, c2w[4 * c + 0]);
+        acc = fmaf(cy, c2w[4 * c + 1], acc);
+        acc = fmaf(cz, c2w[4 * c + 2], acc);
+        w[c] = acc;
+    }
+    float s = __fmul_rn(w[0], w[0]);
+    s = fmaf(w[1], w[1], s);
+    s = fmaf(w[2], w[2], s);
+    const float n = fmaxf(sqrtf(s), 1e-12f);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { d[c] = __fdiv_rn(w[c], n); o[c] = c2w[4 * c + 3]; }
+}
+
+__device__ __forceinline__ void tn_fetch_ray(const RaySource& rs, int64_t r, float (&o)[3], float (&d)[3]) {
+    if (rs.c2w) {
+        tn_pixel_ray(rs.c2w, rs.H, rs.W, rs.focal, rs.index ? rs.index[r] : rs.first + r, o, d);
+    } else {
+        const int64_t i = rs.index ? rs.index[r] : r;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { o[c] = rs.rays_o[3 * i + c]; d[c] = rs.rays_d[3 * i + c]; }
+    }
+}

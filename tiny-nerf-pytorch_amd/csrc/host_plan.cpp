@@ -211,7 +211,7 @@ static int build_classes(const MlpLayout& L, int64_t M, int n_cu, std::vector<Jo
             if (cls[i].chunks >= MB) continue;
             // cycles per 32-sample block: 64 per MFMA step (16 steps per tile) + a fixed cost for staging the block
             // through LDS and the barrier (measured ~3k cycles; it dominates the small enc / head classes)
-            const double t = ((double)cls[i].cost * 2048.0 + 2500.0) * (double)((MB + cls[i].chunks - 1) / cls[i].chunks);   // two waves share each SIMD
+            const double t = ((double)cls[i].cost * 2210.0 + 1980.0) * (double)((MB + cls[i].chunks - 1) / cls[i].chunks);   // measured (tools/wgrad_probe.py): 19.7k / 6.4k / 4.3k cycles per block for 8 / 2 / 1 tiles per wave
             if (t > best_t) { best_t = t; best = (int)i; }
         }
         if (best < 0) break;

@@ -106,7 +106,9 @@ __global__ __launch_bounds__(256, 1) void k_train_bwd(BwdArgs a) {
     if (ray >= a.R) return;
     const int S = a.sa.S;
     const int nseg = (S + 63) / 64;
-    const float dn = tn_norm3(a.rays_d[3 * ray], a.rays_d[3 * ray + 1], a.rays_d[3 * ray + 2]);
+    float ro_[3], rd_[3];
+    tn_fetch_ray(a.rs, ray, ro_, rd_);
+    const float dn = tn_norm3(rd_[0], rd_[1], rd_[2]);
     const float gr = a.g_comp[3 * ray], gg = a.g_comp[3 * ray + 1], gb = a.g_comp[3 * ray + 2];
     const float gbg = a.white ? (gr + gg + gb) : 0.0f;
     const int64_t mray = ray * S; const int orow = a.L.out_row0 * 32; const int64_t SR = a.L.stash_rows;

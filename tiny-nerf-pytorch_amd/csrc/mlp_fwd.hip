@@ -148,8 +148,9 @@ __global__ __launch_bounds__(256, 1) void k_render_fused(FwdArgs a) {
     const int j = lane & 31, h = lane >> 5;
     const int S = a.sa.S;
     const int Lf = (a.L.in_dim - 3) / 6;
-    const float ox = a.rays_o[3 * ray], oy = a.rays_o[3 * ray + 1], oz = a.rays_o[3 * ray + 2];
-    const float dx = a.rays_d[3 * ray], dy = a.rays_d[3 * ray + 1], dz = a.rays_d[3 * ray + 2];
+    float ro_[3], rd_[3];
+    tn_fetch_ray(a.rs, ray, ro_, rd_);
+    const float ox = ro_[0], oy = ro_[1], oz = ro_[2], dx = rd_[0], dy = rd_[1], dz = rd_[2];
     const float dn = tn_norm3(dx, dy, dz);
     TN_STAMP(0);
     float T_in = 1.0f, cr = 0.f, cg = 0.f, cb = 0.f, cd = 0.f, ca = 0.f;
@@ -247,37 +248,68 @@ extern "C" int tnerf_mlp_fwd(const tnerf_mlp_desc* d, const float* packed, const
                  : launch_fwd<false, false>(a, tiles, (hipStream_t)stream, "tnerf_mlp_fwd");
 }
 
-int tn_fused_args(const char* who, FwdArgs& a, const tnerf_mlp_desc* d, const float* packed, const float* rays_o,
-                      const float* rays_d, int64_t R, int32_t S, const float* ztab, int32_t randomized, const float* t_rand,
-                      uint64_t seed, uint64_t offset, int32_t white) {
+int tn_camera_source(const char* who, const tnerf_camera* cam, int64_t R, RaySource* rs) {
+    if (!cam || (R > 0 && !cam->c2w) || cam->H < 1 || cam->W < 1 || !(cam->focal != 0.0f) ||
+        (!cam->pix_index && (cam->pix_first < 0 || cam->pix_first + R > (int64_t)cam->H * cam->W))) {
+        tn_set_error("%s: bad tnerf_camera (c2w=%p H=%d W=%d focal=%g pix_index=%p pix_first=%lld, %lld rays)", who,
+                     cam ? (const void*)cam->c2w : nullptr, cam ? cam->H : 0, cam ? cam->W : 0, cam ? cam->focal : 0.f,
+                     cam ? (const void*)cam->pix_index : nullptr, cam ? (long long)cam->pix_first : 0LL, (long long)R);
+        return TNERF_EINVAL;
+    }
+    *rs = RaySource{nullptr, nullptr, cam->pix_index, cam->c2w, cam->pix_first, cam->H, cam->W, cam->focal};
+    return TNERF_OK;
+}
+
+int tn_fused_args(const char* who, FwdArgs& a, const tnerf_mlp_desc* d, const float* packed, const RaySource& rs,
+                  int64_t R, int32_t S, const float* ztab, int32_t randomized, const float* t_rand,
+                  uint64_t seed, uint64_t offset, int32_t white) {
     int rc = tn_build_layout(d, &a.L); if (rc) return rc;
     if (a.L.in_dim < 9 || (a.L.in_dim - 3) % 6 != 0) {
         tn_set_error("%s: the fused path needs in_dim = 6L+3 (PositionalEncoding with include_input); got %d", who, a.L.in_dim);
         return TNERF_EUNSUPPORTED;
     }
-    if (R < 0 || S < 1 || S > 4096 || (R > 0 && (!packed || !rays_o || !rays_d || !ztab))) {
-        tn_set_error("%s: R=%lld S=%d (1..4096) packed=%p rays_o=%p rays_d=%p ztab=%p", who, (long long)R, S, (const void*)packed,
-                     (const void*)rays_o, (const void*)rays_d, (const void*)ztab);
+    if (R < 0 || S < 1 || S > 4096 || (R > 0 && (!packed || !ztab || (!rs.c2w && (!rs.rays_o || !rs.rays_d))))) {
+        tn_set_error("%s: R=%lld S=%d (1..4096) packed=%p rays_o=%p rays_d=%p c2w=%p ztab=%p", who, (long long)R, S, (const void*)packed,
+                     (const void*)rs.rays_o, (const void*)rs.rays_d, (const void*)rs.c2w, (const void*)ztab);
         return TNERF_EINVAL;
     }
-    a.packed = packed; a.rays_o = rays_o; a.rays_d = rays_d; a.R = R;
+    a.packed = packed; a.rs = rs; a.R = R;
     a.sa = SampleArgs{ztab, t_rand, seed, offset, S, randomized ? 1 : 0};
     a.white = white;
     return TNERF_OK;
 }
 
+static int render_impl(const char* who, const tnerf_mlp_desc* d, const float* packed, const RaySource& rs, int64_t R, int32_t S,
+                       const float* ztab, int32_t randomized, const float* t_rand, uint64_t seed, uint64_t offset, int32_t white,
+                       float* comp, float* depth, float* acc, tnerf_stream_t stream);
+
 extern "C" int tnerf_render_fused(const tnerf_mlp_desc* d, const float* packed, const float* rays_o, const float* rays_d,
                                   int64_t R, int32_t S, const float* ztab, int32_t randomized, const float* t_rand,
                                   uint64_t seed, uint64_t offset, int32_t white, float* comp, float* depth, float* acc,
                                   tnerf_stream_t stream) {
+    return render_impl("tnerf_render_fused", d, packed, tn_table_source(rays_o, rays_d), R, S, ztab, randomized, t_rand, seed, offset,
+                       white, comp, depth, acc, stream);
+}
+
+extern "C" int tnerf_render_fused_cam(const tnerf_mlp_desc* d, const float* packed, const tnerf_camera* cam, int64_t R, int32_t S,
+                                      const float* ztab, int32_t randomized, const float* t_rand, uint64_t seed, uint64_t offset,
+                                      int32_t white, float* comp, float* depth, float* acc, tnerf_stream_t stream) {
+    RaySource rs;
+    int rc = tn_camera_source("tnerf_render_fused_cam", cam, R, &rs); if (rc) return rc;
+    return render_impl("tnerf_render_fused_cam", d, packed, rs, R, S, ztab, randomized, t_rand, seed, offset, white, comp, depth, acc, stream);
+}
+
+static int render_impl(const char* who, const tnerf_mlp_desc* d, const float* packed, const RaySource& rs, int64_t R, int32_t S,
+                       const float* ztab, int32_t randomized, const float* t_rand, uint64_t seed, uint64_t offset, int32_t white,
+                       float* comp, float* depth, float* acc, tnerf_stream_t stream) {
     FwdArgs a{};
-    int rc = tn_fused_args("tnerf_render_fused", a, d, packed, rays_o, rays_d, R, S, ztab, randomized, t_rand, seed, offset, white);
+    int rc = tn_fused_args(who, a, d, packed, rs, R, S, ztab, randomized, t_rand, seed, offset, white);
     if (rc) return rc;
     if (R == 0) return TNERF_OK;
     if (!comp) { tn_set_error("tnerf_render_fused: comp_rgb is NULL"); return TNERF_EINVAL; }
     a.comp = comp; a.depth = depth; a.acc = acc;
-    if (tn_use_pair()) return tn_launch_fwd_pair(a, false, (hipStream_t)stream, "tnerf_render_fused");
-    return launch_fwd<true, false>(a, R, (hipStream_t)stream, "tnerf_render_fused");
+    if (tn_use_pair()) return tn_launch_fwd_pair(a, false, (hipStream_t)stream, who);
+    return launch_fwd<true, false>(a, R, (hipStream_t)stream, who);
 }
 
 extern "C" int tnerf_train_fwd_fused(const tnerf_mlp_desc* d, const float* packed, const float* rays_o, const float* rays_d,
@@ -285,7 +317,7 @@ extern "C" int tnerf_train_fwd_fused(const tnerf_mlp_desc* d, const float* packe
                                      uint64_t seed, uint64_t offset, int32_t white, float* comp, float* stash, int64_t Mp,
                                      tnerf_stream_t stream) {
     FwdArgs a{};
-    int rc = tn_fused_args("tnerf_train_fwd_fused", a, d, packed, rays_o, rays_d, R, S, ztab, randomized, t_rand, seed, offset, white);
+    int rc = tn_fused_args("tnerf_train_fwd_fused", a, d, packed, tn_table_source(rays_o, rays_d), R, S, ztab, randomized, t_rand, seed, offset, white);
     if (rc) return rc;
     if (R == 0) return TNERF_OK;
     if (!comp || !stash || Mp < R * S) {
@@ -304,7 +336,7 @@ extern "C" int tnerf_debug_render_stamps(const tnerf_mlp_desc* d, const float* p
                                          int64_t R, int32_t S, const float* ztab, float* comp, float* stash, int64_t Mp,
                                          unsigned long long* stamps, tnerf_stream_t stream) {
     FwdArgs a{};
-    int rc = tn_fused_args("tnerf_debug_render_stamps", a, d, packed, rays_o, rays_d, R, S, ztab, 0, nullptr, 0, 0, 1);
+    int rc = tn_fused_args("tnerf_debug_render_stamps", a, d, packed, tn_table_source(rays_o, rays_d), R, S, ztab, 0, nullptr, 0, 0, 1);
     if (rc) return rc;
     a.comp = comp; a.stamps = stamps; a.stash = stash; a.Mp = Mp;
     return stash ? launch_fwd<true, true>(a, R, (hipStream_t)stream, "stamps") : launch_fwd<true, false>(a, R, (hipStream_t)stream, "stamps");

@@ -201,8 +201,9 @@ __global__ __launch_bounds__(256, 2) void k_render_fused_pair(FwdArgs a) {
     const int j = lane & 31, h = lane >> 5;
     const int S = a.sa.S;
     const int Lf = (a.L.in_dim - 3) / 6;
-    const float ox = a.rays_o[3 * ray], oy = a.rays_o[3 * ray + 1], oz = a.rays_o[3 * ray + 2];
-    const float dx = a.rays_d[3 * ray], dy = a.rays_d[3 * ray + 1], dz = a.rays_d[3 * ray + 2];
+    float ro_[3], rd_[3];
+    tn_fetch_ray(a.rs, ray, ro_, rd_);
+    const float ox = ro_[0], oy = ro_[1], oz = ro_[2], dx = rd_[0], dy = rd_[1], dz = rd_[2];
     const float dn = tn_norm3(dx, dy, dz);
     // State that survives a tile lives outside the VGPRs (the MLP needs all 256): running sums and transmittance are
     // wave-uniform scalars (SGPRs), the lower half's head outputs wait in LDS for the upper half.
@@ -399,7 +400,9 @@ __global__ __launch_bounds__(256, 2) void k_train_bwd_pair(BwdArgs a) {
     const int64_t ray = live ? ray0 : a.R - 1;
     const int S = a.sa.S;
     const int nseg = (S + 63) / 64;
-    const float dn = tn_norm3(a.rays_d[3 * ray], a.rays_d[3 * ray + 1], a.rays_d[3 * ray + 2]);
+    float ro_[3], rd_[3];
+    tn_fetch_ray(a.rs, ray, ro_, rd_);
+    const float dn = tn_norm3(rd_[0], rd_[1], rd_[2]);
     const float gr = a.g_comp[3 * ray], gg = a.g_comp[3 * ray + 1], gb = a.g_comp[3 * ray + 2];
     const float gbg = a.white ? (gr + gg + gb) : 0.0f;
     const int64_t mray = ray * S; const int orow = a.L.out_row0 * 32; const int64_t SR = a.L.stash_rows;

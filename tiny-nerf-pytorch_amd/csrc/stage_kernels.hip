@@ -12,26 +12,12 @@ __global__ __launch_bounds__(256) void k_get_rays(int H, int W, float focal, con
                                                   float* __restrict__ rays_o, float* __restrict__ rays_d) {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= (int64_t)H * W) return;
-    const int col = (int)(p % W), row = (int)(p / W);
-    const float cx = __fdiv_rn(__fsub_rn((float)col, (float)(W * 0.5)), focal);
-    const float cy = __fdiv_rn(-__fsub_rn((float)row, (float)(H * 0.5)), focal);
-    const float cz = -1.0f;
-    float w[3];
+    float o[3], d[3];
+    tn_pixel_ray(c2w, H, W, focal, p, o, d);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        float acc = __fmul_rn(cx, c2w[4 * c + 0]);
-        acc = fmaf(cy, c2w[4 * c + 1], acc);
-        acc = fmaf(cz, c2w[4 * c + 2], acc);
-        w[c] = acc;
-    }
-    float s = __fmul_rn(w[0], w[0]);
-    s = fmaf(w[1], w[1], s);
-    s = fmaf(w[2], w[2], s);
-    const float n = fmaxf(sqrtf(s), 1e-12f);
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        rays_d[3 * p + c] = __fdiv_rn(w[c], n);
-        if (rays_o) rays_o[3 * p + c] = c2w[4 * c + 3];
+        rays_d[3 * p + c] = d[c];
+        if (rays_o) rays_o[3 * p + c] = o[c];
     }
 }
 

@@ -35,16 +35,16 @@ extern "C" int tnerf_mlp_bwd(const tnerf_mlp_desc* d, const float* packed, int64
     return tn_launch_reduce(slabs, reduce_table, a.L.n_params, grads, s);
 }
 
-static int train_bwd_impl(const char* who, const tnerf_mlp_desc* d, const float* packed, const float* rays_o, const float* rays_d,
+static int train_bwd_impl(const char* who, const tnerf_mlp_desc* d, const float* packed, const RaySource& rs,
                           int64_t R, int32_t S, const float* ztab, int32_t randomized, const float* t_rand, uint64_t seed,
                           uint64_t offset, int32_t white, const float* g_comp, float* stash, int64_t Mp, const int32_t* job_table,
                           int64_t n_jobs, float* slabs, const int32_t* reduce_table, float* grads, hipStream_t s) {
     FwdArgs f{};
-    int rc = tn_fused_args(who, f, d, packed, rays_o, rays_d, R, S, ztab, randomized, t_rand, seed, offset, white); if (rc) return rc;
+    int rc = tn_fused_args(who, f, d, packed, rs, R, S, ztab, randomized, t_rand, seed, offset, white); if (rc) return rc;
     if (R < 1 || !g_comp) { tn_set_error("%s: R=%lld g_comp=%p", who, (long long)R, (const void*)g_comp); return TNERF_EINVAL; }
     rc = bwd_common_check(who, packed, stash, Mp, R * S, job_table, n_jobs, slabs, reduce_table, grads); if (rc) return rc;
     BwdArgs a{};
-    a.L = f.L; a.packed = packed; a.stash = stash; a.Mp = Mp; a.rays_o = rays_o; a.rays_d = rays_d; a.R = R; a.sa = f.sa;
+    a.L = f.L; a.packed = packed; a.stash = stash; a.Mp = Mp; a.rs = f.rs; a.R = R; a.sa = f.sa;
     a.white = white; a.g_comp = g_comp;
     if ((rc = tn_use_pair() ? tn_launch_train_bwd_pair(a, s) : tn_launch_train_bwd(a, s))) return rc;
     if ((rc = tn_launch_wgrad(stash, a.L.stash_rows, R * S, job_table, n_jobs, slabs, s))) return rc;
@@ -56,7 +56,7 @@ extern "C" int tnerf_train_bwd_fused(const tnerf_mlp_desc* d, const float* packe
                                      uint64_t seed, uint64_t offset, int32_t white, const float* g_comp, float* stash, int64_t Mp,
                                      const int32_t* job_table, int64_t n_jobs, float* slabs, const int32_t* reduce_table,
                                      float* grads, tnerf_stream_t stream) {
-    return train_bwd_impl("tnerf_train_bwd_fused", d, packed, rays_o, rays_d, R, S, ztab, randomized, t_rand, seed, offset, white,
+    return train_bwd_impl("tnerf_train_bwd_fused", d, packed, tn_table_source(rays_o, rays_d), R, S, ztab, randomized, t_rand, seed, offset, white,
                           g_comp, stash, Mp, job_table, n_jobs, slabs, reduce_table, grads, (hipStream_t)stream);
 }
 
@@ -65,11 +65,11 @@ extern "C" int tnerf_train_dgrad_fused(const tnerf_mlp_desc* d, const float* pac
                                        uint64_t seed, uint64_t offset, int32_t white, const float* g_comp, float* stash, int64_t Mp,
                                        tnerf_stream_t stream) {
     FwdArgs f{};
-    int rc = tn_fused_args("tnerf_train_dgrad_fused", f, d, packed, rays_o, rays_d, R, S, ztab, randomized, t_rand, seed, offset, white);
+    int rc = tn_fused_args("tnerf_train_dgrad_fused", f, d, packed, tn_table_source(rays_o, rays_d), R, S, ztab, randomized, t_rand, seed, offset, white);
     if (rc) return rc;
     if (R < 1 || !g_comp || !stash || Mp < R * S) { tn_set_error("tnerf_train_dgrad_fused: R=%lld g_comp=%p stash=%p Mp=%lld", (long long)R, (const void*)g_comp, (void*)stash, (long long)Mp); return TNERF_EINVAL; }
     BwdArgs a{};
-    a.L = f.L; a.packed = packed; a.stash = stash; a.Mp = Mp; a.rays_o = rays_o; a.rays_d = rays_d; a.R = R; a.sa = f.sa;
+    a.L = f.L; a.packed = packed; a.stash = stash; a.Mp = Mp; a.rs = f.rs; a.R = R; a.sa = f.sa;
     a.white = white; a.g_comp = g_comp;
     return tn_use_pair() ? tn_launch_train_bwd_pair(a, (hipStream_t)stream) : tn_launch_train_bwd(a, (hipStream_t)stream);
 }
@@ -86,22 +86,59 @@ extern "C" int tnerf_wgrad_reduce(const float* slabs, const int32_t* reduce_tabl
     return tn_launch_reduce(slabs, reduce_table, n_params, grads, (hipStream_t)stream);
 }
 
+int tn_train_fwd_impl(const char* who, const tnerf_mlp_desc* d, const float* packed, const RaySource& rs, int64_t R, int32_t S,
+                      const float* ztab, int32_t randomized, const float* t_rand, uint64_t seed, uint64_t offset, int32_t white,
+                      float* comp, float* stash, int64_t Mp, hipStream_t stream) {
+    FwdArgs a{};
+    int rc = tn_fused_args(who, a, d, packed, rs, R, S, ztab, randomized, t_rand, seed, offset, white);
+    if (rc) return rc;
+    if (!comp || !stash || Mp < R * S) { tn_set_error("%s: comp=%p stash=%p Mp=%lld < R*S=%lld", who, (void*)comp, (void*)stash, (long long)Mp, (long long)(R * S)); return TNERF_EINVAL; }
+    a.comp = comp; a.stash = stash; a.Mp = Mp;
+    if (tn_use_pair()) return tn_launch_fwd_pair(a, true, stream, who);
+    return tn_launch_fwd(a, true, true, R, stream, who);
+}
+
+static int train_step_impl(const char* who, const tnerf_mlp_desc* d, const float* packed, const RaySource& rs, const float* target,
+                           const int64_t* target_index, int64_t R, int32_t S, const float* ztab, int32_t randomized,
+                           const float* t_rand, uint64_t seed, uint64_t offset, int32_t white, double loss_denominator,
+                           float* comp_rgb, float* g_comp_ws, float* loss_out, float* stash, int64_t Mp,
+                           const int32_t* job_table, int64_t n_jobs, float* slabs, const int32_t* reduce_table,
+                           float* grads, hipStream_t stream) {
+    if (!target || !comp_rgb || !g_comp_ws || !loss_out || !(loss_denominator > 0.0) || R < 1) {
+        tn_set_error("%s: target=%p comp=%p g_ws=%p loss=%p denom=%g R=%lld", who, (const void*)target, (void*)comp_rgb,
+                     (void*)g_comp_ws, (void*)loss_out, loss_denominator, (long long)R);
+        return TNERF_EINVAL;
+    }
+    int rc = tn_train_fwd_impl(who, d, packed, rs, R, S, ztab, randomized, t_rand, seed, offset, white, comp_rgb, stash, Mp, stream);
+    if (rc) return rc;
+    if ((rc = tn_launch_loss_grad(comp_rgb, target, target_index, R, loss_denominator, g_comp_ws, loss_out, stream))) return rc;
+    return train_bwd_impl(who, d, packed, rs, R, S, ztab, randomized, t_rand, seed, offset, white,
+                          g_comp_ws, stash, Mp, job_table, n_jobs, slabs, reduce_table, grads, stream);
+}
+
 extern "C" int tnerf_train_step_fused(const tnerf_mlp_desc* d, const float* packed, const float* rays_o, const float* rays_d,
                                       const float* target, int64_t R, int32_t S, const float* ztab, int32_t randomized,
                                       const float* t_rand, uint64_t seed, uint64_t offset, int32_t white, double loss_denominator,
                                       float* comp_rgb, float* g_comp_ws, float* loss_out, float* stash, int64_t Mp,
                                       const int32_t* job_table, int64_t n_jobs, float* slabs, const int32_t* reduce_table,
                                       float* grads, tnerf_stream_t stream) {
-    if (!target || !comp_rgb || !g_comp_ws || !loss_out || !(loss_denominator > 0.0) || R < 1) {
-        tn_set_error("tnerf_train_step_fused: target=%p comp=%p g_ws=%p loss=%p denom=%g R=%lld", (const void*)target, (void*)comp_rgb,
-                     (void*)g_comp_ws, (void*)loss_out, loss_denominator, (long long)R);
-        return TNERF_EINVAL;
-    }
-    int rc = tnerf_train_fwd_fused(d, packed, rays_o, rays_d, R, S, ztab, randomized, t_rand, seed, offset, white, comp_rgb, stash, Mp, stream);
-    if (rc) return rc;
-    if ((rc = tn_launch_loss_grad(comp_rgb, target, R, loss_denominator, g_comp_ws, loss_out, (hipStream_t)stream))) return rc;
-    return train_bwd_impl("tnerf_train_step_fused", d, packed, rays_o, rays_d, R, S, ztab, randomized, t_rand, seed, offset, white,
-                          g_comp_ws, stash, Mp, job_table, n_jobs, slabs, reduce_table, grads, (hipStream_t)stream);
+    return train_step_impl("tnerf_train_step_fused", d, packed, tn_table_source(rays_o, rays_d), target, nullptr, R, S, ztab, randomized,
+                           t_rand, seed, offset, white, loss_denominator, comp_rgb, g_comp_ws, loss_out, stash, Mp, job_table, n_jobs,
+                           slabs, reduce_table, grads, (hipStream_t)stream);
+}
+
+extern "C" int tnerf_train_step_fused_cam(const tnerf_mlp_desc* d, const float* packed, const tnerf_camera* cam, const float* pixels,
+                                          int64_t R, int32_t S, const float* ztab, int32_t randomized, const float* t_rand,
+                                          uint64_t seed, uint64_t offset, int32_t white, double loss_denominator, float* comp_rgb,
+                                          float* g_comp_ws, float* loss_out, float* stash, int64_t Mp, const int32_t* job_table,
+                                          int64_t n_jobs, float* slabs, const int32_t* reduce_table, float* grads,
+                                          tnerf_stream_t stream) {
+    RaySource rs;
+    int rc = tn_camera_source("tnerf_train_step_fused_cam", cam, R, &rs); if (rc) return rc;
+    if (!cam->pix_index) { tn_set_error("tnerf_train_step_fused_cam: pix_index is required (it also selects the target pixels)"); return TNERF_EINVAL; }
+    return train_step_impl("tnerf_train_step_fused_cam", d, packed, rs, pixels, cam->pix_index, R, S, ztab, randomized, t_rand, seed,
+                           offset, white, loss_denominator, comp_rgb, g_comp_ws, loss_out, stash, Mp, job_table, n_jobs, slabs,
+                           reduce_table, grads, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------ RCCL

@@ -149,6 +149,9 @@ __device__ __forceinline__ void wgrad_body(const float* __restrict__ stash, int6
 __global__ __launch_bounds__(512, 2) void k_wgrad(const float* __restrict__ stash, int64_t stash_rows, int64_t M,
                                                   const int32_t* __restrict__ jobs, float* __restrict__ slabs) {
     __shared__ __attribute__((aligned(16))) float lds[WG_LDS_FLOATS];
+#ifdef TN_STAMPS   // diagnostic build: per-workgroup duration, written over the (unused) tail of the job record
+    const unsigned long long t_start = __builtin_amdgcn_s_memtime();
+#endif
     const int32_t* job = jobs + (int64_t)blockIdx.x * TN_JOB_INTS;
     const int n_at = job[JOB_N_AT], n_bt = job[JOB_N_BT], WA = job[JOB_WA], WB = 8 / WA;
     const int ta = (n_at + WA - 1) / WA, tb = (n_bt + WB - 1) / WB;     // the host plan only emits full-or-idle waves
@@ -159,6 +162,13 @@ __global__ __launch_bounds__(512, 2) void k_wgrad(const float* __restrict__ stas
         case 1 * 8 + 1: wgrad_body<1, 1>(stash, stash_rows, M, job, slabs, lds); break;
         default: break;   // unreachable: shapes are validated on the host (tnerf_plan_fill)
     }
+#ifdef TN_STAMPS
+    if (threadIdx.x == 0) {
+        const unsigned long long dt = __builtin_amdgcn_s_memtime() - t_start;
+        int32_t* rec = const_cast<int32_t*>(jobs) + (int64_t)blockIdx.x * TN_JOB_INTS;
+        rec[14] = (int32_t)(dt & 0xffffffffu); rec[15] = (int32_t)(dt >> 32);
+    }
+#endif
 }
 
 int tn_launch_wgrad(const float* stash, int64_t stash_rows, int64_t M, const int32_t* jobs, int64_t n_jobs, float* slabs, hipStream_t stream) {
@@ -214,12 +224,12 @@ extern "C" int tnerf_mlp_pack(const float* params, const int32_t* pack_table, in
 // ------------------------------------------------------------------------------- loss
 // loss = sum((comp - target)^2) / denom ; g = 2 (comp - target) / denom      [reference src/train.py:122]
 // One workgroup, fixed summation order (deterministic).
-__global__ __launch_bounds__(1024) void k_loss_grad(const float* __restrict__ comp, const float* __restrict__ target, int64_t n,
+__global__ __launch_bounds__(1024) void k_loss_grad(const float* __restrict__ comp, const float* __restrict__ target, const int64_t* __restrict__ tindex, int64_t n,
                                                     float inv_denom, float* __restrict__ g, float* __restrict__ loss_out) {
     __shared__ float part[16];
     float s = 0.0f;
     for (int64_t i = threadIdx.x; i < n; i += 1024) {
-        const float d = comp[i] - target[i];
+        const float d = comp[i] - (tindex ? target[3 * tindex[i / 3] + i % 3] : target[i]);
         s += d * d;
         g[i] = (2.0f * d) * inv_denom;
     }
@@ -233,8 +243,8 @@ __global__ __launch_bounds__(1024) void k_loss_grad(const float* __restrict__ co
     }
 }
 
-int tn_launch_loss_grad(const float* comp, const float* target, int64_t R, double denom, float* g_comp, float* loss_out, hipStream_t stream) {
-    hipLaunchKernelGGL(k_loss_grad, dim3(1), dim3(1024), 0, stream, comp, target, R * 3, (float)(1.0 / denom), g_comp, loss_out);
+int tn_launch_loss_grad(const float* comp, const float* target, const int64_t* target_index, int64_t R, double denom, float* g_comp, float* loss_out, hipStream_t stream) {
+    hipLaunchKernelGGL(k_loss_grad, dim3(1), dim3(1024), 0, stream, comp, target, target_index, R * 3, (float)(1.0 / denom), g_comp, loss_out);
     TN_HIP_CHECK_LAUNCH("train_step/loss");
     return TNERF_OK;
 }

@@ -77,21 +77,22 @@ def render_one(model: nn.Module, encoder: nn.Module, H: int, W: int, focal: floa
                device: torch.device, n_samples: int = 64, near: float = 2.0, far: float = 6.0,
                chunk: int = 8192) -> torch.Tensor:
     """Full image for one pose, chunked over rays, clamped to [0,1].   [reference src/train.py:36-59]
-    Each chunk is ONE fused kernel (rays in, colours out) when model/encoder are this package's."""
+    Each chunk is ONE fused kernel (pose in, colours out) when model/encoder are this package's."""
     model.eval()
-    rays_o, rays_d = get_rays(H, W, focal, pose.to(device), device=device)
     parts = []
     fused = _fusable(model, encoder)
-    if fused:
-        st, params = model._ensure_packed(), model._param_list()
+    if fused:      # rays are generated inside the fused kernel: no get_rays launch, no (HW,3) tables
+        st, pose_d = model._ensure_packed(), pose.to(device)
+        for i in range(0, H * W, chunk):
+            comp, _, _ = ops.render_camera_fused(st, pose_d, H, W, focal, i, min(chunk, H * W - i), near, far, n_samples)
+            parts.append(comp)
+        return torch.cat(parts, dim=0).reshape(H, W, 3).clamp(0.0, 1.0)
+    rays_o, rays_d = get_rays(H, W, focal, pose.to(device), device=device)
     for i in range(0, rays_o.shape[0], chunk):
         ro, rd = rays_o[i:i + chunk], rays_d[i:i + chunk]
-        if fused:
-            comp, _, _ = ops.render_rays_fused(st, params, ro, rd, near, far, n_samples, randomized=False)
-        else:
-            z_vals, pts = stratified_samples(near, far, n_samples, ro, rd, randomized=False)
-            rgb, sigma = model(encoder(pts.reshape(-1, 3)))
-            comp, _, _, _ = volume_render(rgb.reshape(pts.shape[0], n_samples, 3), sigma.reshape(pts.shape[0], n_samples, 1), z_vals, rd)
+        z_vals, pts = stratified_samples(near, far, n_samples, ro, rd, randomized=False)
+        rgb, sigma = model(encoder(pts.reshape(-1, 3)))
+        comp, _, _, _ = volume_render(rgb.reshape(pts.shape[0], n_samples, 3), sigma.reshape(pts.shape[0], n_samples, 1), z_vals, rd)
         parts.append(comp)
     return torch.cat(parts, dim=0).reshape(H, W, 3).clamp(0.0, 1.0)
 
@@ -134,9 +135,10 @@ def main(cfg: Config):
         start_step = int(ckpt.get("step", 0))
         print(f"[resume] loaded {cfg.ckpt_path} from step {start_step}")
 
-    rays = [get_rays(H, W, focal, poses[i], device=device) for i in range(N)]   # train.py:94-101
-    all_rays_o = torch.stack([r[0] for r in rays], dim=0)
-    all_rays_d = torch.stack([r[1] for r in rays], dim=0)
+    if not cfg.fused:                                                           # train.py:94-101 (the fused step makes its rays in-kernel)
+        rays = [get_rays(H, W, focal, poses[i], device=device) for i in range(N)]
+        all_rays_o = torch.stack([r[0] for r in rays], dim=0)
+        all_rays_d = torch.stack([r[1] for r in rays], dim=0)
     pixels = images.view(N, H * W, 3)
 
     try:
@@ -149,12 +151,12 @@ def main(cfg: Config):
         model.train()
         img_i = step % N
         inds = torch.randint(0, H * W, (cfg.n_rand,), device=device)             # train.py:109
-        ro, rd, target = all_rays_o[img_i, inds], all_rays_d[img_i, inds], pixels[img_i, inds]
         if cfg.fused:
             t_rand = torch.rand(cfg.n_rand, cfg.n_samples, device=device)        # the draw of sampling.py:24
-            loss, _ = step_fn.step(ro, rd, target, t_rand=t_rand)
+            loss, _ = step_fn.step_camera(poses[img_i], H, W, focal, inds, pixels[img_i], t_rand=t_rand)
             psnr = mse2psnr(loss)
         else:
+            ro, rd, target = all_rays_o[img_i, inds], all_rays_d[img_i, inds], pixels[img_i, inds]
             z_vals, pts = stratified_samples(cfg.near, cfg.far, cfg.n_samples, ro, rd, randomized=True)
             rgb, sigma = model(encoder(pts.reshape(-1, 3)))
             comp_rgb, _, _, _ = volume_render(rgb.reshape(cfg.n_rand, cfg.n_samples, 3),

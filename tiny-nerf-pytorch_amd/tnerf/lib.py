@@ -15,6 +15,11 @@ class MlpDesc(C.Structure):
     _fields_ = [("in_dim", C.c_int32), ("hidden", C.c_int32), ("depth", C.c_int32), ("skip_at", C.c_int32)]
 
 
+class Camera(C.Structure):
+    _fields_ = [("c2w", C.c_void_p), ("H", C.c_int32), ("W", C.c_int32), ("focal", C.c_float),
+                ("pix_index", C.c_void_p), ("pix_first", C.c_int64)]
+
+
 class PlanSizes(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("n_params", "packed_floats", "stash_floats", "slab_floats", "job_ints",
                                          "reduce_ints", "n_jobs", "stash_row_stride")]
@@ -51,6 +56,9 @@ SIGNATURES = {
     "tnerf_wgrad_reduce": (C.c_int, [_P, _P, _I64, _P, _P]),
     "tnerf_train_step_fused": (C.c_int, [_DESC, _P, _P, _P, _P, _I64, _I32, _P, _I32, _P, _U64, _U64, _I32, _D,
                                          _P, _P, _P, _P, _I64, _P, _I64, _P, _P, _P, _P]),
+    "tnerf_render_fused_cam": (C.c_int, [_DESC, _P, C.POINTER(Camera), _I64, _I32, _P, _I32, _P, _U64, _U64, _I32, _P, _P, _P, _P]),
+    "tnerf_train_step_fused_cam": (C.c_int, [_DESC, _P, C.POINTER(Camera), _P, _I64, _I32, _P, _I32, _P, _U64, _U64, _I32, _D,
+                                             _P, _P, _P, _P, _I64, _P, _I64, _P, _P, _P, _P]),
     "tnerf_adam_step": (C.c_int, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _I64, _F, _P]),
     "tnerf_comm_unique_id": (C.c_int, [_P]),
     "tnerf_comm_init_rank": (C.c_int, [_P, _I32, _I32, C.POINTER(C.c_void_p)]),

@@ -337,3 +337,35 @@ def render_rays_fused(st: ModelState, params, rays_o, rays_d, near, far, n_sampl
             raise ValueError(f"t_rand must be ({rays_o.shape[0]},{S})")
     train = torch.is_grad_enabled() and any(p.requires_grad for p in params)
     return _FusedRaysFn.apply(st, rays_o, rays_d, ztab, S, rnd, tr, seed, off, int(bool(white_bkgd)), train, *params)
+
+
+def camera_struct(c2w: torch.Tensor, H: int, W: int, focal: float, pix_index: Optional[torch.Tensor] = None, pix_first: int = 0):
+    """tnerf_camera for the *_cam entry points (keeps the tensors alive through the returned tuple)."""
+    _need_cuda(c2w, pix_index)
+    c2w = _f32c(c2w)
+    if c2w.shape != (4, 4):
+        raise ValueError(f"c2w must be (4,4), got {tuple(c2w.shape)}")
+    if pix_index is not None:
+        if pix_index.dtype != torch.int64:
+            pix_index = pix_index.long()
+        pix_index = pix_index.contiguous()
+    cam = _l.Camera(c2w.data_ptr(), int(H), int(W), float(focal), _ptr(pix_index), int(pix_first))
+    return cam, (c2w, pix_index)
+
+
+@torch.no_grad()
+def render_camera_fused(st: ModelState, c2w, H, W, focal, pix_first, n_rays, near, far, n_samples, white_bkgd=True,
+                        randomized=False, t_rand=None, philox=None):
+    """Inference render of pixels pix_first .. pix_first+n_rays-1 of one pose: rays are generated in the kernel
+    (no get_rays launch, no ray tables).  Returns (comp_rgb, depth, acc)."""
+    dev = st.device
+    S = int(n_samples)
+    ztab = depth_table(near, far, S, dev)
+    rnd, tr, seed, off = _rng_args(randomized, t_rand, philox)
+    cam, keep = camera_struct(c2w, H, W, focal, None, pix_first)
+    comp = torch.empty(n_rays, 3, dtype=torch.float32, device=dev)
+    depth = torch.empty(n_rays, 1, dtype=torch.float32, device=dev)
+    acc = torch.empty(n_rays, 1, dtype=torch.float32, device=dev)
+    _l.call("tnerf_render_fused_cam", C.byref(st.desc), st.packed.data_ptr(), C.byref(cam), int(n_rays), S, ztab.data_ptr(), rnd,
+            _ptr(tr), seed, off, int(bool(white_bkgd)), comp.data_ptr(), depth.data_ptr(), acc.data_ptr(), _stream(dev))
+    return comp, depth, acc

@@ -114,3 +114,31 @@ class FusedTrainer:
         _dist.all_reduce_sum_(st.grad)
         self.opt.step(grads_in_flat=True)
         return self.loss, self._comp
+
+    @torch.no_grad()
+    def step_camera(self, pose, H: int, W: int, focal: float, inds, pixels, t_rand: Optional[torch.Tensor] = None, philox=None,
+                    global_rays: Optional[int] = None, randomized: bool = True):
+        """The same step with the rays generated in the kernel from `pose` and the flat pixel indices `inds`
+        (train.py:109) and the targets read as pixels[inds] (`pixels`: this image as [H*W, 3]): no (N,HW,3) ray
+        tables, no gathers."""
+        st, dev = self.st, self.st.device
+        R = int(inds.shape[0])
+        plan = st.plan(R * self.S)
+        if self._comp is None or self._comp.shape[0] != R:
+            self._comp = torch.empty(R, 3, dtype=torch.float32, device=dev)
+            self._gws = torch.empty(R, 3, dtype=torch.float32, device=dev)
+        ztab = _ops.depth_table(self.near, self.far, self.S, dev)
+        rnd, tr, seed, off = _ops._rng_args(randomized, t_rand, philox)
+        if tr is not None:
+            tr = _ops._f32c(tr)
+        pixels = _ops._f32c(pixels)
+        cam, keep = _ops.camera_struct(pose, H, W, focal, inds, 0)
+        self.model._ensure_packed()
+        denom = 3.0 * float(global_rays if global_rays is not None else R)
+        _l.call("tnerf_train_step_fused_cam", C.byref(st.desc), st.packed.data_ptr(), C.byref(cam), pixels.data_ptr(), R, self.S,
+                ztab.data_ptr(), rnd, _ops._ptr(tr), seed, off, self.white, denom, self._comp.data_ptr(), self._gws.data_ptr(),
+                self.loss.data_ptr(), plan.stash.data_ptr(), plan.Mp, plan.jobs.data_ptr(), plan.n_jobs, plan.slabs.data_ptr(),
+                plan.reduce.data_ptr(), st.grad.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+        _dist.all_reduce_sum_(st.grad)
+        self.opt.step(grads_in_flat=True)
+        return self.loss, self._comp
