@@ -17,7 +17,7 @@ __device__ __forceinline__ void tn_bwd_tile(const BwdArgs& a, const float (&dzh)
     constexpr int NT = HID / 32;
     const MlpLayout& L = a.L;
     const int h = lane >> 5;
-    const float* __restrict__ packed = a.packed;
+    const __amdgpu_buffer_rsrc_t wrsrc = tn_packed_rsrc(a.packed, L.packed_floats);
     float* __restrict__ stash = a.stash;
     const int64_t Mp = a.Mp;
     const int64_t ms = valid ? m : Mp + (lane & 31);           // padding lanes use the dump block
@@ -37,11 +37,11 @@ __device__ __forceinline__ void tn_bwd_tile(const BwdArgs& a, const float (&dzh)
 #pragma unroll
         for (int w = 0; w < NT / 2; ++w) mb[w] = mrow[(int64_t)l * (Mp + 32) * NT + w];
         float* __restrict__ zrow = pl + L.dz_row0[l] * 32;
-        const f32x4* __restrict__ Wt = reinterpret_cast<const f32x4*>(packed + L.bw_head) + lane;
+        const int sbh = (int)(L.bw_head * 4);
         const float b0 = h ? 0.0f : dzh[0], b1 = h ? 0.0f : dzh[1], b2 = h ? 0.0f : dzh[2], b3 = h ? 0.0f : dzh[3];
         tn_static_for<NT>([&](auto tc) TN_INLINE_LAMBDA {
             constexpr int t = decltype(tc)::value;
-            const f32x4 a4 = Wt[t * 64];
+            const f32x4 a4 = tn_frag_load(wrsrc, lane * 16, sbh + t * 1024);
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
@@ -60,7 +60,7 @@ __device__ __forceinline__ void tn_bwd_tile(const BwdArgs& a, const float (&dzh)
 #pragma unroll
         for (int w = 0; w < NT / 2; ++w) mb[w] = mrow[(int64_t)(l - 1) * (Mp + 32) * NT + w];
         float* __restrict__ zrow = pl + L.dz_row0[l - 1] * 32;
-        tn_layer_bwd<HID>(packed, L.bw_hid[l], dz, lane, [&](auto tc, const f32x16& acc) TN_INLINE_LAMBDA {
+        tn_layer_bwd<HID>(wrsrc, L.bw_hid[l], dz, lane, [&](auto tc, const f32x16& acc) TN_INLINE_LAMBDA {
             constexpr int t = decltype(tc)::value;
             tn_static_for<16>([&](auto rc) TN_INLINE_LAMBDA {
                 constexpr int r = decltype(rc)::value;

@@ -36,12 +36,24 @@ __device__ __forceinline__ void tn_static_for(F&& f) {
 }
 #define TN_INLINE_LAMBDA __attribute__((always_inline))
 
+// Weight fragments are fetched with BUFFER loads: descriptor in SGPRs, per-lane 32-bit offset (lane*16), the fragment's
+// position as a scalar offset.  Measured (tools/mfma_feed_probe.hip): one such load per 4 dependent MFMAs is free
+// (64.0 cycles/MFMA), while a global_load with a 64-bit per-lane address costs the wave ~29 cycles of issue that no MFMA
+// overlaps (71.2 cycles/MFMA) at one wave per SIMD.  (Stash STORES were tried as bounds-checked buffer stores too:
+// correct, 3 % slower than global stores with immediate row offsets, so they stay global.)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tn_packed_rsrc(const float* packed, int64_t packed_floats) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(packed), 0, (int)(packed_floats * 4), 0x00020000);
+}
+__device__ __forceinline__ f32x4 tn_frag_load(__amdgpu_buffer_rsrc_t rsrc, int voff_bytes, int soff_bytes) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff_bytes, soff_bytes, 0));
+}
+
 // One dense layer for a 32-sample tile.
 //   HAS_HID: the layer consumes the previous hidden activations `hin` (HID/2 regs per lane)
 //   HAS_ENC: the layer consumes the network input `enc` (NE regs per lane; layer 0 and the skip layer)
 // `fin(integral_constant<t>, acc)` is called once per finished n-tile with the pre-activation accumulator.
 template <int HID, int NE, bool HAS_HID, bool HAS_ENC, typename Fin>
-__device__ __forceinline__ void tn_layer(const float* __restrict__ packed, int64_t off_bias, int64_t off_enc,
+__device__ __forceinline__ void tn_layer(__amdgpu_buffer_rsrc_t rsrc, int64_t off_bias, int64_t off_enc,
                                          int64_t off_hid, const float (&hin)[HID / 2], const float (&enc)[NE],
                                          int lane, Fin&& fin) {
     constexpr int NT = HID / 32;
@@ -50,24 +62,26 @@ __device__ __forceinline__ void tn_layer(const float* __restrict__ packed, int64
     constexpr int GT = GH + GE;
     constexpr int TOTAL = NT * GT;
     constexpr int PF = TN_PFDIST;               // A-fragment prefetch distance (groups of 4 MFMAs = 256 cycles each)
-    const f32x4* __restrict__ Wh = reinterpret_cast<const f32x4*>(packed + (HAS_HID ? off_hid : 0)) + lane;
-    const f32x4* __restrict__ We = reinterpret_cast<const f32x4*>(packed + (HAS_ENC ? off_enc : 0)) + lane;
-    const f32x4* __restrict__ Bf = reinterpret_cast<const f32x4*>(packed + off_bias) + (lane >> 5) * 4;
+    const int vlane = lane * 16, vbias = (lane >> 5) * 64;                      // per-lane byte offsets
+    const int sh = (int)((HAS_HID ? off_hid : 0) * 4), se = (int)((HAS_ENC ? off_enc : 0) * 4), sb = (int)(off_bias * 4);
+    auto Wh = [&](int idx) TN_INLINE_LAMBDA { return tn_frag_load(rsrc, vlane, sh + idx * 1024); };   // group idx of the hidden part
+    auto We = [&](int idx) TN_INLINE_LAMBDA { return tn_frag_load(rsrc, vlane, se + idx * 1024); };
+    auto Bf = [&](int idx) TN_INLINE_LAMBDA { return tn_frag_load(rsrc, vbias, sb + idx * 16); };
 
     f32x4 ring[PF];
     tn_static_for<PF>([&](auto ic) TN_INLINE_LAMBDA {
         constexpr int i = decltype(ic)::value;
         constexpr int t = i / GT, g = i % GT;
         if constexpr (i < TOTAL) {
-            if constexpr (g < GH) ring[i] = Wh[(t * GH + g) * 64];
-            else                  ring[i] = We[(t * GE + (g - GH)) * 64];
+            if constexpr (g < GH) ring[i] = Wh(t * GH + g);
+            else                  ring[i] = We(t * GE + (g - GH));
         }
     });
     tn_static_for<NT>([&](auto tc) TN_INLINE_LAMBDA {
         constexpr int t = decltype(tc)::value;
         f32x16 acc;
         {
-            const f32x4 b0 = Bf[t * 8 + 0], b1 = Bf[t * 8 + 1], b2 = Bf[t * 8 + 2], b3 = Bf[t * 8 + 3];
+            const f32x4 b0 = Bf(t * 8 + 0), b1 = Bf(t * 8 + 1), b2 = Bf(t * 8 + 2), b3 = Bf(t * 8 + 3);
 #pragma unroll
             for (int r = 0; r < 4; ++r) { acc[r] = b0[r]; acc[4 + r] = b1[r]; acc[8 + r] = b2[r]; acc[12 + r] = b3[r]; }
         }
@@ -77,8 +91,8 @@ __device__ __forceinline__ void tn_layer(const float* __restrict__ packed, int64
             const f32x4 a4 = ring[i % PF];
             if constexpr (i + PF < TOTAL) {
                 constexpr int t2 = (i + PF) / GT, g2 = (i + PF) % GT;
-                if constexpr (g2 < GH) ring[i % PF] = Wh[(t2 * GH + g2) * 64];
-                else                   ring[i % PF] = We[(t2 * GE + (g2 - GH)) * 64];
+                if constexpr (g2 < GH) ring[i % PF] = Wh(t2 * GH + g2);
+                else                   ring[i % PF] = We(t2 * GE + (g2 - GH));
             }
             if constexpr (g < GH) {
                 acc = TN_MFMA(a4[0], hin[g * 4 + 0], acc); acc = TN_MFMA(a4[1], hin[g * 4 + 1], acc);
@@ -99,15 +113,16 @@ __device__ __forceinline__ void tn_layer(const float* __restrict__ packed, int64
 // Transposed layer for the backward chain: dH_in^T[k][m] = sum_n W[n][k] dZ^T[n][m]
 // (A operand = W^T fragments packed at off_bw, B operand = dz registers).
 template <int HID, typename Fin>
-__device__ __forceinline__ void tn_layer_bwd(const float* __restrict__ packed, int64_t off_bw,
+__device__ __forceinline__ void tn_layer_bwd(__amdgpu_buffer_rsrc_t rsrc, int64_t off_bw,
                                              const float (&dz)[HID / 2], int lane, Fin&& fin) {
     constexpr int NT = HID / 32;
     constexpr int GT = NT * 4;
     constexpr int TOTAL = NT * GT;
     constexpr int PF = TN_PFDIST;
-    const f32x4* __restrict__ Wt = reinterpret_cast<const f32x4*>(packed + off_bw) + lane;
+    const int vlane = lane * 16, sw = (int)(off_bw * 4);
+    auto Wt = [&](int idx) TN_INLINE_LAMBDA { return tn_frag_load(rsrc, vlane, sw + idx * 1024); };
     f32x4 ring[PF];
-    tn_static_for<PF>([&](auto ic) TN_INLINE_LAMBDA { constexpr int i = decltype(ic)::value; ring[i] = Wt[i * 64]; });
+    tn_static_for<PF>([&](auto ic) TN_INLINE_LAMBDA { constexpr int i = decltype(ic)::value; ring[i] = Wt(i); });
     tn_static_for<NT>([&](auto tc) TN_INLINE_LAMBDA {
         constexpr int t = decltype(tc)::value;
         f32x16 acc;
@@ -117,7 +132,7 @@ __device__ __forceinline__ void tn_layer_bwd(const float* __restrict__ packed, i
             constexpr int g = decltype(gc)::value;
             constexpr int i = t * GT + g;
             const f32x4 a4 = ring[i % PF];
-            if constexpr (i + PF < TOTAL) ring[i % PF] = Wt[(i + PF) * 64];
+            if constexpr (i + PF < TOTAL) ring[i % PF] = Wt(i + PF);
             acc = TN_MFMA(a4[0], dz[g * 4 + 0], acc); acc = TN_MFMA(a4[1], dz[g * 4 + 1], acc);
             acc = TN_MFMA(a4[2], dz[g * 4 + 2], acc); acc = TN_MFMA(a4[3], dz[g * 4 + 3], acc);
             __builtin_amdgcn_sched_barrier(0);

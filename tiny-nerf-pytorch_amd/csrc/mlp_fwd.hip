@@ -28,7 +28,7 @@ __device__ __forceinline__ void tn_mlp_tile(const FwdArgs& a, const float (&enc)
     constexpr int NT = HID / 32;
     const MlpLayout& L = a.L;
     const int h = lane >> 5;
-    const float* __restrict__ packed = a.packed;
+    const __amdgpu_buffer_rsrc_t wrsrc = tn_packed_rsrc(a.packed, L.packed_floats);
     float* __restrict__ stash = a.stash;
     const int64_t Mp = a.Mp;
     const int64_t ms = valid ? m : Mp + (lane & 31);           // padding lanes write to the dump block: stores need no branch
@@ -50,7 +50,7 @@ __device__ __forceinline__ void tn_mlp_tile(const FwdArgs& a, const float (&enc)
     // ---- layer 0: input only
     {
         float* __restrict__ srow = TRAIN ? pl + L.h_row0[0] * 32 : nullptr;
-        tn_layer<HID, NE, false, true>(packed, L.fw_bias[0], L.fw_enc[0], 0, hnext, enc, lane,
+        tn_layer<HID, NE, false, true>(wrsrc, L.fw_bias[0], L.fw_enc[0], 0, hnext, enc, lane,
             [&](auto tc, const f32x16& acc) TN_INLINE_LAMBDA {
                 constexpr int t = decltype(tc)::value;
                 if (TRAIN && (t & 1) == 0) mb[t / 2] = 0u;
@@ -82,8 +82,8 @@ __device__ __forceinline__ void tn_mlp_tile(const FwdArgs& a, const float (&enc)
                 if (TRAIN) srow[(32 * t + (r & 3) + 8 * (r >> 2)) * 32] = v;
             });
         };
-        if (l == L.skip_at) tn_layer<HID, NE, true, true>(packed, L.fw_bias[l], L.fw_enc[l], L.fw_hid[l], hcur, enc, lane, fin);
-        else                tn_layer<HID, NE, true, false>(packed, L.fw_bias[l], 0, L.fw_hid[l], hcur, enc, lane, fin);
+        if (l == L.skip_at) tn_layer<HID, NE, true, true>(wrsrc, L.fw_bias[l], L.fw_enc[l], L.fw_hid[l], hcur, enc, lane, fin);
+        else                tn_layer<HID, NE, true, false>(wrsrc, L.fw_bias[l], 0, L.fw_hid[l], hcur, enc, lane, fin);
         tn_static_for<HID / 2>([&](auto ic) TN_INLINE_LAMBDA { hcur[decltype(ic)::value] = hnext[decltype(ic)::value]; });
         if (TRAIN) {
 #pragma unroll
@@ -94,15 +94,14 @@ __device__ __forceinline__ void tn_mlp_tile(const FwdArgs& a, const float (&enc)
     // ---- heads: one n-tile whose rows 0..2 are rgb.0 and row 3 is sigma.0 (rows 4..31 are zero)
     {
         constexpr int GT = NT * 4;
-        const f32x4* __restrict__ Wh = reinterpret_cast<const f32x4*>(packed + L.fw_head) + lane;
-        const f32x4* __restrict__ Bf = reinterpret_cast<const f32x4*>(packed + L.fw_head_bias) + h * 4;
+        const int shd = (int)(L.fw_head * 4);
         f32x16 acc;
-        const f32x4 b0 = Bf[0];
+        const f32x4 b0 = tn_frag_load(wrsrc, h * 64, (int)(L.fw_head_bias * 4));
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = r < 4 ? b0[r] : 0.0f;
         tn_static_for<GT>([&](auto gc) TN_INLINE_LAMBDA {
             constexpr int g = decltype(gc)::value;
-            const f32x4 a4 = Wh[g * 64];
+            const f32x4 a4 = tn_frag_load(wrsrc, lane * 16, shd + g * 1024);
             acc = TN_MFMA(a4[0], hcur[g * 4 + 0], acc); acc = TN_MFMA(a4[1], hcur[g * 4 + 1], acc);
             acc = TN_MFMA(a4[2], hcur[g * 4 + 2], acc); acc = TN_MFMA(a4[3], hcur[g * 4 + 3], acc);
         });
