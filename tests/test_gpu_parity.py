@@ -503,3 +503,13 @@ def test_camera_sourced_rays_equal_table_rays_bitwise(mods, dev):
         assert torch.equal(x, y)
     with pytest.raises(ValueError):
         mods["ops"].render_camera_fused(st, pose, H, W, focal, H * W - 10, 11, 2.0, 6.0, 64)      # pixel range beyond the image
+
+
+def test_render_one_sharded_single_rank_equals_render_one(mods, dev):
+    cfg, params = golden_params("4x128")
+    g = load_golden("render_4x128")
+    model = make_model(mods, cfg, params, dev)
+    enc = mods["encoding"].PositionalEncoding(cfg["L"], True).to(dev)
+    a = mods["train"].render_one(model, enc, g["H"], g["W"], g["focal"], g["pose"], dev, 64, 2.0, 6.0, 500)
+    b = mods["train"].render_one_sharded(model, enc, g["H"], g["W"], g["focal"], g["pose"], dev, 64, 2.0, 6.0, 500)
+    assert torch.equal(a, b) and float((a.cpu() - g["img"]).abs().max()) <= RGB_TOL

@@ -25,10 +25,22 @@ def main(ckpt_path="checkpoints/tinynerf_latest.pth", out_dir="outputs"):
     encoder = PositionalEncoding(num_freqs=(in_dim - 3) // 6, include_input=True).to(device)
     model = TinyNeRF(in_dim=in_dim, **ckpt["cfg"]).to(device)
     model.load_state_dict(ckpt["model"])
+    # Under torch.distributed (one process per GPU) the 60 poses are dealt round-robin to the ranks — whole frames
+    # need no communication; single process: all frames here.
+    import torch.distributed as dist
+    rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
     frames = []
-    for pose in spiral_poses(poses[0], n_frames=60, radius=0.3):
+    for k, pose in enumerate(spiral_poses(poses[0], n_frames=60, radius=0.3)):
+        if k % world != rank:
+            continue
         img = render_one(model, encoder, H, W, focal, pose, device, n_samples=64, near=2.0, far=6.0)
         frames.append((img.cpu().numpy() * 255).astype(np.uint8))
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, frames)
+        frames = [gathered[k % world][k // world] for k in range(60)]
+        if rank != 0:
+            return
     os.makedirs(out_dir, exist_ok=True)
     try:
         import imageio.v2 as imageio

@@ -97,6 +97,25 @@ def render_one(model: nn.Module, encoder: nn.Module, H: int, W: int, focal: floa
     return torch.cat(parts, dim=0).reshape(H, W, 3).clamp(0.0, 1.0)
 
 
+@torch.no_grad()
+def render_one_sharded(model: nn.Module, encoder: nn.Module, H: int, W: int, focal: float, pose: torch.Tensor,
+                       device: torch.device, n_samples: int = 64, near: float = 2.0, far: float = 6.0,
+                       chunk: int = 8192) -> torch.Tensor:
+    """render_one with the image's pixels sharded over the ranks of the default process group (contiguous flat
+    pixel ranges) and all-gathered; identical to render_one on one rank.  Every rank returns the
+    full (H,W,3) image."""
+    rank, world = _dist.world()
+    if world == 1 or not _fusable(model, encoder):
+        return render_one(model, encoder, H, W, focal, pose, device, n_samples, near, far, chunk)
+    model.eval()
+    lo, hi = _dist.shard_bounds(H * W, rank, world)
+    st, pose_d = model._ensure_packed(), pose.to(device)
+    parts = [ops.render_camera_fused(st, pose_d, H, W, focal, i, min(chunk, hi - i), near, far, n_samples)[0]
+             for i in range(lo, hi, chunk)]
+    local = torch.cat(parts, dim=0) if parts else torch.zeros(0, 3, device=device)
+    return _dist.all_gather_rows(local, H * W).reshape(H, W, 3).clamp(0.0, 1.0)
+
+
 def _save_ckpt(cfg, model, optimizer, step, in_dim):
     torch.save({"model": model.state_dict(), "opt": optimizer.state_dict(), "step": step, "in_dim": in_dim,
                 "cfg": dict(hidden=cfg.hidden, depth=cfg.depth, skip_at=cfg.skip_at)}, cfg.ckpt_path)
