@@ -239,6 +239,40 @@ int tnerf_train_step_fused_cam(const tnerf_mlp_desc* d, const float* packed, con
                                const int32_t* job_table, int64_t n_jobs, float* slabs,
                                const int32_t* reduce_table, float* grads, tnerf_stream_t stream);
 
+/* ------------------------------------------------------------------- bf16 mode (BASELINE cfg 4) */
+/* The same fused paths with bf16 weights and activations on v_mfma_f32_32x32x16_bf16: fp32 accumulation, fp32 biases,
+ * fp32 ray / sample / compositing arithmetic (sample bins stay bit-exact); the encoder output and every hidden
+ * activation are rounded to bf16 (round-to-nearest-even) where the fp32 path keeps fp32.  Weights are streamed once
+ * per workgroup through an LDS ring and shared by its four wavefronts (64 samples each).  Tolerances against the fp32
+ * path: SURVEY.md 8(d) cfg 4.  Requires in_dim = 6L+3. */
+typedef struct tnerf_bf16_sizes {
+    int64_t packed_bytes;       /* fragment-stream of bf16 weights followed by the fp32 biases          */
+    int64_t pack_entries;       /* int32 entries of the pack table                                       */
+    int64_t n_fragments;        /* 1 KB MFMA A-fragments per pass over the network                       */
+    int64_t bias_offset_bytes;  /* where the fp32 biases start inside the packed buffer                  */
+} tnerf_bf16_sizes;
+
+/* HOST. Buffer / table sizes for a model. */
+int tnerf_bf16_plan_sizes(const tnerf_mlp_desc* d, tnerf_bf16_sizes* out);
+/* HOST. table[pack_entries]: first n_fragments*512 entries -> bf16 element i of the stream = bf16(params[table[i]])
+ * (0 if < 0); the remaining entries -> fp32 bias j = params[table[n_fragments*512 + j]]. */
+int tnerf_bf16_pack_table(const tnerf_mlp_desc* d, int32_t* table);
+/* Gather + round the flat fp32 parameters into the packed buffer (after every optimizer step). [src/nerf.py:18-27] */
+int tnerf_mlp_pack_bf16(const tnerf_mlp_desc* d, const float* params, const int32_t* table, void* packed16,
+                        tnerf_stream_t stream);
+/* tnerf_render_fused / tnerf_render_fused_cam in bf16 mode (same arguments; packed16 from tnerf_mlp_pack_bf16).
+ *                                                                         [src/train.py:46-56] */
+int tnerf_render_fused_bf16(const tnerf_mlp_desc* d, const void* packed16,
+                            const float* rays_o, const float* rays_d, int64_t n_rays, int32_t n_samples,
+                            const float* ztab, int32_t randomized, const float* t_rand,
+                            uint64_t seed, uint64_t offset, int32_t white_bkgd,
+                            float* comp_rgb, float* depth, float* acc, tnerf_stream_t stream);
+int tnerf_render_fused_cam_bf16(const tnerf_mlp_desc* d, const void* packed16, const tnerf_camera* cam,
+                                int64_t n_rays, int32_t n_samples,
+                                const float* ztab, int32_t randomized, const float* t_rand,
+                                uint64_t seed, uint64_t offset, int32_t white_bkgd,
+                                float* comp_rgb, float* depth, float* acc, tnerf_stream_t stream);
+
 /* torch.optim.Adam(lr, betas, eps, weight_decay=0) on the flat buffers   [src/train.py:80,127]
  * step = 1-based step count t used for the bias corrections; grad_scale multiplies the gradient
  * first (1/world_size after an all-reduce SUM of already globally-normalised shards = 1). */

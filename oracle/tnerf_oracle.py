@@ -173,6 +173,41 @@ def render_rays(params, skip_at, num_freqs, rays_o, rays_d, near, far, n_samples
     return composite(rgb.reshape(R, n_samples, 3), sigma.reshape(R, n_samples, 1), z, rays_d, white_bkgd)
 
 
+# ----------------------------------------------------------------------- bf16 mode (BASELINE cfg 4)
+def bf16_round(x: Tensor) -> Tensor:
+    """fp32 -> nearest-even bf16 -> fp32 (what v_cvt_pk_bf16_f32 does to an MFMA operand)."""
+    return x.to(torch.bfloat16).to(x.dtype)
+
+
+def mlp_forward_bf16(params: Sequence[Tensor], x: Tensor, skip_at: int) -> Tuple[Tensor, Tensor]:
+    """mlp_forward with the numerics of the bf16 mode (SURVEY.md 8d cfg 4): weights, the network input and every
+    hidden activation rounded to bf16, products accumulated in fp32 (fp64 here: products of bf16 pairs are exact, only
+    the summation order differs), biases / sigmoid / head ReLU in fp32.  Not a reference function: the reference has no
+    reduced-precision path; this restates tiny-nerf-pytorch_amd/csrc/mlp16_core.hpp on the CPU for the parity tests."""
+    depth = (len(params) - 4) // 2
+    xb = bf16_round(x)
+    h = xb
+
+    def lin(inp, w, b):
+        return (inp.double() @ bf16_round(w).double().t()).float() + b
+
+    for i in range(depth):
+        h = bf16_round(torch.relu(lin(h, params[2 * i], params[2 * i + 1])))
+        if i == skip_at - 1:
+            h = torch.cat([h, xb], dim=-1)
+    w_s, b_s, w_c, b_c = params[2 * depth: 2 * depth + 4]
+    return torch.sigmoid(lin(h, w_c, b_c)), torch.relu(lin(h, w_s, b_s))
+
+
+def render_rays_bf16(params, skip_at, num_freqs, rays_o, rays_d, near, far, n_samples, t_rand=None,
+                     include_input=True, white_bkgd=True):
+    """render_rays with mlp_forward_bf16: sampling, encoding and compositing stay fp32."""
+    R = rays_o.shape[0]
+    z, pts = stratified(near, far, n_samples, rays_o, rays_d, t_rand)
+    rgb, sigma = mlp_forward_bf16(params, posenc(pts.reshape(-1, 3), num_freqs, include_input), skip_at)
+    return composite(rgb.reshape(R, n_samples, 3), sigma.reshape(R, n_samples, 1), z, rays_d, white_bkgd)
+
+
 @torch.no_grad()
 def render_image(params, skip_at, num_freqs, H, W, focal, pose, n_samples=64, near=2.0, far=6.0,
                  chunk=8192) -> Tensor:

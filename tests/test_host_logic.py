@@ -304,3 +304,106 @@ def test_input_pairing_is_a_permutation():
         for c in range(3):
             assert e[3 * k + c, 0] == 3 + 6 * k + c and e[3 * k + c, 1] == 3 + 6 * k + 3 + c     # (sin, cos) pair
     assert e[18].tolist() == [0, 1] and e[19].tolist() == [2, -1]
+
+
+# ------------------------------------------------------------------------------------- bf16 mode
+def _mfma16(a, b, acc):
+    """v_mfma_f32_32x32x16_bf16 in exact arithmetic: a, b: [64, 8] (lane, element) with k = 8*(lane>>5) + e;
+    acc: [16, 64].  D[i][j] += sum_k A[i][k] B[k][j]."""
+    A = np.zeros((32, 16)); B = np.zeros((16, 32))
+    for L_ in range(64):
+        A[L_ & 31, 8 * (L_ >> 5):8 * (L_ >> 5) + 8] = a[L_]
+        B[8 * (L_ >> 5):8 * (L_ >> 5) + 8, L_ & 31] = b[L_]
+    D = A @ B
+    for r in range(16):
+        for h in range(2):
+            acc[r, 32 * h:32 * h + 32] += D[_acc_row(r, h), :]
+    return acc
+
+
+@pytest.mark.parametrize("cfg", [(39, 256, 8, 4), (63, 128, 4, 2), (39, 128, 2, 1), (15, 128, 1, 0)])
+def test_bf16_fragment_stream_emulated_chain_equals_mlp(cfg):
+    """The bf16 kernels' register data flow (fragment stream order, accumulator -> packed B operand chaining, input
+    k-slot map) emulated in exact arithmetic must reproduce TinyNeRF.forward for the same (unrounded) weights."""
+    in_dim, hidden, depth, skip_at = cfg
+    lib = tl.load()
+    d = _desc(*cfg)
+    sz = tl.Bf16Sizes()
+    assert lib.tnerf_bf16_plan_sizes(C.byref(d), C.byref(sz)) == 0, tl.last_error()
+    tab = np.empty(sz.pack_entries, np.int32)
+    assert lib.tnerf_bf16_pack_table(C.byref(d), _ptr(tab)) == 0, tl.last_error()
+    assert sz.n_fragments % 16 == 0 and sz.bias_offset_bytes == sz.n_fragments * 1024
+    assert sz.packed_bytes == sz.bias_offset_bytes + 4 * (depth * hidden + 4)
+    g = torch.Generator().manual_seed(11)
+    params = O.mlp_init(in_dim, hidden, depth, skip_at, g)
+    flat = torch.cat([p.reshape(-1) for p in params]).double().numpy()
+    used = tab[tab >= 0]
+    assert len(np.unique(used)) == len(used) == flat.size          # every parameter exactly once
+    vals = np.where(tab >= 0, flat[np.clip(tab, 0, None)], 0.0)
+    frags = vals[:sz.n_fragments * 512].reshape(sz.n_fragments, 64, 8)
+    bias = vals[sz.n_fragments * 512:]
+    Lf = (in_dim - 3) // 6
+    x3 = torch.rand(32, 3, generator=g) * 4 - 2
+    x = O.posenc(x3.double(), Lf, True)                               # [32, in_dim]
+    NT, KH, KE = hidden // 32, hidden // 16, 4
+    lane = np.arange(64); j = lane & 31; h = lane >> 5
+    # input k-steps: slot a = 8u+e -> (sin, cos)[h] of 2^(a/3) x_(a%3); a = 3L: (x, y)[h]; a = 3L+1: (z, 0)[h]
+    enc = np.zeros((KE, 64, 8))
+    for u in range(KE):
+        for e in range(8):
+            a = 8 * u + e
+            for L_ in range(64):
+                if a < 3 * Lf:
+                    col = 3 + 6 * (a // 3) + (a % 3) + 3 * h[L_]
+                elif a == 3 * Lf:
+                    col = h[L_]
+                elif a == 3 * Lf + 1:
+                    col = 2 if h[L_] == 0 else -1
+                else:
+                    col = -1
+                enc[u, L_, e] = x[j[L_], col].item() if col >= 0 else 0.0
+    f = 0
+    cur = None                                                        # [KH, 64, 8] B operands of the hidden k-steps
+    for l in range(depth):
+        nxt = np.zeros((KH, 64, 8))
+        for t in range(NT):
+            acc = np.zeros((16, 64))
+            if l > 0:
+                for s_ in range(KH):
+                    acc = _mfma16(frags[f], cur[s_], acc); f += 1
+            if l == 0 or (skip_at > 0 and l == skip_at):
+                for u in range(KE):
+                    acc = _mfma16(frags[f], enc[u], acc); f += 1
+            for r in range(16):
+                for L_ in range(64):
+                    v = max(acc[r, L_] + bias[l * hidden + 32 * t + _acc_row(r, h[L_])], 0.0)
+                    nxt[2 * t + (r >> 3), L_, r & 7] = v            # registers 0..7 -> k-step 2t, 8..15 -> k-step 2t+1
+        assert f % 16 == 0                                            # every layer is a whole number of stages
+        cur = nxt
+    acc = np.zeros((16, 64))
+    for s_ in range(KH):
+        acc = _mfma16(frags[f], cur[s_], acc); f += 1
+    assert np.all(frags[f:] == 0.0) and sz.n_fragments - f == 16 - KH
+    hb = bias[depth * hidden:depth * hidden + 4]
+    rgb = 1.0 / (1.0 + np.exp(-(acc[:3, :32] + hb[:3, None]))); sigma = np.maximum(acc[3, :32] + hb[3], 0.0)
+    want_rgb, want_sigma = O.mlp_forward([p.double() for p in params], x, skip_at)
+    np.testing.assert_allclose(rgb.T, want_rgb.numpy(), rtol=0, atol=1e-12)
+    np.testing.assert_allclose(sigma, want_sigma.numpy()[:, 0], rtol=0, atol=1e-12)
+
+
+def test_bf16_mode_rejects_generic_input_width():
+    lib = tl.load()
+    sz = tl.Bf16Sizes()
+    assert lib.tnerf_bf16_plan_sizes(C.byref(_desc(10, 128, 2, 1)), C.byref(sz)) == tl.EUNSUPPORTED
+    assert b"6L+3" in lib.tnerf_last_error_string()
+
+
+def test_oracle_bf16_forward_is_close_to_fp32():
+    """Sanity of the CPU restatement of the bf16 mode: bf16 rounding of weights/activations moves the outputs by a
+    few 1e-3, far less than SURVEY.md 8(d) cfg 4's 2e-2 bound on rendered RGB."""
+    g = load_golden("mlp_8x256")
+    cfg, params = golden_params("8x256")
+    rgb, sigma = O.mlp_forward(params, g["x"], cfg["skip_at"])
+    rgb16, sigma16 = O.mlp_forward_bf16(params, g["x"], cfg["skip_at"])
+    assert float((rgb - rgb16).abs().max()) < 2e-2
+    assert float((sigma - sigma16).abs().max()) <= 2e-2 * max(1.0, float(sigma.abs().max()))

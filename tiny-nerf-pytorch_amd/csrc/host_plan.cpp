@@ -364,3 +364,79 @@ extern "C" int tnerf_plan_fill(const tnerf_mlp_desc* d, int64_t M, int32_t n_cu,
     }
     return TNERF_OK;
 }
+
+// ------------------------------------------------------------------------------------ bf16 mode
+extern "C" int tn_build_net16(const tnerf_mlp_desc* d, Net16* n) {
+    int rc = check_desc(d); if (rc) return rc;
+    if (d->in_dim < 9 || (d->in_dim - 3) % 6 != 0) {
+        tn_set_error("bf16 mode: only the fused paths are built and they need in_dim = 6L+3; got %d", d->in_dim);
+        return TNERF_EUNSUPPORTED;
+    }
+    memset(n, 0, sizeof(*n));
+    n->in_dim = d->in_dim; n->hidden = d->hidden; n->depth = d->depth; n->skip_at = d->skip_at;
+    n->Lf = (d->in_dim - 3) / 6;
+    const int NT = d->hidden / 32, KH = d->hidden / 16;
+    int frags = NT * TN16_KE;
+    for (int l = 1; l < d->depth; ++l) frags += NT * (KH + ((d->skip_at > 0 && l == d->skip_at) ? TN16_KE : 0));
+    frags += TN16_STAGE;                                     // heads: KH (<= 16) fragments padded to one stage
+    if (frags % TN16_STAGE != 0) { tn_set_error("bf16 mode: fragment stream is not a whole number of stages"); return TNERF_EUNSUPPORTED; }
+    n->n_frag = frags; n->n_stage = frags / TN16_STAGE;
+    n->bias_off = frags * 1024;
+    n->n_bias = d->depth * d->hidden + 4;
+    n->packed_bytes = (int64_t)n->bias_off + (int64_t)n->n_bias * 4;
+    n->pack_entries = (int64_t)frags * 512 + n->n_bias;
+    return TNERF_OK;
+}
+
+extern "C" int tnerf_bf16_plan_sizes(const tnerf_mlp_desc* d, tnerf_bf16_sizes* out) {
+    Net16 n; int rc = tn_build_net16(d, &n); if (rc) return rc;
+    if (!out) { tn_set_error("tnerf_bf16_plan_sizes: NULL output"); return TNERF_EINVAL; }
+    out->packed_bytes = n.packed_bytes; out->pack_entries = n.pack_entries;
+    out->n_fragments = n.n_frag; out->bias_offset_bytes = n.bias_off;
+    return TNERF_OK;
+}
+
+extern "C" int tnerf_bf16_pack_table(const tnerf_mlp_desc* d, int32_t* T) {
+    Net16 n; int rc = tn_build_net16(d, &n); if (rc) return rc;
+    MlpLayout L; rc = tn_build_layout(d, &L); if (rc) return rc;
+    if (!T) { tn_set_error("tnerf_bf16_pack_table: NULL table"); return TNERF_EINVAL; }
+    for (int64_t i = 0; i < n.pack_entries; ++i) T[i] = -1;
+    const int H = L.hidden, NT = H / 32, KH = H / 16, Lf = n.Lf;
+    auto hid_feature = [](int s, int h, int e) { return 32 * (s >> 1) + TN_ACC_ROW(8 * (s & 1) + e, h); };
+    auto enc_column = [&](int u, int h, int e) -> int {
+        const int a = 8 * u + e;
+        if (a < 3 * Lf) return 3 + 6 * (a / 3) + (a % 3) + 3 * h;        // encoding.py:27-33 column order
+        if (a == 3 * Lf) return h;                                        // x | y
+        if (a == 3 * Lf + 1) return h ? -1 : 2;                           // z | 0
+        return -1;
+    };
+    int64_t f = 0;                                                        // running fragment index
+    auto put = [&](int lane, int e, int64_t src) { T[(f * 64 + lane) * 8 + e] = (int32_t)src; };
+    for (int l = 0; l < L.depth; ++l) {
+        const int fan = L.fan_in[l];
+        const bool skip = L.skip_at > 0 && l == L.skip_at;
+        for (int t = 0; t < NT; ++t) {
+            if (l > 0)
+                for (int s = 0; s < KH; ++s, ++f)
+                    for (int lane = 0; lane < 64; ++lane) for (int e = 0; e < 8; ++e)
+                        put(lane, e, L.p_w[l] + (int64_t)(32 * t + (lane & 31)) * fan + hid_feature(s, lane >> 5, e));
+            if (l == 0 || skip)
+                for (int u = 0; u < TN16_KE; ++u, ++f)
+                    for (int lane = 0; lane < 64; ++lane) for (int e = 0; e < 8; ++e) {
+                        const int c = enc_column(u, lane >> 5, e);
+                        if (c >= 0) put(lane, e, L.p_w[l] + (int64_t)(32 * t + (lane & 31)) * fan + (l == 0 ? 0 : H) + c);
+                    }
+        }
+    }
+    for (int s = 0; s < KH; ++s, ++f)                                     // head tile: rows r,g,b (rgb.0) and sigma.0
+        for (int lane = 0; lane < 64; ++lane) for (int e = 0; e < 8; ++e) {
+            const int row = lane & 31, k = hid_feature(s, lane >> 5, e);
+            if (row < 3) put(lane, e, L.p_wc + (int64_t)row * H + k);
+            else if (row == 3) put(lane, e, L.p_ws + k);
+        }
+    int32_t* B = T + (int64_t)n.n_frag * 512;
+    for (int l = 0; l < L.depth; ++l) for (int j = 0; j < H; ++j) B[l * H + j] = (int32_t)(L.p_b[l] + j);
+    for (int j = 0; j < 3; ++j) B[L.depth * H + j] = (int32_t)(L.p_bc + j);
+    B[L.depth * H + 3] = (int32_t)L.p_bs;
+    return TNERF_OK;
+}

@@ -1,0 +1,204 @@
+// bf16 mode: fused ray -> sample -> encode -> MLP (bf16 MFMA) -> composite (fp32), the body of render_one
+// (reference src/train.py:46-56) for BASELINE cfg 4.  One persistent 512-thread workgroup per CU; a wavefront owns one
+// ray at a time and marches it 32 samples per pass over the network (mlp16_core.hpp), the eight wavefronts of the
+// workgroup sharing the LDS-resident weight stream.
+#include "mlp16_core.hpp"
+#include "mlp_args.hpp"
+
+struct Fwd16Args {
+    Net16 n;
+    const unsigned char* packed;
+    RaySource rs; int64_t R; SampleArgs sa; int32_t white;
+    float* comp; float* depth; float* acc;
+};
+
+// The network for one 32-sample tile: enc -> res[4] (r,g,b after sigmoid; sigma after ReLU; lane-half 0 only).
+template <int HID>
+__device__ __forceinline__ void tn16_mlp_tile(Pipe16& p, const unsigned char* lds, const Net16& n, int h,
+                                              const bf16x8 (&enc)[TN16_KE], float (&res)[4]) {
+    constexpr int KH = HID / 16;
+    const int depth = n.depth, skip_at = n.skip_at;
+    const uint32_t vb0 = TN16_RING + 16u * h;                                   // + layer * HID * 4
+    bf16x8 X[KH], Y[KH];
+    f32x16 acc;
+    tn16_layer<HID, 0>(p, lds, vb0, X, enc, X, acc);
+    int l = 1;
+    while (l < depth) {
+        if (l == skip_at) tn16_layer<HID, 2>(p, lds, vb0 + l * HID * 4, X, enc, Y, acc);
+        else              tn16_layer<HID, 1>(p, lds, vb0 + l * HID * 4, X, enc, Y, acc);
+        if (++l >= depth) break;
+        if (l == skip_at) tn16_layer<HID, 2>(p, lds, vb0 + l * HID * 4, Y, enc, X, acc);
+        else              tn16_layer<HID, 1>(p, lds, vb0 + l * HID * 4, Y, enc, X, acc);
+        ++l;
+    }
+    if ((depth - 1) & 1) tn16_layer<HID, 3>(p, lds, 0, Y, enc, Y, acc);
+    else                 tn16_layer<HID, 3>(p, lds, 0, X, enc, X, acc);
+    // heads: rows 0..2 = rgb.0 (sigmoid), row 3 = sigma.0 (ReLU)                                   nerf.py:39-40
+    const f32x4 hb = *reinterpret_cast<const f32x4*>(lds + TN16_RING + depth * HID * 4);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) res[i] = 1.0f / (1.0f + expf(-(acc[i] + hb[i])));
+    res[3] = fmaxf(acc[3] + hb[3], 0.0f);
+}
+
+template <int HID>
+__global__ __launch_bounds__(512, 2) void k_render16(Fwd16Args a) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    const int lane = tn_lane();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int j = lane & 31, h = lane >> 5;
+    const int S = a.sa.S, Lf = a.n.Lf;
+
+    // fp32 biases -> LDS (behind the ring)
+    {
+        float* bl = reinterpret_cast<float*>(lds + TN16_RING);
+        const float* bg = reinterpret_cast<const float*>(a.packed + a.n.bias_off);
+        for (int i = threadIdx.x; i < a.n.n_bias; i += 512) bl[i] = bg[i];
+    }
+    Pipe16 p;
+    p.lane16 = lane * 16;
+    p.src = a.packed; p.src_off = 0; p.stream_bytes = (uint32_t)a.n.n_stage * TN16_SLOT;
+    p.dst_off = 0; p.lag = wave >= 4;
+    p.lds_dst0 = (uint32_t)(uintptr_t)lds + wave * 2048;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) p.voff[i] = lane * 16 + wave * 2048 + i * 1024;
+    // prologue: stages 0..3 in flight; stage 0 landed and published before the first fragment reads
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    tn16_issue_stage(p); tn16_issue_stage(p); tn16_issue_stage(p); tn16_issue_stage(p);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    p.va_cur = p.lane16; p.va_nxt = p.lane16; p.nxt_off = 0;                  // the first boundary moves va_cur onto slot 0
+#pragma unroll
+    for (int i = 0; i < TN16_PF; ++i) p.afr[i] = *reinterpret_cast<const bf16x8*>(lds + p.lane16 + i * 1024);
+
+    // Every wave of the workgroup runs the same number of network passes (the stage barriers are workgroup-wide):
+    // rays beyond R are computed on a clamped index and not stored.
+    const int64_t n_groups = (a.R + 7) / 8;
+    for (int64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
+        const int64_t ray = g * 8 + wave;
+        const bool rvalid = ray < a.R;
+        const int64_t rayc = rvalid ? ray : a.R - 1;
+        float ro_[3], rd_[3];
+        tn_fetch_ray(a.rs, rayc, ro_, rd_);
+        const float ox = ro_[0], oy = ro_[1], oz = ro_[2], dx = rd_[0], dy = rd_[1], dz = rd_[2];
+        const float dn = tn_norm3(dx, dy, dz);
+        float T_in = 1.0f, cr = 0.f, cg = 0.f, cb = 0.f, cd = 0.f, ca = 0.f;
+        // March the ray 32 samples per pass; every second pass (or the last one) the 64 lanes composite a segment:
+        // lane l <- sample s0 + l.
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int sb = 0; sb < S; sb += 32) {
+            {
+                const int s = sb + j;
+                const int sc = s < S ? s : S - 1;
+                const float z = tn_depth(a.sa, rayc, sc);
+                bf16x8 enc[TN16_KE];
+                tn16_encode(tn_point(ox, dx, z), tn_point(oy, dy, z), tn_point(oz, dz, z), Lf, h, enc);
+                float res[4];
+                tn16_mlp_tile<HID>(p, lds, a.n, h, enc, res);
+                const bool upper = (sb & 32) != 0;                            // wave-uniform
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float mv = __shfl(res[i], lane & 31, 64);           // lanes 32..63 <- lanes 0..31
+                    v[i] = upper ? (h ? mv : v[i]) : res[i];
+                }
+            }
+            if ((sb & 32) == 0 && sb + 32 < S) continue;                      // wait for the upper half
+            const int s0 = sb & ~63;
+            const int s = s0 + lane;
+            const bool ok = s < S && (s - s0) < ((sb & 32) ? 64 : 32);
+            const int sc = s < S ? s : S - 1;
+            const float z = tn_depth(a.sa, rayc, sc);
+            const float zn = (s + 1 < S) ? tn_depth(a.sa, rayc, s + 1) : z;
+            const CompTerms t = tn_comp_terms(ok ? v[3] : 0.0f, z, zn, s == S - 1, dn);       // volume.py:18-31
+            const float om = ok ? t.om : 1.0f;
+            const float incl = tn_wave_scan_mul(om, lane);
+            float excl = __shfl_up(incl, 1, 64);
+            if (lane == 0) excl = 1.0f;
+            const float T = T_in * excl;
+            const float w = ok ? t.alpha * T : 0.0f;                                          // volume.py:34
+            cr += w * v[0]; cg += w * v[1]; cb += w * v[2]; cd += w * z; ca += w;             // volume.py:36-38
+            T_in *= __shfl(incl, 63, 64);
+        }
+        cr = tn_wave_sum(cr); cg = tn_wave_sum(cg); cb = tn_wave_sum(cb); cd = tn_wave_sum(cd); ca = tn_wave_sum(ca);
+        if (lane == 0 && rvalid) {
+            const float bg = a.white ? (1.0f - ca) : 0.0f;                                    // volume.py:42
+            a.comp[3 * ray] = cr + bg; a.comp[3 * ray + 1] = cg + bg; a.comp[3 * ray + 2] = cb + bg;
+            if (a.depth) a.depth[ray] = cd;
+            if (a.acc) a.acc[ray] = ca;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // no DMA may still be writing this workgroup's LDS at exit
+}
+
+// ----------------------------------------------------------------------------------- entry points
+static int render16_impl(const char* who, const tnerf_mlp_desc* d, const void* packed16, const RaySource& rs, int64_t R, int32_t S,
+                         const float* ztab, int32_t randomized, const float* t_rand, uint64_t seed, uint64_t offset, int32_t white,
+                         float* comp, float* depth, float* acc, tnerf_stream_t stream) {
+    Fwd16Args a{};
+    int rc = tn_build_net16(d, &a.n); if (rc) return rc;
+    if (R < 0 || S < 1 || S > 4096 || (R > 0 && (!packed16 || !ztab || !comp || (!rs.c2w && (!rs.rays_o || !rs.rays_d))))) {
+        tn_set_error("%s: R=%lld S=%d (1..4096) packed16=%p rays_o=%p rays_d=%p c2w=%p ztab=%p comp=%p", who, (long long)R, S, packed16,
+                     (const void*)rs.rays_o, (const void*)rs.rays_d, (const void*)rs.c2w, (const void*)ztab, (void*)comp);
+        return TNERF_EINVAL;
+    }
+    if (R == 0) return TNERF_OK;
+    a.packed = static_cast<const unsigned char*>(packed16); a.rs = rs; a.R = R;
+    a.sa = SampleArgs{ztab, t_rand, seed, offset, S, randomized ? 1 : 0};
+    a.white = white; a.comp = comp; a.depth = depth; a.acc = acc;
+    int dev = 0, n_cu = 256;
+    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    const int64_t groups = (R + 7) / 8;
+    const dim3 grid((unsigned)(groups < n_cu ? groups : n_cu)), block(512);
+    const size_t lds_bytes = TN16_RING + (size_t)((a.n.n_bias + 3) / 4 * 4) * 4;
+    if (a.n.hidden == 256) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_render16<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        hipLaunchKernelGGL((k_render16<256>), grid, block, lds_bytes, (hipStream_t)stream, a);
+    } else {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_render16<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        hipLaunchKernelGGL((k_render16<128>), grid, block, lds_bytes, (hipStream_t)stream, a);
+    }
+    TN_HIP_CHECK_LAUNCH(who);
+    return TNERF_OK;
+}
+
+extern "C" int tnerf_render_fused_bf16(const tnerf_mlp_desc* d, const void* packed16, const float* rays_o, const float* rays_d,
+                                       int64_t R, int32_t S, const float* ztab, int32_t randomized, const float* t_rand,
+                                       uint64_t seed, uint64_t offset, int32_t white, float* comp, float* depth, float* acc,
+                                       tnerf_stream_t stream) {
+    return render16_impl("tnerf_render_fused_bf16", d, packed16, tn_table_source(rays_o, rays_d), R, S, ztab, randomized, t_rand, seed,
+                         offset, white, comp, depth, acc, stream);
+}
+
+extern "C" int tnerf_render_fused_cam_bf16(const tnerf_mlp_desc* d, const void* packed16, const tnerf_camera* cam, int64_t R, int32_t S,
+                                           const float* ztab, int32_t randomized, const float* t_rand, uint64_t seed, uint64_t offset,
+                                           int32_t white, float* comp, float* depth, float* acc, tnerf_stream_t stream) {
+    RaySource rs;
+    int rc = tn_camera_source("tnerf_render_fused_cam_bf16", cam, R, &rs); if (rc) return rc;
+    return render16_impl("tnerf_render_fused_cam_bf16", d, packed16, rs, R, S, ztab, randomized, t_rand, seed, offset, white, comp, depth,
+                         acc, stream);
+}
+
+// ----------------------------------------------------------------------------------- packing
+__global__ __launch_bounds__(256) void k_pack16(const float* __restrict__ params, const int32_t* __restrict__ table, int64_t n_w,
+                                                int64_t n_all, unsigned short* __restrict__ out16, float* __restrict__ out32) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_all) return;
+    const int32_t s = table[i];
+    const float v = s >= 0 ? params[s] : 0.0f;
+    if (i < n_w) out16[i] = __builtin_bit_cast(unsigned short, (__bf16)v);      // round to nearest even
+    else out32[i - n_w] = v;
+}
+
+extern "C" int tnerf_mlp_pack_bf16(const tnerf_mlp_desc* d, const float* params, const int32_t* table, void* packed16,
+                                   tnerf_stream_t stream) {
+    Net16 n; int rc = tn_build_net16(d, &n); if (rc) return rc;
+    if (!params || !table || !packed16) {
+        tn_set_error("tnerf_mlp_pack_bf16: params=%p table=%p packed16=%p", (const void*)params, (const void*)table, packed16);
+        return TNERF_EINVAL;
+    }
+    const int64_t n_w = (int64_t)n.n_frag * 512;
+    hipLaunchKernelGGL(k_pack16, dim3((unsigned)((n.pack_entries + 255) / 256)), dim3(256), 0, (hipStream_t)stream, params, table, n_w,
+                       n.pack_entries, static_cast<unsigned short*>(packed16),
+                       reinterpret_cast<float*>(static_cast<unsigned char*>(packed16) + n.bias_off));
+    TN_HIP_CHECK_LAUNCH("tnerf_mlp_pack_bf16");
+    return TNERF_OK;
+}

@@ -34,11 +34,34 @@ struct MlpLayout {
     int32_t enc_row0, h_row0[TN_MAXD], out_row0, dz_row0[TN_MAXD], dzh_row0, stash_rows;
 };
 
+// bf16 mode (mlp16_*.hip): the weights are one STREAM of 1 KB MFMA A-fragments (v_mfma_f32_32x32x16_bf16: lane l holds
+// 8 bf16 = W[row l&31][k-slot 8(l>>5)+e]) in exactly the order a wavefront consumes them during one pass over the
+// network, cut into stages of TN16_STAGE fragments; a workgroup streams the stages through an LDS ring.  Order:
+//   layer 0      : for n-tile t: TN16_KE input k-steps
+//   hidden layer : for n-tile t: hidden/16 k-steps           (skip layer: then TN16_KE input k-steps)
+//   heads        : hidden/16 k-steps of the one head tile (rows r,g,b,sigma), zero-padded to a whole stage
+// followed by the fp32 biases (depth*hidden hidden-layer biases in natural order, then r,g,b,sigma).
+// K-slot <-> feature maps (what makes an accumulator tile the next layer's B operand with no data movement):
+//   hidden k-step s, lane-half h, element e : feature 32(s>>1) + TN_ACC_ROW(8(s&1)+e, h)
+//   input  k-step u, lane-half h, element e : slot a = 8u+e;  a < 3L: (sin, cos)[h](2^(a/3) x_(a%3));  a = 3L: (x, y)[h];
+//                                             a = 3L+1: (z, 0)[h];  else 0          (L = (in_dim-3)/6 <= 10)
+#define TN16_STAGE 16
+#define TN16_KE 4
+struct Net16 {
+    int32_t in_dim, hidden, depth, skip_at, Lf;
+    int32_t n_frag, n_stage;      // per pass
+    int32_t bias_off;             // byte offset of the fp32 biases inside the packed buffer (= n_frag * 1024)
+    int32_t n_bias;               // depth*hidden + 4
+    int64_t packed_bytes;
+    int64_t pack_entries;         // n_frag*512 + n_bias
+};
+
 #ifdef __cplusplus
 extern "C" {
 #endif
 // host_plan.cpp
 int  tn_build_layout(const tnerf_mlp_desc* d, MlpLayout* L);   // 0 or TNERF_E*
+int  tn_build_net16(const tnerf_mlp_desc* d, Net16* n);        // 0 or TNERF_E*
 void tn_set_error(const char* fmt, ...);
 #ifdef __cplusplus
 }

@@ -25,6 +25,10 @@ class PlanSizes(C.Structure):
                                          "reduce_ints", "n_jobs", "stash_row_stride")]
 
 
+class Bf16Sizes(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("packed_bytes", "pack_entries", "n_fragments", "bias_offset_bytes")]
+
+
 _P = C.c_void_p           # device pointers travel as integers (tensor.data_ptr())
 _I32, _I64, _U64, _F, _D = C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_double
 _DESC = C.POINTER(MlpDesc)
@@ -59,6 +63,11 @@ SIGNATURES = {
     "tnerf_render_fused_cam": (C.c_int, [_DESC, _P, C.POINTER(Camera), _I64, _I32, _P, _I32, _P, _U64, _U64, _I32, _P, _P, _P, _P]),
     "tnerf_train_step_fused_cam": (C.c_int, [_DESC, _P, C.POINTER(Camera), _P, _I64, _I32, _P, _I32, _P, _U64, _U64, _I32, _D,
                                              _P, _P, _P, _P, _I64, _P, _I64, _P, _P, _P, _P]),
+    "tnerf_bf16_plan_sizes": (C.c_int, [_DESC, C.POINTER(Bf16Sizes)]),
+    "tnerf_bf16_pack_table": (C.c_int, [_DESC, _P]),
+    "tnerf_mlp_pack_bf16": (C.c_int, [_DESC, _P, _P, _P, _P]),
+    "tnerf_render_fused_bf16": (C.c_int, [_DESC, _P, _P, _P, _I64, _I32, _P, _I32, _P, _U64, _U64, _I32, _P, _P, _P, _P]),
+    "tnerf_render_fused_cam_bf16": (C.c_int, [_DESC, _P, C.POINTER(Camera), _I64, _I32, _P, _I32, _P, _U64, _U64, _I32, _P, _P, _P, _P]),
     "tnerf_adam_step": (C.c_int, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _I64, _F, _P]),
     "tnerf_comm_unique_id": (C.c_int, [_P]),
     "tnerf_comm_init_rank": (C.c_int, [_P, _I32, _I32, C.POINTER(C.c_void_p)]),

@@ -208,6 +208,7 @@ class ModelState:
         self.packed = torch.empty(self.packed_floats, dtype=torch.float32, device=device)
         self.packed_key = None
         self.plans: Dict[int, _Plan] = {}
+        self.bf16: Optional[_Bf16State] = None          # built on first use of the bf16 mode
 
     def plan(self, M: int) -> _Plan:
         p = self.plans.get(M)
@@ -235,8 +236,33 @@ class ModelState:
                 _stream(self.device))
         self.packed_key = key
 
+    def repack_bf16(self, key=None) -> "_Bf16State":
+        """bf16 mode (BASELINE cfg 4): (re)build the bf16 fragment stream + fp32 biases from the flat parameters."""
+        if self.bf16 is None:
+            self.bf16 = _Bf16State(self)
+        b = self.bf16
+        if key is None or key != b.key:
+            _l.call("tnerf_mlp_pack_bf16", C.byref(self.desc), self.flat.data_ptr(), b.table.data_ptr(), b.packed.data_ptr(),
+                    _stream(self.device))
+            b.key = key
+        return b
+
     def grad_views(self, params):
         return [self.grad[o:o + p.numel()].view(p.shape) for p, o in zip(params, self.offsets)]
+
+
+class _Bf16State:
+    """Pack table and packed buffer of the bf16 mode for one model (include/tnerf.h, "bf16 mode")."""
+
+    def __init__(self, st: ModelState):
+        sz = _l.Bf16Sizes()
+        _l.call("tnerf_bf16_plan_sizes", C.byref(st.desc), C.byref(sz))
+        tab = np.empty(int(sz.pack_entries), np.int32)
+        _l.call("tnerf_bf16_pack_table", C.byref(st.desc), tab.ctypes.data_as(C.c_void_p))
+        self.table = torch.from_numpy(tab).to(st.device)
+        self.packed = torch.empty(int(sz.packed_bytes), dtype=torch.uint8, device=st.device)
+        self.n_fragments = int(sz.n_fragments)
+        self.key = None
 
 
 # ---------------------------------------------------------------------------------- MLP op
@@ -367,5 +393,46 @@ def render_camera_fused(st: ModelState, c2w, H, W, focal, pix_first, n_rays, nea
     depth = torch.empty(n_rays, 1, dtype=torch.float32, device=dev)
     acc = torch.empty(n_rays, 1, dtype=torch.float32, device=dev)
     _l.call("tnerf_render_fused_cam", C.byref(st.desc), st.packed.data_ptr(), C.byref(cam), int(n_rays), S, ztab.data_ptr(), rnd,
+            _ptr(tr), seed, off, int(bool(white_bkgd)), comp.data_ptr(), depth.data_ptr(), acc.data_ptr(), _stream(dev))
+    return comp, depth, acc
+
+
+# ------------------------------------------------------------------------------------- bf16 mode
+@torch.no_grad()
+def render_rays_fused_bf16(st: ModelState, rays_o, rays_d, near, far, n_samples, randomized=False, white_bkgd=True,
+                           t_rand=None, philox=None, key=None):
+    """render_rays_fused (inference) with bf16 weights/activations on MFMA, fp32 accumulate and compositing
+    (BASELINE cfg 4).  Returns (comp_rgb [R,3], depth [R,1], acc [R,1])."""
+    dev = _need_cuda(rays_o, rays_d, t_rand)
+    rays_o, rays_d = _f32c(rays_o), _f32c(rays_d)
+    R, S = rays_o.shape[0], int(n_samples)
+    ztab = depth_table(near, far, S, dev)
+    rnd, tr, seed, off = _rng_args(randomized, t_rand, philox)
+    if tr is not None:
+        tr = _f32c(tr)
+    b = st.repack_bf16(key)
+    comp = torch.empty(R, 3, dtype=torch.float32, device=dev)
+    depth = torch.empty(R, 1, dtype=torch.float32, device=dev)
+    acc = torch.empty(R, 1, dtype=torch.float32, device=dev)
+    _l.call("tnerf_render_fused_bf16", C.byref(st.desc), b.packed.data_ptr(), rays_o.data_ptr(), rays_d.data_ptr(), R, S,
+            ztab.data_ptr(), rnd, _ptr(tr), seed, off, int(bool(white_bkgd)), comp.data_ptr(), depth.data_ptr(), acc.data_ptr(),
+            _stream(dev))
+    return comp, depth, acc
+
+
+@torch.no_grad()
+def render_camera_fused_bf16(st: ModelState, c2w, H, W, focal, pix_first, n_rays, near, far, n_samples, white_bkgd=True,
+                             randomized=False, t_rand=None, philox=None, key=None):
+    """render_camera_fused in bf16 mode."""
+    dev = st.device
+    S = int(n_samples)
+    ztab = depth_table(near, far, S, dev)
+    rnd, tr, seed, off = _rng_args(randomized, t_rand, philox)
+    cam, keep = camera_struct(c2w, H, W, focal, None, pix_first)
+    b = st.repack_bf16(key)
+    comp = torch.empty(n_rays, 3, dtype=torch.float32, device=dev)
+    depth = torch.empty(n_rays, 1, dtype=torch.float32, device=dev)
+    acc = torch.empty(n_rays, 1, dtype=torch.float32, device=dev)
+    _l.call("tnerf_render_fused_cam_bf16", C.byref(st.desc), b.packed.data_ptr(), C.byref(cam), int(n_rays), S, ztab.data_ptr(), rnd,
             _ptr(tr), seed, off, int(bool(white_bkgd)), comp.data_ptr(), depth.data_ptr(), acc.data_ptr(), _stream(dev))
     return comp, depth, acc
