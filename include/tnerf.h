@@ -248,8 +248,9 @@ int tnerf_train_step_fused_cam(const tnerf_mlp_desc* d, const float* packed, con
 typedef struct tnerf_bf16_sizes {
     int64_t packed_bytes;       /* fragment-stream of bf16 weights followed by the fp32 biases          */
     int64_t pack_entries;       /* int32 entries of the pack table                                       */
-    int64_t n_fragments;        /* 1 KB MFMA A-fragments per pass over the network                       */
+    int64_t n_fragments;        /* 1 KB MFMA A-fragments: forward stream + backward (transposed) stream  */
     int64_t bias_offset_bytes;  /* where the fp32 biases start inside the packed buffer                  */
+    int64_t n_fwd_fragments;    /* fragments of the forward stream (one pass over the network)           */
 } tnerf_bf16_sizes;
 
 /* HOST. Buffer / table sizes for a model. */
@@ -272,6 +273,55 @@ int tnerf_render_fused_cam_bf16(const tnerf_mlp_desc* d, const void* packed16, c
                                 const float* ztab, int32_t randomized, const float* t_rand,
                                 uint64_t seed, uint64_t offset, int32_t white_bkgd,
                                 float* comp_rgb, float* depth, float* acc, tnerf_stream_t stream);
+
+/* bf16 training (forward + backward of the step body, src/train.py:114-126): activations and activation gradients are
+ * rounded to bf16 between layers, every product is accumulated in fp32, the weight gradients leave the kernels in fp32
+ * (slabs -> fixed-order reduction -> grads[n_params], exactly like the fp32 path) and the optimizer keeps fp32 master
+ * weights.  The stash is organised by tiles of 32 sample slots (n_tiles = n_rays * ceil(n_samples / 32)). */
+typedef struct tnerf_bf16_train_plan {
+    int64_t n_tiles;
+    int64_t stash_bytes;        /* bf16 activations / activation gradients (wgrad operand order), ReLU bits, head outputs */
+    int64_t slab_floats;        /* fp32 weight-gradient partial slabs (one per wgrad workgroup)                           */
+    int64_t job_ints;           /* wgrad job table (int32)                                                                */
+    int64_t reduce_ints;        /* slab -> flat-gradient gather table (int32), same format as tnerf_plan_fill's           */
+    int64_t n_jobs;
+} tnerf_bf16_train_plan;
+/* HOST. */
+int tnerf_bf16_train_sizes(const tnerf_mlp_desc* d, int64_t n_rays, int32_t n_samples, int32_t n_cu, tnerf_bf16_train_plan* out);
+/* HOST. Fill job_table[job_ints] and reduce_table[reduce_ints] (either may be NULL). */
+int tnerf_bf16_train_fill(const tnerf_mlp_desc* d, int64_t n_rays, int32_t n_samples, int32_t n_cu,
+                          int32_t* job_table, int32_t* reduce_table);
+/* The stages of a bf16 training step (arguments as in the fp32 entry points of the same names):
+ *   fwd  : comp_rgb [R,3] + stash;  dgrad: g_comp -> dZ records of the stash;  wgrad: stash -> slabs
+ * followed by tnerf_wgrad_reduce(slabs, reduce_table, n_params, grads). */
+int tnerf_train_fwd_fused_bf16(const tnerf_mlp_desc* d, const void* packed16,
+                               const float* rays_o, const float* rays_d, int64_t n_rays, int32_t n_samples,
+                               const float* ztab, int32_t randomized, const float* t_rand,
+                               uint64_t seed, uint64_t offset, int32_t white_bkgd,
+                               float* comp_rgb, void* stash16, tnerf_stream_t stream);
+int tnerf_train_dgrad_fused_bf16(const tnerf_mlp_desc* d, const void* packed16,
+                                 const float* rays_o, const float* rays_d, int64_t n_rays, int32_t n_samples,
+                                 const float* ztab, int32_t randomized, const float* t_rand,
+                                 uint64_t seed, uint64_t offset, int32_t white_bkgd,
+                                 const float* g_comp, void* stash16, tnerf_stream_t stream);
+int tnerf_wgrad_bf16(const tnerf_mlp_desc* d, const void* stash16, int64_t n_tiles,
+                     const int32_t* job_table, int64_t n_jobs, float* slabs, tnerf_stream_t stream);
+/* tnerf_train_step_fused / tnerf_train_step_fused_cam in bf16 mode: forward, loss, backward -> grads (overwritten). */
+int tnerf_train_step_fused_bf16(const tnerf_mlp_desc* d, const void* packed16,
+                                const float* rays_o, const float* rays_d, const float* target,
+                                int64_t n_rays, int32_t n_samples,
+                                const float* ztab, int32_t randomized, const float* t_rand,
+                                uint64_t seed, uint64_t offset, int32_t white_bkgd, double loss_denominator,
+                                float* comp_rgb, float* g_comp_ws, float* loss_out, void* stash16,
+                                const int32_t* job_table, int64_t n_jobs, float* slabs,
+                                const int32_t* reduce_table, float* grads, tnerf_stream_t stream);
+int tnerf_train_step_fused_cam_bf16(const tnerf_mlp_desc* d, const void* packed16, const tnerf_camera* cam,
+                                    const float* pixels, int64_t n_rays, int32_t n_samples,
+                                    const float* ztab, int32_t randomized, const float* t_rand,
+                                    uint64_t seed, uint64_t offset, int32_t white_bkgd, double loss_denominator,
+                                    float* comp_rgb, float* g_comp_ws, float* loss_out, void* stash16,
+                                    const int32_t* job_table, int64_t n_jobs, float* slabs,
+                                    const int32_t* reduce_table, float* grads, tnerf_stream_t stream);
 
 /* torch.optim.Adam(lr, betas, eps, weight_decay=0) on the flat buffers   [src/train.py:80,127]
  * step = 1-based step count t used for the bias corrections; grad_scale multiplies the gradient

@@ -237,6 +237,54 @@ def loss_and_grads(params, skip_at, num_freqs, rays_o, rays_d, target, near, far
     return loss.detach(), psnr_from_mse(loss.detach()), [g.detach() for g in grads]
 
 
+def loss_and_grads_bf16(params, skip_at, num_freqs, rays_o, rays_d, target, near, far, n_samples, t_rand,
+                        loss_denominator: Optional[int] = None):
+    """loss_and_grads with the numerics of the bf16 training kernels (mlp16_fwd.hip / mlp16_bwd.hip), written out by
+    hand: bf16 weights, inputs, hidden activations H_l and activation gradients dZ_l (incl. the head gradients), every
+    contraction accumulated exactly (fp64 here, fp32 on the GPU), compositing forward/backward in fp32, fp32 weight
+    gradients.  Not a reference function (the reference has no reduced-precision path).
+    Returns (loss, psnr, [grad per param])."""
+    depth = (len(params) - 4) // 2
+    R = rays_o.shape[0]
+    z, pts = stratified(near, far, n_samples, rays_o, rays_d, t_rand)
+    xb = bf16_round(posenc(pts.reshape(-1, 3), num_freqs, True))
+    Wb = [bf16_round(params[2 * i]) for i in range(depth)]
+    w_s, b_s, w_c, b_c = params[2 * depth: 2 * depth + 4]
+    Wh = bf16_round(torch.cat([w_c, w_s], 0))                                   # rows r,g,b,sigma
+    bh = torch.cat([b_c, b_s], 0)
+
+    def mm(a, b):                                                               # exact products, exact-enough sums
+        return (a.double() @ b.double()).float()
+
+    ins, hs = [], []
+    inp = xb
+    for i in range(depth):
+        ins.append(inp)
+        h = bf16_round(torch.relu(mm(inp, Wb[i].t()) + params[2 * i + 1]))
+        hs.append(h)
+        inp = torch.cat([h, xb], -1) if i == skip_at - 1 else h
+    zh = mm(hs[-1], Wh.t()) + bh
+    rgb = torch.sigmoid(zh[:, :3]).requires_grad_(True)
+    sigma = torch.relu(zh[:, 3:4]).requires_grad_(True)
+    comp = composite(rgb.reshape(R, n_samples, 3), sigma.reshape(R, n_samples, 1), z, rays_d, True)[0]
+    sq = (comp - target) ** 2
+    loss = sq.mean() if loss_denominator is None else sq.sum() / float(loss_denominator)
+    d_rgb, d_sigma = torch.autograd.grad(loss, [rgb, sigma])
+    rgb, sigma = rgb.detach(), sigma.detach()
+    dzh = bf16_round(torch.cat([d_rgb * (rgb * (1.0 - rgb)), d_sigma * (sigma > 0).float()], -1))
+    grads = [None] * len(params)
+    gWh = mm(dzh.t(), hs[-1]); gbh = dzh.double().sum(0).float()
+    grads[2 * depth] = gWh[3:4]; grads[2 * depth + 1] = gbh[3:4]
+    grads[2 * depth + 2] = gWh[:3]; grads[2 * depth + 3] = gbh[:3]
+    hidden = params[1].numel()
+    dz = bf16_round(mm(dzh, Wh) * (hs[-1] > 0).float())
+    for i in range(depth - 1, -1, -1):
+        grads[2 * i] = mm(dz.t(), ins[i]); grads[2 * i + 1] = dz.double().sum(0).float()
+        if i > 0:
+            dz = bf16_round(mm(dz, Wb[i][:, :hidden]) * (hs[i - 1] > 0).float())
+    return loss.detach(), psnr_from_mse(loss.detach()), grads
+
+
 class AdamState:
     """torch.optim.Adam defaults as used by the reference (lr from Config, betas (0.9,0.999),
     eps 1e-8, no weight decay).   [src/train.py:80]   Written out explicitly so the fused HIP

@@ -379,12 +379,20 @@ extern "C" int tn_build_net16(const tnerf_mlp_desc* d, Net16* n) {
     int frags = NT * TN16_KE;
     for (int l = 1; l < d->depth; ++l) frags += NT * (KH + ((d->skip_at > 0 && l == d->skip_at) ? TN16_KE : 0));
     frags += TN16_STAGE;                                     // heads: KH (<= 16) fragments padded to one stage
-    if (frags % TN16_STAGE != 0) { tn_set_error("bf16 mode: fragment stream is not a whole number of stages"); return TNERF_EUNSUPPORTED; }
+    const int bw = TN16_STAGE + (d->depth - 1) * NT * KH;    // heads^T: NT (<= 16) fragments padded to one stage
+    if (frags % TN16_STAGE != 0 || bw % TN16_STAGE != 0) { tn_set_error("bf16 mode: fragment stream is not a whole number of stages"); return TNERF_EUNSUPPORTED; }
     n->n_frag = frags; n->n_stage = frags / TN16_STAGE;
-    n->bias_off = frags * 1024;
+    n->n_bw_frag = bw; n->n_bw_stage = bw / TN16_STAGE;
+    n->bias_off = (frags + bw) * 1024;
     n->n_bias = d->depth * d->hidden + 4;
     n->packed_bytes = (int64_t)n->bias_off + (int64_t)n->n_bias * 4;
-    n->pack_entries = (int64_t)frags * 512 + n->n_bias;
+    n->pack_entries = (int64_t)(frags + bw) * 512 + n->n_bias;
+    int ft = 0;
+    n->ft_enc = ft; ft += 2;
+    for (int l = 0; l < d->depth; ++l) { n->ft_h[l] = ft; ft += NT; }
+    for (int l = 0; l < d->depth; ++l) { n->ft_dz[l] = ft; ft += NT; }
+    n->ft_dzh = ft; ft += 1;
+    n->n_ft = ft;
     return TNERF_OK;
 }
 
@@ -392,9 +400,21 @@ extern "C" int tnerf_bf16_plan_sizes(const tnerf_mlp_desc* d, tnerf_bf16_sizes* 
     Net16 n; int rc = tn_build_net16(d, &n); if (rc) return rc;
     if (!out) { tn_set_error("tnerf_bf16_plan_sizes: NULL output"); return TNERF_EINVAL; }
     out->packed_bytes = n.packed_bytes; out->pack_entries = n.pack_entries;
-    out->n_fragments = n.n_frag; out->bias_offset_bytes = n.bias_off;
+    out->n_fragments = n.n_frag + n.n_bw_frag; out->bias_offset_bytes = n.bias_off;
+    out->n_fwd_fragments = n.n_frag;
     return TNERF_OK;
 }
+
+namespace {
+inline int hid_feature16(int s, int h, int e) { return 32 * (s >> 1) + TN_ACC_ROW(8 * (s & 1) + e, h); }
+inline int enc_column16(int Lf, int u, int h, int e) {
+    const int a = 8 * u + e;
+    if (a < 3 * Lf) return 3 + 6 * (a / 3) + (a % 3) + 3 * h;        // encoding.py:27-33 column order
+    if (a == 3 * Lf) return h;                                        // x | y
+    if (a == 3 * Lf + 1) return h ? -1 : 2;                           // z | 0
+    return -1;
+}
+}  // namespace
 
 extern "C" int tnerf_bf16_pack_table(const tnerf_mlp_desc* d, int32_t* T) {
     Net16 n; int rc = tn_build_net16(d, &n); if (rc) return rc;
@@ -402,16 +422,10 @@ extern "C" int tnerf_bf16_pack_table(const tnerf_mlp_desc* d, int32_t* T) {
     if (!T) { tn_set_error("tnerf_bf16_pack_table: NULL table"); return TNERF_EINVAL; }
     for (int64_t i = 0; i < n.pack_entries; ++i) T[i] = -1;
     const int H = L.hidden, NT = H / 32, KH = H / 16, Lf = n.Lf;
-    auto hid_feature = [](int s, int h, int e) { return 32 * (s >> 1) + TN_ACC_ROW(8 * (s & 1) + e, h); };
-    auto enc_column = [&](int u, int h, int e) -> int {
-        const int a = 8 * u + e;
-        if (a < 3 * Lf) return 3 + 6 * (a / 3) + (a % 3) + 3 * h;        // encoding.py:27-33 column order
-        if (a == 3 * Lf) return h;                                        // x | y
-        if (a == 3 * Lf + 1) return h ? -1 : 2;                           // z | 0
-        return -1;
-    };
     int64_t f = 0;                                                        // running fragment index
     auto put = [&](int lane, int e, int64_t src) { T[(f * 64 + lane) * 8 + e] = (int32_t)src; };
+    auto head_w = [&](int row, int k) -> int64_t { return row < 3 ? L.p_wc + (int64_t)row * H + k : (row == 3 ? L.p_ws + k : -1); };
+    // ---- forward stream
     for (int l = 0; l < L.depth; ++l) {
         const int fan = L.fan_in[l];
         const bool skip = L.skip_at > 0 && l == L.skip_at;
@@ -419,24 +433,172 @@ extern "C" int tnerf_bf16_pack_table(const tnerf_mlp_desc* d, int32_t* T) {
             if (l > 0)
                 for (int s = 0; s < KH; ++s, ++f)
                     for (int lane = 0; lane < 64; ++lane) for (int e = 0; e < 8; ++e)
-                        put(lane, e, L.p_w[l] + (int64_t)(32 * t + (lane & 31)) * fan + hid_feature(s, lane >> 5, e));
+                        put(lane, e, L.p_w[l] + (int64_t)(32 * t + (lane & 31)) * fan + hid_feature16(s, lane >> 5, e));
             if (l == 0 || skip)
                 for (int u = 0; u < TN16_KE; ++u, ++f)
                     for (int lane = 0; lane < 64; ++lane) for (int e = 0; e < 8; ++e) {
-                        const int c = enc_column(u, lane >> 5, e);
+                        const int c = enc_column16(Lf, u, lane >> 5, e);
                         if (c >= 0) put(lane, e, L.p_w[l] + (int64_t)(32 * t + (lane & 31)) * fan + (l == 0 ? 0 : H) + c);
                     }
         }
     }
     for (int s = 0; s < KH; ++s, ++f)                                     // head tile: rows r,g,b (rgb.0) and sigma.0
         for (int lane = 0; lane < 64; ++lane) for (int e = 0; e < 8; ++e) {
-            const int row = lane & 31, k = hid_feature(s, lane >> 5, e);
-            if (row < 3) put(lane, e, L.p_wc + (int64_t)row * H + k);
-            else if (row == 3) put(lane, e, L.p_ws + k);
+            const int64_t src = head_w(lane & 31, hid_feature16(s, lane >> 5, e));
+            if (src >= 0) put(lane, e, src);
         }
-    int32_t* B = T + (int64_t)n.n_frag * 512;
+    f = n.n_frag;
+    // ---- backward stream
+    for (int t = 0; t < NT; ++t, ++f)                                     // heads^T: dH[k] = sum_{row<4} W_head[row][k] dZh[row]
+        for (int lane = 0; lane < 32; ++lane) for (int e = 0; e < 4; ++e) put(lane, e, head_w(e, 32 * t + lane));
+    f = n.n_frag + TN16_STAGE;
+    for (int l = L.depth - 1; l >= 1; --l) {
+        const int fan = L.fan_in[l];
+        for (int t = 0; t < NT; ++t)
+            for (int s = 0; s < KH; ++s, ++f)
+                for (int lane = 0; lane < 64; ++lane) for (int e = 0; e < 8; ++e)
+                    put(lane, e, L.p_w[l] + (int64_t)hid_feature16(s, lane >> 5, e) * fan + (32 * t + (lane & 31)));
+    }
+    int32_t* B = T + (int64_t)(n.n_frag + n.n_bw_frag) * 512;
     for (int l = 0; l < L.depth; ++l) for (int j = 0; j < H; ++j) B[l * H + j] = (int32_t)(L.p_b[l] + j);
     for (int j = 0; j < 3; ++j) B[L.depth * H + j] = (int32_t)(L.p_bc + j);
     B[L.depth * H + 3] = (int32_t)L.p_bs;
+    return TNERF_OK;
+}
+
+// ---- bf16 training plan: weight-gradient jobs over the tile-organised stash (tnerf_internal.h)
+namespace {
+struct Job16Class { int a_ft0, n_at, b_ft0, n_bt, wa, has_bias, chunks; int64_t slab0, slab_stride; };
+
+int build_classes16(const Net16& n, int64_t tiles, int n_cu, std::vector<Job16Class>& cls, int64_t* slab_total) {
+    const int NT = n.hidden / 32;
+    bool bad = false;
+    auto add = [&](int a0, int nat, int b0, int nbt, int bias) {
+        Job16Class c{}; c.a_ft0 = a0; c.n_at = nat; c.b_ft0 = b0; c.n_bt = nbt; c.has_bias = bias;
+        int cost; pick_split(nat, nbt, &c.wa, &cost); if (c.wa == 0) bad = true;
+        cls.push_back(c);
+    };
+    // class order (what the reduce table refers to): [0] (dZ_0, ENC) owns b_0; [l] (dZ_l, H_{l-1}) owns b_l;
+    // [depth] (dZ_skip, ENC) if skip; [last] (dZ_head, H_{depth-1}) owns the head biases
+    add(n.ft_dz[0], NT, n.ft_enc, 2, 1);
+    for (int l = 1; l < n.depth; ++l) add(n.ft_dz[l], NT, n.ft_h[l - 1], NT, 1);
+    if (n.skip_at > 0) add(n.ft_dz[n.skip_at], NT, n.ft_enc, 2, 0);
+    add(n.ft_dzh, 1, n.ft_h[n.depth - 1], NT, 1);
+    if (bad) { tn_set_error("bf16 wgrad: no kernel for this layer-shape / wave split"); return TNERF_EUNSUPPORTED; }
+    if ((int)cls.size() > TN_RED_MAXCLS) { tn_set_error("too many wgrad job classes"); return TNERF_EUNSUPPORTED; }
+    // The kernel is HBM-bound: a workgroup's time ~ bytes it streams = (n_at + n_bt) * 2 KB per tile (+ a fixed cost per
+    // tile).  One workgroup per CU: keep splitting the class whose workgroups stream the most.
+    for (auto& c : cls) c.chunks = 1;
+    int total = (int)cls.size();
+    while (total < n_cu) {
+        int best = -1; double best_t = 0.0;
+        for (size_t i = 0; i < cls.size(); ++i) {
+            if (cls[i].chunks >= tiles) continue;
+            const double t = ((double)(cls[i].n_at + cls[i].n_bt) * 2048.0 + 4096.0) * (double)((tiles + cls[i].chunks - 1) / cls[i].chunks);
+            if (t > best_t) { best_t = t; best = (int)i; }
+        }
+        if (best < 0) break;
+        ++cls[best].chunks; ++total;
+    }
+    int64_t off = 0;
+    for (auto& c : cls) {
+        const int64_t per = (tiles + c.chunks - 1) / c.chunks;
+        c.chunks = (int)((tiles + per - 1) / per);
+        c.slab_stride = (int64_t)c.n_at * 32 * (c.n_bt * 32) + (int64_t)c.n_at * 32;
+        c.slab0 = off; off += c.slab_stride * c.chunks;
+    }
+    if (off >= (int64_t)1 << 31) { tn_set_error("slab workspace exceeds int32 offsets"); return TNERF_EUNSUPPORTED; }
+    *slab_total = off;
+    return TNERF_OK;
+}
+}  // namespace
+
+extern "C" int tnerf_bf16_train_sizes(const tnerf_mlp_desc* d, int64_t n_rays, int32_t n_samples, int32_t n_cu,
+                                      tnerf_bf16_train_plan* out) {
+    Net16 n; int rc = tn_build_net16(d, &n); if (rc) return rc;
+    if (!out || n_rays < 1 || n_samples < 1 || n_cu < 1) {
+        tn_set_error("tnerf_bf16_train_sizes: rays=%lld samples=%d n_cu=%d", (long long)n_rays, n_samples, n_cu); return TNERF_EINVAL; }
+    const int64_t tiles = n_rays * ((n_samples + 31) / 32);
+    std::vector<Job16Class> cls; int64_t slab = 0;
+    rc = build_classes16(n, tiles, n_cu, cls, &slab); if (rc) return rc;
+    int64_t jobs = 0; for (auto& c : cls) jobs += c.chunks;
+    MlpLayout L; rc = tn_build_layout(d, &L); if (rc) return rc;
+    out->n_tiles = tiles;
+    out->stash_bytes = TN16_STASH_FRAG_BYTES(n, tiles) + TN16_STASH_MASK_BYTES(n, tiles) + TN16_STASH_OUT_BYTES(n, tiles);
+    out->slab_floats = slab;
+    out->job_ints = jobs * TN_JOB_INTS;
+    out->reduce_ints = TN_RED_HDR + 2 * L.n_params;
+    out->n_jobs = jobs;
+    return TNERF_OK;
+}
+
+extern "C" int tnerf_bf16_train_fill(const tnerf_mlp_desc* d, int64_t n_rays, int32_t n_samples, int32_t n_cu,
+                                     int32_t* job_table, int32_t* reduce_table) {
+    Net16 n; int rc = tn_build_net16(d, &n); if (rc) return rc;
+    MlpLayout L; rc = tn_build_layout(d, &L); if (rc) return rc;
+    if (n_rays < 1 || n_samples < 1 || n_cu < 1) { tn_set_error("tnerf_bf16_train_fill: bad sizes"); return TNERF_EINVAL; }
+    const int64_t tiles = n_rays * ((n_samples + 31) / 32);
+    std::vector<Job16Class> cls; int64_t slab = 0;
+    rc = build_classes16(n, tiles, n_cu, cls, &slab); if (rc) return rc;
+    if (job_table) {
+        int64_t j = 0;
+        int maxch = 0; for (auto& c : cls) maxch = std::max(maxch, c.chunks);
+        for (int ch = 0; ch < maxch; ++ch)
+            for (size_t ci = 0; ci < cls.size(); ++ci) {
+                const Job16Class& c = cls[ci];
+                if (ch >= c.chunks) continue;
+                const int64_t per = (tiles + c.chunks - 1) / c.chunks;
+                int32_t* r = job_table + j * TN_JOB_INTS;
+                memset(r, 0, sizeof(int32_t) * TN_JOB_INTS);
+                r[JOB_A_ROW0] = c.a_ft0; r[JOB_A_ROWS] = c.n_at * 32; r[JOB_B_ROW0] = c.b_ft0; r[JOB_B_ROWS] = c.n_bt * 32;
+                r[JOB_N_AT] = c.n_at; r[JOB_N_BT] = c.n_bt; r[JOB_WA] = c.wa;
+                r[JOB_MBLK0] = (int32_t)(ch * per);
+                r[JOB_MBLKN] = (int32_t)std::max<int64_t>(0, std::min<int64_t>(per, tiles - ch * per));
+                r[JOB_SLAB_OFF] = (int32_t)(c.slab0 + c.slab_stride * ch);
+                r[JOB_CLASS] = (int32_t)ci; r[JOB_HAS_BIAS] = c.has_bias;
+                ++j;
+            }
+    }
+    if (reduce_table) {
+        int32_t* hdr = reduce_table;
+        memset(hdr, 0, sizeof(int32_t) * TN_RED_HDR);
+        hdr[0] = (int32_t)cls.size();
+        for (size_t ci = 0; ci < cls.size(); ++ci) {
+            hdr[1 + 4 * ci + 0] = (int32_t)cls[ci].slab0;
+            hdr[1 + 4 * ci + 1] = (int32_t)cls[ci].slab_stride;
+            hdr[1 + 4 * ci + 2] = cls[ci].chunks;
+        }
+        int32_t* E = reduce_table + TN_RED_HDR;
+        auto put = [&](int64_t param, int cls_id, int64_t elem) { E[2 * param] = (int32_t)elem; E[2 * param + 1] = cls_id; };
+        const int H = L.hidden;
+        const int cls_skip_enc = L.skip_at > 0 ? L.depth : -1;
+        const int cls_head = (int)cls.size() - 1;
+        // input column -> column (32 T + c) of the two ENC feature tiles
+        int inv[64]; for (int c = 0; c < 64; ++c) inv[c] = -1;
+        for (int u = 0; u < TN16_KE; ++u) for (int h = 0; h < 2; ++h) for (int e = 0; e < 8; ++e) {
+            const int col = enc_column16(n.Lf, u, h, e);
+            if (col >= 0) inv[col] = 32 * (u >> 1) + TN_ACC_ROW(8 * (u & 1) + e, h);
+        }
+        for (int l = 0; l < L.depth; ++l) {
+            const int fan = L.fan_in[l];
+            const int ldm = cls[l].n_bt * 32;
+            for (int row = 0; row < H; ++row) {
+                for (int k = 0; k < fan; ++k) {
+                    const int64_t pi = L.p_w[l] + (int64_t)row * fan + k;
+                    if (l == 0) put(pi, 0, (int64_t)row * ldm + inv[k]);
+                    else if (k < H) put(pi, l, (int64_t)row * ldm + k);
+                    else put(pi, cls_skip_enc, (int64_t)row * 64 + inv[k - H]);
+                }
+                put(L.p_b[l] + row, l, (int64_t)cls[l].n_at * 32 * ldm + row);
+            }
+        }
+        const int ldh = cls[cls_head].n_bt * 32;
+        for (int k = 0; k < H; ++k) {
+            put(L.p_ws + k, cls_head, (int64_t)3 * ldh + k);
+            for (int row = 0; row < 3; ++row) put(L.p_wc + (int64_t)row * H + k, cls_head, (int64_t)row * ldh + k);
+        }
+        put(L.p_bs, cls_head, (int64_t)32 * ldh + 3);
+        for (int row = 0; row < 3; ++row) put(L.p_bc + row, cls_head, (int64_t)32 * ldh + row);
+    }
     return TNERF_OK;
 }

@@ -78,10 +78,14 @@ __device__ __forceinline__ void tn16_issue_stage(Pipe16& p) {
 // 0..3 at the start of stage k and by waves 4..7 (p.lag) in the MIDDLE of stage k-1: the two waves of a SIMD thus run
 // half a stage (one n-tile of a 256-wide layer) out of phase, and one's epilogue / encoder / compositing arithmetic
 // overlaps the other's MFMAs instead of both leaving the pipe idle at the same time.
-template <bool MID>
+// STORES: the caller interleaves global stores (training stash) with the stream.  vmcnt retires in issue order, so the
+// wait may leave 2 more operations outstanding — every 3 consecutive stages of the training kernels issue at least
+// two stores — instead of draining stores that were issued a few hundred cycles ago.
+template <bool MID, bool STORES>
 __device__ __forceinline__ void tn16_boundary(Pipe16& p) {
     if (p.lag == MID) {
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if constexpr (STORES) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else                  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         tn16_issue_stage(p);
     }
@@ -92,25 +96,89 @@ __device__ __forceinline__ void tn16_boundary(Pipe16& p) {
     }
 }
 
+// Where a training kernel puts the current tile's records (layout: tnerf_internal.h).
+struct Stash16 {              // all wave-uniform: the lane term is added as a 32-bit offset (scalar-base addressing)
+    unsigned char* frag;      // fragment region + (tile * n_ft) * 2048
+    unsigned char* mask;      // mask region + tile * 64 * (hidden/64) * 4                (layer 0)
+    int64_t mask_lstride;     // bytes between layers
+};
+#define TN16_SEL_OFF(n_bias) (TN16_RING + (uint32_t)(((n_bias) + 3) / 4 * 4) * 4)   // LDS byte offset of the selector pair
+
+// Selector B operands of the transposing MFMAs (2 x 64 lanes x 16 B in LDS): sel_u[k-slot (h,e)][col c] = (c == TN_ACC_ROW(8u+e, h)).
+// A x sel_0 + A' x sel_1 turns two packed k-steps (lane = sample, element = feature slot) into a 32 x 32 tile with the
+// FEATURE on the lane and the 32 samples in the 16 accumulator registers: the K = samples operand of the weight-gradient
+// MFMAs.  The products are exact (x * 1 + 0), so the transposed tile holds the very bf16 values the forward used.
+__device__ __forceinline__ void tn16_write_selectors(unsigned char* lds, uint32_t sel_off, int lane) {
+    const int c = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        unsigned short v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (c == TN_ACC_ROW(8 * u + e, hh)) ? (unsigned short)0x3F80 : (unsigned short)0;
+        u32x4 w;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[i] = (unsigned)v[2 * i] | ((unsigned)v[2 * i + 1] << 16);
+        *reinterpret_cast<u32x4*>(lds + sel_off + u * 1024 + lane * 16) = w;
+    }
+}
+
+// Transpose the k-step pair (b0, b1) and store it as feature tile `ft` of the current tile's stash record.
+__device__ __forceinline__ void tn16_stash_tile(const unsigned char* lds, uint32_t sel_off, uint32_t lane16, const Stash16& st, int ft,
+                                                const bf16x8& b0, const bf16x8& b1, f32x16& d) {
+    const bf16x8 s0 = *reinterpret_cast<const bf16x8*>(lds + sel_off + lane16);
+    const bf16x8 s1 = *reinterpret_cast<const bf16x8*>(lds + sel_off + 1024 + lane16);
+    const f32x16 z = {};
+    d = TN16_MFMA(b0, s0, z);
+    d = TN16_MFMA(b1, s1, d);
+    // (vector elements are copied to scalars first: __builtin_bit_cast applied directly to d[i] reads element 0)
+    u32x4 p0, p1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                                   // exact: the values are bf16-representable
+        const float l0 = d[2 * i], h0 = d[2 * i + 1], l1 = d[8 + 2 * i], h1 = d[8 + 2 * i + 1];
+        p0[i] = __builtin_amdgcn_perm(__float_as_uint(h0), __float_as_uint(l0), 0x07060302u);
+        p1[i] = __builtin_amdgcn_perm(__float_as_uint(h1), __float_as_uint(l1), 0x07060302u);
+    }
+    unsigned char* dst = st.frag + (int64_t)ft * TN16_FT_BYTES;       // uniform
+    *reinterpret_cast<u32x4*>(dst + lane16) = p0;
+    *reinterpret_cast<u32x4*>(dst + 1024 + lane16) = p1;
+}
+
+// 16 ReLU sign bits of an n-tile from its packed outputs (dword q of lo|hi = registers 2q, 2q+1): bit r <-> register r.
+__device__ __forceinline__ unsigned tn16_sign_bits(const u32x4& lo, const u32x4& hi) {
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    const u16x2 one = {1, 1};
+    unsigned am = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const unsigned w = q < 4 ? lo[q] : hi[q - 4];
+        const unsigned t1 = __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(u16x2, w), one));
+        am |= t1 << (2 * q);                                        // low half -> bit 2q, high half -> bit 16 + 2q
+    }
+    return (am & 0xFFFFu) | (am >> 15);
+}
+
 // One layer for the wave's 32-sample tile.
 //   KIND 0: first layer (input k-steps only)   1: hidden   2: skip layer (hidden + input k-steps)   3: heads
 // The epilogue of an n-tile (bias add in fp32, round to bf16, ReLU on the packed pair) follows its last MFMA; the MFMA
 // pipe is kept busy meanwhile by the SIMD's other wave, which runs half a stage out of phase (tn16_boundary).
 // vb: per-lane LDS byte offset of this layer's biases (+ 16 h).  KIND 3 leaves the raw head accumulator in `acc`.
-template <int HID, int KIND>
+// TRAIN: also stash the layer's output tiles (transposed, feature tiles ft0 + t) and its ReLU sign bits (layer l).
+template <int HID, int KIND, bool TRAIN = false>
 __device__ __forceinline__ void tn16_layer(Pipe16& p, const unsigned char* lds, uint32_t vb,
                                            const bf16x8 (&bin)[HID / 16], const bf16x8 (&enc)[TN16_KE],
-                                           bf16x8 (&bout)[HID / 16], f32x16& acc) {
+                                           bf16x8 (&bout)[HID / 16], f32x16& acc,
+                                           const Stash16& st = Stash16{}, uint32_t sel_off = 0, int ft0 = 0, int l = 0) {
     constexpr int NT = KIND == 3 ? 1 : HID / 32, KH = HID / 16;
     constexpr int KPT = KIND == 0 ? TN16_KE : (KIND == 1 ? KH : (KIND == 2 ? KH + TN16_KE : TN16_STAGE));
     constexpr int KUSE = KIND == 3 ? KH : KPT;                 // k-steps with MFMAs (the head stage is zero-padded)
     static_assert((NT * KPT) % TN16_STAGE == 0, "a layer must be a whole number of stages");
+    uint32_t mb[HID / 64];
     tn_static_for<NT>([&](auto tc) TN_INLINE_LAMBDA {
         constexpr int t = decltype(tc)::value;
         tn_static_for<KPT>([&](auto sc) TN_INLINE_LAMBDA {
             constexpr int s = decltype(sc)::value;
             constexpr int F = t * KPT + s;
-            if constexpr (F % (TN16_STAGE / 2) == 0) tn16_boundary<(F % TN16_STAGE) != 0>(p);
+            if constexpr (F % (TN16_STAGE / 2) == 0) tn16_boundary<(F % TN16_STAGE) != 0, TRAIN>(p);
             const bf16x8 afrag = p.afr[F % TN16_PF];
             {
                 constexpr int o = (F % TN16_STAGE) + TN16_PF;
@@ -128,24 +196,57 @@ __device__ __forceinline__ void tn16_layer(Pipe16& p, const unsigned char* lds, 
             __builtin_amdgcn_sched_barrier(0);
         });
         if constexpr (KIND != 3) {
-            tn_static_for<2>([&](auto hc) TN_INLINE_LAMBDA {
-                constexpr int half = decltype(hc)::value;
-                const f32x4 b0 = *reinterpret_cast<const f32x4*>(lds + vb + (32 * t + 16 * half) * 4);
-                const f32x4 b1 = *reinterpret_cast<const f32x4*>(lds + vb + (32 * t + 16 * half + 8) * 4);
-                u32x4 w;
-                w[0] = tn16_relu2(tn16_cvt2(acc[8 * half + 0] + b0[0], acc[8 * half + 1] + b0[1]));
-                w[1] = tn16_relu2(tn16_cvt2(acc[8 * half + 2] + b0[2], acc[8 * half + 3] + b0[3]));
-                w[2] = tn16_relu2(tn16_cvt2(acc[8 * half + 4] + b1[0], acc[8 * half + 5] + b1[1]));
-                w[3] = tn16_relu2(tn16_cvt2(acc[8 * half + 6] + b1[2], acc[8 * half + 7] + b1[3]));
-                bout[2 * t + half] = __builtin_bit_cast(bf16x8, w);
-            });
+            u32x4 w0, w1;
+            {
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(lds + vb + (32 * t) * 4);
+                const f32x4 b1 = *reinterpret_cast<const f32x4*>(lds + vb + (32 * t + 8) * 4);
+                w0[0] = tn16_relu2(tn16_cvt2(acc[0] + b0[0], acc[1] + b0[1]));
+                w0[1] = tn16_relu2(tn16_cvt2(acc[2] + b0[2], acc[3] + b0[3]));
+                w0[2] = tn16_relu2(tn16_cvt2(acc[4] + b1[0], acc[5] + b1[1]));
+                w0[3] = tn16_relu2(tn16_cvt2(acc[6] + b1[2], acc[7] + b1[3]));
+                bout[2 * t] = __builtin_bit_cast(bf16x8, w0);
+            }
+            {
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(lds + vb + (32 * t + 16) * 4);
+                const f32x4 b1 = *reinterpret_cast<const f32x4*>(lds + vb + (32 * t + 24) * 4);
+                w1[0] = tn16_relu2(tn16_cvt2(acc[8] + b0[0], acc[9] + b0[1]));
+                w1[1] = tn16_relu2(tn16_cvt2(acc[10] + b0[2], acc[11] + b0[3]));
+                w1[2] = tn16_relu2(tn16_cvt2(acc[12] + b1[0], acc[13] + b1[1]));
+                w1[3] = tn16_relu2(tn16_cvt2(acc[14] + b1[2], acc[15] + b1[3]));
+                bout[2 * t + 1] = __builtin_bit_cast(bf16x8, w1);
+            }
+            if constexpr (TRAIN) {
+                const unsigned m16 = tn16_sign_bits(w0, w1);
+                if constexpr ((t & 1) == 0) mb[t / 2] = m16; else mb[t / 2] |= m16 << 16;
+                tn16_stash_tile(lds, sel_off, p.lane16, st, ft0 + t, bout[2 * t], bout[2 * t + 1], acc);
+            }
         }
     });
+    if constexpr (TRAIN && KIND != 3) {
+        typedef unsigned mvec __attribute__((ext_vector_type(HID / 64)));
+        mvec mv;
+#pragma unroll
+        for (int i = 0; i < HID / 64; ++i) mv[i] = mb[i];
+        *reinterpret_cast<mvec*>(st.mask + (int64_t)l * st.mask_lstride + p.lane16 / 16 * (HID / 16)) = mv;
+    }
 }
 
 // PositionalEncoding(L, include_input=True) of one point as the bf16 B operand of the input k-steps (slot map:
-// tnerf_internal.h).  reference src/encoding.py:27-33; sin/cos in fp32 (tn_sincos), rounded to bf16.
+// tnerf_internal.h).  reference src/encoding.py:27-33.  The result is rounded to bf16 (2^-9 relative), so sin/cos come
+// from the hardware v_sin_f32 (argument in revolutions, |error| ~ 1e-6): y = 2^k p is exact, y/(2 pi) is formed in two
+// terms (c_hi, c_lo, residual by fma) so that the fractional turn is good to ~1e-7 even at 2^9 * 6 / 2 pi = 490 turns,
+// and cos(x) = sin(x + 1/4 turn).
+__device__ __forceinline__ float tn16_sin_turns(float y, float quarter) {
+    const float c_hi = 0.15915494f, c_lo = 6.4206382e-09f;              // 1/(2 pi) = c_hi + c_lo, c_hi = fp32(1/(2 pi))
+    const float r_hi = __fmul_rn(y, c_hi);
+    const float err = fmaf(y, c_hi, -r_hi);                              // exact residual of the product
+    const float lo = fmaf(y, c_lo, err);
+    const float fr = __builtin_amdgcn_fractf(r_hi);
+    return __builtin_amdgcn_sinf(__builtin_amdgcn_fractf((fr + quarter) + lo));
+}
+
 __device__ __forceinline__ void tn16_encode(float px, float py, float pz, int Lf, int h, bf16x8 (&enc)[TN16_KE]) {
+    const float quarter = h ? 0.25f : 0.0f;
     tn_static_for<TN16_KE>([&](auto uc) TN_INLINE_LAMBDA {
         constexpr int u = decltype(uc)::value;
         float v[8];
@@ -155,9 +256,7 @@ __device__ __forceinline__ void tn16_encode(float px, float py, float pz, int Lf
             const float pc = c == 0 ? px : (c == 1 ? py : pz);
             float r = 0.0f;
             if (a < 3 * Lf) {
-                float sn, cs;
-                tn_sincos(pc * (float)(1u << (k < 31 ? k : 0)), sn, cs);
-                r = h ? cs : sn;
+                r = tn16_sin_turns(pc * (float)(1u << (k < 31 ? k : 0)), quarter);
             } else if (a == 3 * Lf) {
                 r = h ? py : px;
             } else if (a == 3 * Lf + 1) {
@@ -170,3 +269,29 @@ __device__ __forceinline__ void tn16_encode(float px, float py, float pz, int Lf
         enc[u] = __builtin_bit_cast(bf16x8, w);
     });
 }
+
+// Workgroup prologue shared by the bf16 kernels: biases (and the transposition selectors) -> LDS, the first four stages
+// of the stream starting at `src` in flight, stage 0 published, the first fragments in registers.
+__device__ __forceinline__ void tn16_prologue(Pipe16& p, unsigned char* lds, const unsigned char* packed, const Net16& n,
+                                              const unsigned char* src, int n_stage, int lane, int wave, bool selectors) {
+    {
+        float* bl = reinterpret_cast<float*>(lds + TN16_RING);
+        const float* bg = reinterpret_cast<const float*>(packed + n.bias_off);
+        for (int i = threadIdx.x; i < n.n_bias; i += 512) bl[i] = bg[i];
+        if (selectors && wave == 0) tn16_write_selectors(lds, TN16_SEL_OFF(n.n_bias), lane);
+    }
+    p.lane16 = lane * 16;
+    p.src = src; p.src_off = 0; p.stream_bytes = (uint32_t)n_stage * TN16_SLOT;
+    p.dst_off = 0; p.lag = wave >= 4;
+    p.lds_dst0 = (uint32_t)(uintptr_t)lds + wave * 2048;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) p.voff[i] = lane * 16 + wave * 2048 + i * 1024;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    tn16_issue_stage(p); tn16_issue_stage(p); tn16_issue_stage(p); tn16_issue_stage(p);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    p.va_cur = p.lane16; p.va_nxt = p.lane16; p.nxt_off = 0;                  // the first boundary moves va_cur onto slot 0
+#pragma unroll
+    for (int i = 0; i < TN16_PF; ++i) p.afr[i] = *reinterpret_cast<const bf16x8*>(lds + p.lane16 + i * 1024);
+}
+

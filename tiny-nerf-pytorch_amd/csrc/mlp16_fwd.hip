@@ -3,36 +3,33 @@
 // ray at a time and marches it 32 samples per pass over the network (mlp16_core.hpp), the eight wavefronts of the
 // workgroup sharing the LDS-resident weight stream.
 #include "mlp16_core.hpp"
-#include "mlp_args.hpp"
-
-struct Fwd16Args {
-    Net16 n;
-    const unsigned char* packed;
-    RaySource rs; int64_t R; SampleArgs sa; int32_t white;
-    float* comp; float* depth; float* acc;
-};
+#include "mlp16_args.hpp"
 
 // The network for one 32-sample tile: enc -> res[4] (r,g,b after sigmoid; sigma after ReLU; lane-half 0 only).
-template <int HID>
+template <int HID, bool TRAIN>
 __device__ __forceinline__ void tn16_mlp_tile(Pipe16& p, const unsigned char* lds, const Net16& n, int h,
-                                              const bf16x8 (&enc)[TN16_KE], float (&res)[4]) {
+                                              const bf16x8 (&enc)[TN16_KE], float (&res)[4], const Stash16& st, uint32_t sel_off) {
     constexpr int KH = HID / 16;
     const int depth = n.depth, skip_at = n.skip_at;
     const uint32_t vb0 = TN16_RING + 16u * h;                                   // + layer * HID * 4
     bf16x8 X[KH], Y[KH];
     f32x16 acc;
-    tn16_layer<HID, 0>(p, lds, vb0, X, enc, X, acc);
+    if constexpr (TRAIN) {                                                      // the network input, as wgrad's B operand
+        tn16_stash_tile(lds, sel_off, p.lane16, st, n.ft_enc, enc[0], enc[1], acc);
+        tn16_stash_tile(lds, sel_off, p.lane16, st, n.ft_enc + 1, enc[2], enc[3], acc);
+    }
+    tn16_layer<HID, 0, TRAIN>(p, lds, vb0, X, enc, X, acc, st, sel_off, n.ft_h[0], 0);
     int l = 1;
     while (l < depth) {
-        if (l == skip_at) tn16_layer<HID, 2>(p, lds, vb0 + l * HID * 4, X, enc, Y, acc);
-        else              tn16_layer<HID, 1>(p, lds, vb0 + l * HID * 4, X, enc, Y, acc);
+        if (l == skip_at) tn16_layer<HID, 2, TRAIN>(p, lds, vb0 + l * HID * 4, X, enc, Y, acc, st, sel_off, n.ft_h[l], l);
+        else              tn16_layer<HID, 1, TRAIN>(p, lds, vb0 + l * HID * 4, X, enc, Y, acc, st, sel_off, n.ft_h[l], l);
         if (++l >= depth) break;
-        if (l == skip_at) tn16_layer<HID, 2>(p, lds, vb0 + l * HID * 4, Y, enc, X, acc);
-        else              tn16_layer<HID, 1>(p, lds, vb0 + l * HID * 4, Y, enc, X, acc);
+        if (l == skip_at) tn16_layer<HID, 2, TRAIN>(p, lds, vb0 + l * HID * 4, Y, enc, X, acc, st, sel_off, n.ft_h[l], l);
+        else              tn16_layer<HID, 1, TRAIN>(p, lds, vb0 + l * HID * 4, Y, enc, X, acc, st, sel_off, n.ft_h[l], l);
         ++l;
     }
-    if ((depth - 1) & 1) tn16_layer<HID, 3>(p, lds, 0, Y, enc, Y, acc);
-    else                 tn16_layer<HID, 3>(p, lds, 0, X, enc, X, acc);
+    if ((depth - 1) & 1) tn16_layer<HID, 3, TRAIN>(p, lds, 0, Y, enc, Y, acc);
+    else                 tn16_layer<HID, 3, TRAIN>(p, lds, 0, X, enc, X, acc);
     // heads: rows 0..2 = rgb.0 (sigmoid), row 3 = sigma.0 (ReLU)                                   nerf.py:39-40
     const f32x4 hb = *reinterpret_cast<const f32x4*>(lds + TN16_RING + depth * HID * 4);
 #pragma unroll
@@ -40,39 +37,21 @@ __device__ __forceinline__ void tn16_mlp_tile(Pipe16& p, const unsigned char* ld
     res[3] = fmaxf(acc[3] + hb[3], 0.0f);
 }
 
-template <int HID>
+template <int HID, bool TRAIN>
 __global__ __launch_bounds__(512, 2) void k_render16(Fwd16Args a) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
     const int lane = tn_lane();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int j = lane & 31, h = lane >> 5;
     const int S = a.sa.S, Lf = a.n.Lf;
-
-    // fp32 biases -> LDS (behind the ring)
-    {
-        float* bl = reinterpret_cast<float*>(lds + TN16_RING);
-        const float* bg = reinterpret_cast<const float*>(a.packed + a.n.bias_off);
-        for (int i = threadIdx.x; i < a.n.n_bias; i += 512) bl[i] = bg[i];
-    }
+    const uint32_t sel_off = TN16_SEL_OFF(a.n.n_bias);
     Pipe16 p;
-    p.lane16 = lane * 16;
-    p.src = a.packed; p.src_off = 0; p.stream_bytes = (uint32_t)a.n.n_stage * TN16_SLOT;
-    p.dst_off = 0; p.lag = wave >= 4;
-    p.lds_dst0 = (uint32_t)(uintptr_t)lds + wave * 2048;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) p.voff[i] = lane * 16 + wave * 2048 + i * 1024;
-    // prologue: stages 0..3 in flight; stage 0 landed and published before the first fragment reads
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    tn16_issue_stage(p); tn16_issue_stage(p); tn16_issue_stage(p); tn16_issue_stage(p);
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    p.va_cur = p.lane16; p.va_nxt = p.lane16; p.nxt_off = 0;                  // the first boundary moves va_cur onto slot 0
-#pragma unroll
-    for (int i = 0; i < TN16_PF; ++i) p.afr[i] = *reinterpret_cast<const bf16x8*>(lds + p.lane16 + i * 1024);
+    tn16_prologue(p, lds, a.packed, a.n, a.packed, a.n.n_stage, lane, wave, TRAIN);
 
     // Every wave of the workgroup runs the same number of network passes (the stage barriers are workgroup-wide):
-    // rays beyond R are computed on a clamped index and not stored.
+    // rays beyond R are computed on a clamped index and stored nowhere (training: into the dump tile).
     const int64_t n_groups = (a.R + 7) / 8;
+    const int TPR = (S + 31) / 32;
     for (int64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
         const int64_t ray = g * 8 + wave;
         const bool rvalid = ray < a.R;
@@ -92,8 +71,22 @@ __global__ __launch_bounds__(512, 2) void k_render16(Fwd16Args a) {
                 const float z = tn_depth(a.sa, rayc, sc);
                 bf16x8 enc[TN16_KE];
                 tn16_encode(tn_point(ox, dx, z), tn_point(oy, dy, z), tn_point(oz, dz, z), Lf, h, enc);
+                Stash16 st{};
+                int64_t tile = 0;
+                if constexpr (TRAIN) {
+                    tile = rvalid ? rayc * TPR + (sb >> 5) : a.n_tiles;
+                    st.frag = a.stash + (tile * a.n.n_ft) * TN16_FT_BYTES;
+                    st.mask = a.stash + TN16_STASH_FRAG_BYTES(a.n, a.n_tiles) + tile * (64 * (HID / 64) * 4);
+                    st.mask_lstride = (a.n_tiles + 1) * (64 * (HID / 64) * 4);
+                }
                 float res[4];
-                tn16_mlp_tile<HID>(p, lds, a.n, h, enc, res);
+                tn16_mlp_tile<HID, TRAIN>(p, lds, a.n, h, enc, res, st, sel_off);
+                if constexpr (TRAIN) {
+                    f32x4* o4 = reinterpret_cast<f32x4*>(a.stash + TN16_STASH_FRAG_BYTES(a.n, a.n_tiles) + TN16_STASH_MASK_BYTES(a.n, a.n_tiles)) + (tile * 32 + j);
+                    const bool live = s < S;                                   // slots past S: zero outputs
+                    const f32x4 r4 = {live ? res[0] : 0.f, live ? res[1] : 0.f, live ? res[2] : 0.f, live ? res[3] : 0.f};
+                    if (h == 0) *o4 = r4;
+                }
                 const bool upper = (sb & 32) != 0;                            // wave-uniform
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -129,35 +122,49 @@ __global__ __launch_bounds__(512, 2) void k_render16(Fwd16Args a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // no DMA may still be writing this workgroup's LDS at exit
 }
 
+int tn16_launch_fwd(const Fwd16Args& a, bool train, hipStream_t stream, const char* who) {
+    int dev = 0, n_cu = 256;
+    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    const int64_t groups = (a.R + 7) / 8;
+    const dim3 grid((unsigned)(groups < n_cu ? groups : n_cu)), block(512);
+    const size_t lds_bytes = TN16_SEL_OFF(a.n.n_bias) + 2048;
+#define TN16_CASE(H_, T_)                                                                                                        \
+    if (a.n.hidden == H_ && train == T_) {                                                                                        \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_render16<H_, T_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
+        hipLaunchKernelGGL((k_render16<H_, T_>), grid, block, lds_bytes, stream, a);                                              \
+        TN_HIP_CHECK_LAUNCH(who);                                                                                                 \
+        return TNERF_OK;                                                                                                          \
+    }
+    TN16_CASE(256, false) TN16_CASE(256, true) TN16_CASE(128, false) TN16_CASE(128, true)
+#undef TN16_CASE
+    tn_set_error("%s: no bf16 kernel for hidden=%d", who, a.n.hidden);
+    return TNERF_EUNSUPPORTED;
+}
+
 // ----------------------------------------------------------------------------------- entry points
+int tn16_fused_args(const char* who, Fwd16Args& a, const tnerf_mlp_desc* d, const void* packed16, const RaySource& rs, int64_t R, int32_t S,
+                    const float* ztab, int32_t randomized, const float* t_rand, uint64_t seed, uint64_t offset, int32_t white) {
+    int rc = tn_build_net16(d, &a.n); if (rc) return rc;
+    if (R < 0 || S < 1 || S > 4096 || (R > 0 && (!packed16 || !ztab || (!rs.c2w && (!rs.rays_o || !rs.rays_d))))) {
+        tn_set_error("%s: R=%lld S=%d (1..4096) packed16=%p rays_o=%p rays_d=%p c2w=%p ztab=%p", who, (long long)R, S, packed16,
+                     (const void*)rs.rays_o, (const void*)rs.rays_d, (const void*)rs.c2w, (const void*)ztab);
+        return TNERF_EINVAL;
+    }
+    a.packed = static_cast<const unsigned char*>(packed16); a.rs = rs; a.R = R;
+    a.sa = SampleArgs{ztab, t_rand, seed, offset, S, randomized ? 1 : 0};
+    a.white = white;
+    return TNERF_OK;
+}
+
 static int render16_impl(const char* who, const tnerf_mlp_desc* d, const void* packed16, const RaySource& rs, int64_t R, int32_t S,
                          const float* ztab, int32_t randomized, const float* t_rand, uint64_t seed, uint64_t offset, int32_t white,
                          float* comp, float* depth, float* acc, tnerf_stream_t stream) {
     Fwd16Args a{};
-    int rc = tn_build_net16(d, &a.n); if (rc) return rc;
-    if (R < 0 || S < 1 || S > 4096 || (R > 0 && (!packed16 || !ztab || !comp || (!rs.c2w && (!rs.rays_o || !rs.rays_d))))) {
-        tn_set_error("%s: R=%lld S=%d (1..4096) packed16=%p rays_o=%p rays_d=%p c2w=%p ztab=%p comp=%p", who, (long long)R, S, packed16,
-                     (const void*)rs.rays_o, (const void*)rs.rays_d, (const void*)rs.c2w, (const void*)ztab, (void*)comp);
-        return TNERF_EINVAL;
-    }
+    int rc = tn16_fused_args(who, a, d, packed16, rs, R, S, ztab, randomized, t_rand, seed, offset, white); if (rc) return rc;
     if (R == 0) return TNERF_OK;
-    a.packed = static_cast<const unsigned char*>(packed16); a.rs = rs; a.R = R;
-    a.sa = SampleArgs{ztab, t_rand, seed, offset, S, randomized ? 1 : 0};
-    a.white = white; a.comp = comp; a.depth = depth; a.acc = acc;
-    int dev = 0, n_cu = 256;
-    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
-    const int64_t groups = (R + 7) / 8;
-    const dim3 grid((unsigned)(groups < n_cu ? groups : n_cu)), block(512);
-    const size_t lds_bytes = TN16_RING + (size_t)((a.n.n_bias + 3) / 4 * 4) * 4;
-    if (a.n.hidden == 256) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_render16<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        hipLaunchKernelGGL((k_render16<256>), grid, block, lds_bytes, (hipStream_t)stream, a);
-    } else {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_render16<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        hipLaunchKernelGGL((k_render16<128>), grid, block, lds_bytes, (hipStream_t)stream, a);
-    }
-    TN_HIP_CHECK_LAUNCH(who);
-    return TNERF_OK;
+    if (!comp) { tn_set_error("%s: comp_rgb is NULL", who); return TNERF_EINVAL; }
+    a.comp = comp; a.depth = depth; a.acc = acc;
+    return tn16_launch_fwd(a, false, (hipStream_t)stream, who);
 }
 
 extern "C" int tnerf_render_fused_bf16(const tnerf_mlp_desc* d, const void* packed16, const float* rays_o, const float* rays_d,
@@ -195,7 +202,7 @@ extern "C" int tnerf_mlp_pack_bf16(const tnerf_mlp_desc* d, const float* params,
         tn_set_error("tnerf_mlp_pack_bf16: params=%p table=%p packed16=%p", (const void*)params, (const void*)table, packed16);
         return TNERF_EINVAL;
     }
-    const int64_t n_w = (int64_t)n.n_frag * 512;
+    const int64_t n_w = (int64_t)(n.n_frag + n.n_bw_frag) * 512;
     hipLaunchKernelGGL(k_pack16, dim3((unsigned)((n.pack_entries + 255) / 256)), dim3(256), 0, (hipStream_t)stream, params, table, n_w,
                        n.pack_entries, static_cast<unsigned short*>(packed16),
                        reinterpret_cast<float*>(static_cast<unsigned char*>(packed16) + n.bias_off));

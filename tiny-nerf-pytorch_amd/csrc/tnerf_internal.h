@@ -47,14 +47,32 @@ struct MlpLayout {
 //                                             a = 3L+1: (z, 0)[h];  else 0          (L = (in_dim-3)/6 <= 10)
 #define TN16_STAGE 16
 #define TN16_KE 4
+// Backward stream (dgrad), after the forward one: W_head^T (one fragment per k-tile: row 32t+i, k-slot (h=0, e<4) <->
+// head row e = r,g,b,sigma; zero-padded to a stage), then for l = depth-1 .. 1 the hidden part of W_l transposed: for
+// k-tile t: hidden/16 k-steps, fragment row 32t+i <-> input feature, k-slot (s,h,e) <-> output feature as above.
+//
+// bf16 training stash, organised by TILES of 32 sample slots (tile = ray * ceil(S/32) + sb/32; slots past S are zero):
+//   fragments: tile * n_ft + ft  ->  2 KB = [k-step u: 2][lane 64][8 bf16], the K = SAMPLES operand of the weight-gradient
+//              MFMAs: lane (c, h) element e = value of feature (32 ft' + c) for sample slot TN_ACC_ROW(8u+e, h).
+//              ft: ft_enc + {0,1} (input slots: tile T = u>>1, c = TN_ACC_ROW(8(u&1)+e, h) of slot (u,h,e)),
+//                  ft_h[l] + t (H_l), ft_dz[l] + t (dZ_l), ft_dzh (rows 0..3 = d r,g,b,sigma pre-activation)
+//   masks    : [layer][tile][lane 64][hidden/64 words]: bit (t&1)*16 + r of word t/2 <-> H_l[feature 32t + TN_ACC_ROW(r,h)] > 0
+//   out4     : [tile][slot 32][4] fp32 head outputs (r,g,b after sigmoid, sigma after ReLU)
+// One extra ("dump") tile follows the real ones in every region: waves that pad the last workgroup store there.
 struct Net16 {
     int32_t in_dim, hidden, depth, skip_at, Lf;
-    int32_t n_frag, n_stage;      // per pass
-    int32_t bias_off;             // byte offset of the fp32 biases inside the packed buffer (= n_frag * 1024)
+    int32_t n_frag, n_stage;      // forward stream, per pass
+    int32_t n_bw_frag, n_bw_stage;// backward stream, per pass (starts at byte n_frag * 1024)
+    int32_t bias_off;             // byte offset of the fp32 biases inside the packed buffer
     int32_t n_bias;               // depth*hidden + 4
+    int32_t ft_enc, ft_h[TN_MAXD], ft_dz[TN_MAXD], ft_dzh, n_ft;
     int64_t packed_bytes;
-    int64_t pack_entries;         // n_frag*512 + n_bias
+    int64_t pack_entries;         // (n_frag + n_bw_frag)*512 + n_bias
 };
+#define TN16_FT_BYTES 2048
+#define TN16_STASH_FRAG_BYTES(n, tiles) ((int64_t)((tiles) + 1) * (n).n_ft * TN16_FT_BYTES)
+#define TN16_STASH_MASK_BYTES(n, tiles) ((int64_t)(n).depth * ((tiles) + 1) * 64 * ((n).hidden / 64) * 4)
+#define TN16_STASH_OUT_BYTES(n, tiles)  ((int64_t)((tiles) + 1) * 32 * 16)
 
 #ifdef __cplusplus
 extern "C" {

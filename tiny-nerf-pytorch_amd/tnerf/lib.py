@@ -26,7 +26,11 @@ class PlanSizes(C.Structure):
 
 
 class Bf16Sizes(C.Structure):
-    _fields_ = [(n, C.c_int64) for n in ("packed_bytes", "pack_entries", "n_fragments", "bias_offset_bytes")]
+    _fields_ = [(n, C.c_int64) for n in ("packed_bytes", "pack_entries", "n_fragments", "bias_offset_bytes", "n_fwd_fragments")]
+
+
+class Bf16TrainPlan(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("n_tiles", "stash_bytes", "slab_floats", "job_ints", "reduce_ints", "n_jobs")]
 
 
 _P = C.c_void_p           # device pointers travel as integers (tensor.data_ptr())
@@ -68,6 +72,15 @@ SIGNATURES = {
     "tnerf_mlp_pack_bf16": (C.c_int, [_DESC, _P, _P, _P, _P]),
     "tnerf_render_fused_bf16": (C.c_int, [_DESC, _P, _P, _P, _I64, _I32, _P, _I32, _P, _U64, _U64, _I32, _P, _P, _P, _P]),
     "tnerf_render_fused_cam_bf16": (C.c_int, [_DESC, _P, C.POINTER(Camera), _I64, _I32, _P, _I32, _P, _U64, _U64, _I32, _P, _P, _P, _P]),
+    "tnerf_bf16_train_sizes": (C.c_int, [_DESC, _I64, _I32, _I32, C.POINTER(Bf16TrainPlan)]),
+    "tnerf_bf16_train_fill": (C.c_int, [_DESC, _I64, _I32, _I32, _P, _P]),
+    "tnerf_train_fwd_fused_bf16": (C.c_int, [_DESC, _P, _P, _P, _I64, _I32, _P, _I32, _P, _U64, _U64, _I32, _P, _P, _P]),
+    "tnerf_train_dgrad_fused_bf16": (C.c_int, [_DESC, _P, _P, _P, _I64, _I32, _P, _I32, _P, _U64, _U64, _I32, _P, _P, _P]),
+    "tnerf_wgrad_bf16": (C.c_int, [_DESC, _P, _I64, _P, _I64, _P, _P]),
+    "tnerf_train_step_fused_bf16": (C.c_int, [_DESC, _P, _P, _P, _P, _I64, _I32, _P, _I32, _P, _U64, _U64, _I32, _D,
+                                              _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P]),
+    "tnerf_train_step_fused_cam_bf16": (C.c_int, [_DESC, _P, C.POINTER(Camera), _P, _I64, _I32, _P, _I32, _P, _U64, _U64, _I32, _D,
+                                                  _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P]),
     "tnerf_adam_step": (C.c_int, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _I64, _F, _P]),
     "tnerf_comm_unique_id": (C.c_int, [_P]),
     "tnerf_comm_init_rank": (C.c_int, [_P, _I32, _I32, C.POINTER(C.c_void_p)]),

@@ -263,6 +263,34 @@ class _Bf16State:
         self.packed = torch.empty(int(sz.packed_bytes), dtype=torch.uint8, device=st.device)
         self.n_fragments = int(sz.n_fragments)
         self.key = None
+        self.st = st
+        self.plans: Dict[tuple, "_Bf16TrainPlan"] = {}
+
+    def train_plan(self, R: int, S: int) -> "_Bf16TrainPlan":
+        p = self.plans.get((R, S))
+        if p is None:
+            if len(self.plans) >= 2:
+                self.plans.pop(next(iter(self.plans)))
+            p = self.plans[(R, S)] = _Bf16TrainPlan(self.st, R, S)
+        return p
+
+
+class _Bf16TrainPlan:
+    """Stash, slabs and tables of the bf16 training step for one (rays, samples) batch shape."""
+
+    def __init__(self, st: "ModelState", R: int, S: int):
+        dev = st.device
+        sz = _l.Bf16TrainPlan()
+        _l.call("tnerf_bf16_train_sizes", C.byref(st.desc), int(R), int(S), st.n_cu, C.byref(sz))
+        jobs = np.empty(sz.job_ints, np.int32)
+        red = np.empty(sz.reduce_ints, np.int32)
+        _l.call("tnerf_bf16_train_fill", C.byref(st.desc), int(R), int(S), st.n_cu, jobs.ctypes.data_as(C.c_void_p),
+                red.ctypes.data_as(C.c_void_p))
+        self.R, self.S, self.n_tiles, self.n_jobs = int(R), int(S), int(sz.n_tiles), int(sz.n_jobs)
+        self.jobs = torch.from_numpy(jobs).to(dev)
+        self.reduce = torch.from_numpy(red).to(dev)
+        self.stash = torch.empty(int(sz.stash_bytes), dtype=torch.uint8, device=dev)
+        self.slabs = torch.empty(int(sz.slab_floats), dtype=torch.float32, device=dev)
 
 
 # ---------------------------------------------------------------------------------- MLP op

@@ -78,7 +78,13 @@ class FlatAdam(torch.optim.Optimizer):
 class FusedTrainer:
     """One object per (model, optimizer): `step()` is the body of the reference training loop."""
 
-    def __init__(self, model, optimizer: FlatAdam, near: float, far: float, n_samples: int, white_bkgd: bool = True):
+    def __init__(self, model, optimizer: FlatAdam, near: float, far: float, n_samples: int, white_bkgd: bool = True,
+                 precision: str = "fp32"):
+        """precision "bf16" (BASELINE cfg 4): bf16 weights / activations / activation gradients on MFMA with fp32
+        accumulation, fp32 compositing, fp32 weight gradients, fp32 master weights and Adam state."""
+        if precision not in ("fp32", "bf16"):
+            raise ValueError(f"precision must be 'fp32' or 'bf16', got {precision!r}")
+        self.precision = precision
         self.model, self.opt = model, optimizer
         self.near, self.far, self.S, self.white = float(near), float(far), int(n_samples), int(bool(white_bkgd))
         self.st: _ops.ModelState = model.hip_state()
@@ -96,7 +102,6 @@ class FusedTrainer:
         st, dev = self.st, self.st.device
         rays_o, rays_d, target = _ops._f32c(rays_o), _ops._f32c(rays_d), _ops._f32c(target)
         R = rays_o.shape[0]
-        plan = st.plan(R * self.S)
         if self._comp is None or self._comp.shape[0] != R:
             self._comp = torch.empty(R, 3, dtype=torch.float32, device=dev)
             self._gws = torch.empty(R, 3, dtype=torch.float32, device=dev)
@@ -104,8 +109,20 @@ class FusedTrainer:
         rnd, tr, seed, off = _ops._rng_args(randomized, t_rand, philox)
         if tr is not None:
             tr = _ops._f32c(tr)
-        self.model._ensure_packed()
         denom = 3.0 * float(global_rays if global_rays is not None else R)
+        if self.precision == "bf16":
+            b = st.repack_bf16(tuple(p._version for p in self.model._param_list()))
+            bp = b.train_plan(R, self.S)
+            _l.call("tnerf_train_step_fused_bf16", C.byref(st.desc), b.packed.data_ptr(), rays_o.data_ptr(), rays_d.data_ptr(),
+                    target.data_ptr(), R, self.S, ztab.data_ptr(), rnd, _ops._ptr(tr), seed, off, self.white, denom,
+                    self._comp.data_ptr(), self._gws.data_ptr(), self.loss.data_ptr(), bp.stash.data_ptr(),
+                    bp.jobs.data_ptr(), bp.n_jobs, bp.slabs.data_ptr(), bp.reduce.data_ptr(), st.grad.data_ptr(),
+                    torch.cuda.current_stream(dev).cuda_stream)
+            _dist.all_reduce_sum_(st.grad)
+            self.opt.step(grads_in_flat=True)
+            return self.loss, self._comp
+        self.model._ensure_packed()
+        plan = st.plan(R * self.S)
         _l.call("tnerf_train_step_fused", C.byref(st.desc), st.packed.data_ptr(), rays_o.data_ptr(), rays_d.data_ptr(),
                 target.data_ptr(), R, self.S, ztab.data_ptr(), rnd, _ops._ptr(tr), seed, off, self.white, denom,
                 self._comp.data_ptr(), self._gws.data_ptr(), self.loss.data_ptr(), plan.stash.data_ptr(), plan.Mp,
@@ -123,7 +140,6 @@ class FusedTrainer:
         tables, no gathers."""
         st, dev = self.st, self.st.device
         R = int(inds.shape[0])
-        plan = st.plan(R * self.S)
         if self._comp is None or self._comp.shape[0] != R:
             self._comp = torch.empty(R, 3, dtype=torch.float32, device=dev)
             self._gws = torch.empty(R, 3, dtype=torch.float32, device=dev)
@@ -133,8 +149,19 @@ class FusedTrainer:
             tr = _ops._f32c(tr)
         pixels = _ops._f32c(pixels)
         cam, keep = _ops.camera_struct(pose, H, W, focal, inds, 0)
-        self.model._ensure_packed()
         denom = 3.0 * float(global_rays if global_rays is not None else R)
+        if self.precision == "bf16":
+            b = st.repack_bf16(tuple(p._version for p in self.model._param_list()))
+            bp = b.train_plan(R, self.S)
+            _l.call("tnerf_train_step_fused_cam_bf16", C.byref(st.desc), b.packed.data_ptr(), C.byref(cam), pixels.data_ptr(), R, self.S,
+                    ztab.data_ptr(), rnd, _ops._ptr(tr), seed, off, self.white, denom, self._comp.data_ptr(), self._gws.data_ptr(),
+                    self.loss.data_ptr(), bp.stash.data_ptr(), bp.jobs.data_ptr(), bp.n_jobs, bp.slabs.data_ptr(),
+                    bp.reduce.data_ptr(), st.grad.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+            _dist.all_reduce_sum_(st.grad)
+            self.opt.step(grads_in_flat=True)
+            return self.loss, self._comp
+        self.model._ensure_packed()
+        plan = st.plan(R * self.S)
         _l.call("tnerf_train_step_fused_cam", C.byref(st.desc), st.packed.data_ptr(), C.byref(cam), pixels.data_ptr(), R, self.S,
                 ztab.data_ptr(), rnd, _ops._ptr(tr), seed, off, self.white, denom, self._comp.data_ptr(), self._gws.data_ptr(),
                 self.loss.data_ptr(), plan.stash.data_ptr(), plan.Mp, plan.jobs.data_ptr(), plan.n_jobs, plan.slabs.data_ptr(),
