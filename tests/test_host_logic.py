@@ -332,13 +332,14 @@ def test_bf16_fragment_stream_emulated_chain_equals_mlp(cfg):
     assert lib.tnerf_bf16_plan_sizes(C.byref(d), C.byref(sz)) == 0, tl.last_error()
     tab = np.empty(sz.pack_entries, np.int32)
     assert lib.tnerf_bf16_pack_table(C.byref(d), _ptr(tab)) == 0, tl.last_error()
-    assert sz.n_fragments % 16 == 0 and sz.bias_offset_bytes == sz.n_fragments * 1024
+    assert sz.n_fwd_fragments % 16 == 0 and sz.n_fragments % 16 == 0 and sz.bias_offset_bytes == sz.n_fragments * 1024
     assert sz.packed_bytes == sz.bias_offset_bytes + 4 * (depth * hidden + 4)
+    NF = sz.n_fwd_fragments
     g = torch.Generator().manual_seed(11)
     params = O.mlp_init(in_dim, hidden, depth, skip_at, g)
     flat = torch.cat([p.reshape(-1) for p in params]).double().numpy()
-    used = tab[tab >= 0]
-    assert len(np.unique(used)) == len(used) == flat.size          # every parameter exactly once
+    used = tab[:NF * 512][tab[:NF * 512] >= 0]
+    assert len(np.unique(used)) == len(used) == flat.size - (depth * hidden + 4)   # every weight exactly once in the forward stream
     vals = np.where(tab >= 0, flat[np.clip(tab, 0, None)], 0.0)
     frags = vals[:sz.n_fragments * 512].reshape(sz.n_fragments, 64, 8)
     bias = vals[sz.n_fragments * 512:]
@@ -383,12 +384,136 @@ def test_bf16_fragment_stream_emulated_chain_equals_mlp(cfg):
     acc = np.zeros((16, 64))
     for s_ in range(KH):
         acc = _mfma16(frags[f], cur[s_], acc); f += 1
-    assert np.all(frags[f:] == 0.0) and sz.n_fragments - f == 16 - KH
+    assert np.all(frags[f:NF] == 0.0) and NF - f == 16 - KH
     hb = bias[depth * hidden:depth * hidden + 4]
     rgb = 1.0 / (1.0 + np.exp(-(acc[:3, :32] + hb[:3, None]))); sigma = np.maximum(acc[3, :32] + hb[3], 0.0)
     want_rgb, want_sigma = O.mlp_forward([p.double() for p in params], x, skip_at)
     np.testing.assert_allclose(rgb.T, want_rgb.numpy(), rtol=0, atol=1e-12)
     np.testing.assert_allclose(sigma, want_sigma.numpy()[:, 0], rtol=0, atol=1e-12)
+
+    # ---- backward stream: dH = W^T dZ with dZ in the same accumulator -> operand register layout
+    def to_operand(M):                                               # M: [hidden, 32] (feature, sample) -> [KH, 64, 8]
+        out = np.zeros((KH, 64, 8))
+        for s_ in range(KH):
+            for L_ in range(64):
+                for e in range(8):
+                    out[s_, L_, e] = M[32 * (s_ >> 1) + _acc_row(8 * (s_ & 1) + e, h[L_]), j[L_]]
+        return out
+
+    def from_acc(acc):                                               # [16, 64] -> [32 rows, 32 samples]
+        out = np.zeros((32, 32))
+        for r in range(16):
+            for hh in range(2):
+                out[_acc_row(r, hh)] = acc[r, 32 * hh:32 * hh + 32]
+        return out
+
+    rs = np.random.RandomState(5)
+    f = NF
+    dzh = rs.randn(4, 32)                                            # rows r,g,b,sigma
+    zh = np.zeros((64, 8)); zh[:32, :4] = dzh.T                      # lane-half 0, elements 0..3
+    Whead = np.concatenate([params[2 * depth + 2].double().numpy(), params[2 * depth].double().numpy()], 0)
+    want = Whead.T @ dzh
+    for t in range(NT):
+        np.testing.assert_allclose(from_acc(_mfma16(frags[f + t], zh, np.zeros((16, 64)))), want[32 * t:32 * t + 32], atol=1e-12)
+    assert np.all(frags[f + NT:f + 16] == 0.0)
+    f += 16
+    for l in range(depth - 1, 0, -1):
+        dZ = rs.randn(hidden, 32)
+        op = to_operand(dZ)
+        want = params[2 * l].double().numpy()[:, :hidden].T @ dZ
+        for t in range(NT):
+            acc = np.zeros((16, 64))
+            for s_ in range(KH):
+                acc = _mfma16(frags[f], op[s_], acc); f += 1
+            np.testing.assert_allclose(from_acc(acc), want[32 * t:32 * t + 32], atol=1e-12)
+    assert f == sz.n_fragments
+
+    # ---- the transposing MFMAs: operand pair x selectors -> feature on the lane, samples in the registers
+    X = rs.randn(32, 32)                                             # (feature-in-tile, sample)
+    op = to_operand(np.concatenate([X, np.zeros((hidden - 32, 32))], 0))[:2]
+    sel = np.zeros((2, 64, 8))
+    for u in range(2):
+        for L_ in range(64):
+            for e in range(8):
+                sel[u, L_, e] = 1.0 if (L_ & 31) == _acc_row(8 * u + e, L_ >> 5) else 0.0
+    acc = _mfma16(op[1], sel[1], _mfma16(op[0], sel[0], np.zeros((16, 64))))
+    for r in range(16):
+        for L_ in range(64):
+            assert acc[r, L_] == X[L_ & 31, _acc_row(r, L_ >> 5)]    # lane c = feature, register r = sample slot
+
+
+@pytest.mark.parametrize("cfg,R,S,n_cu", [((39, 256, 8, 4), 64, 64, 256), ((63, 128, 4, 2), 37, 100, 256), ((39, 128, 3, 0), 5, 33, 8)])
+def test_bf16_train_plan_jobs_and_reduce_table_reproduce_autograd(cfg, R, S, n_cu):
+    """Emulate the bf16 wgrad decomposition on the host: per job, dW = A^T B over its tiles with A, B read from a stash
+    laid out as the kernels write it (feature tiles; input slots for the encoder tiles), then the reduce table must
+    gather exactly autograd's gradients."""
+    in_dim, hidden, depth, skip_at = cfg
+    lib = tl.load()
+    d = _desc(*cfg)
+    pl = tl.Bf16TrainPlan()
+    assert lib.tnerf_bf16_train_sizes(C.byref(d), R, S, n_cu, C.byref(pl)) == 0, tl.last_error()
+    jobs = np.empty(pl.job_ints, np.int32); red = np.empty(pl.reduce_ints, np.int32)
+    assert lib.tnerf_bf16_train_fill(C.byref(d), R, S, n_cu, _ptr(jobs), _ptr(red)) == 0, tl.last_error()
+    jobs = jobs.reshape(-1, 16)
+    TPR = (S + 31) // 32
+    tiles = R * TPR
+    assert pl.n_tiles == tiles and len(jobs) == pl.n_jobs <= max(n_cu, depth + 2 + (1 if skip_at else 0))
+    NT = hidden // 32
+    n_ft = 2 + 2 * NT * depth + 1
+    ft_enc, ft_h, ft_dz, ft_dzh = 0, [2 + NT * l for l in range(depth)], [2 + NT * depth + NT * l for l in range(depth)], 2 + 2 * NT * depth
+    assert pl.stash_bytes == (tiles + 1) * n_ft * 2048 + depth * (tiles + 1) * 64 * (hidden // 64) * 4 + (tiles + 1) * 512
+    g = torch.Generator().manual_seed(3)
+    params = [p.double().requires_grad_(True) for p in O.mlp_init(in_dim, hidden, depth, skip_at, g)]
+    Lf = (in_dim - 3) // 6
+    M = tiles * 32
+    x = torch.randn(M, in_dim, generator=g, dtype=torch.float64)
+    # forward with hooks on the pre-activations to obtain dZ_l from autograd
+    hcur, zs, hs = x, [], []
+    for i in range(depth):
+        zz = torch.nn.functional.linear(hcur, params[2 * i], params[2 * i + 1]); zz.retain_grad(); zs.append(zz)
+        hh = torch.relu(zz); hs.append(hh)
+        hcur = torch.cat([hh, x], -1) if i == skip_at - 1 else hh
+    zc = torch.nn.functional.linear(hcur, params[2 * depth + 2], params[2 * depth + 3]); zc.retain_grad()
+    zsg = torch.nn.functional.linear(hcur, params[2 * depth], params[2 * depth + 1]); zsg.retain_grad()
+    up = torch.randn(M, 4, generator=g, dtype=torch.float64)
+    (torch.cat([zc, zsg], -1) * up).sum().backward()
+    # the stash as [tile*32 + slot, n_ft*32] (feature tile ft, column c)
+    stash = np.zeros((M, n_ft * 32))
+    for col in range(in_dim):                                        # encoder tiles: input slot order
+        for u in range(4):
+            for hh_ in range(2):
+                for e in range(8):
+                    a = 8 * u + e
+                    cc = 3 + 6 * (a // 3) + (a % 3) + 3 * hh_ if a < 3 * Lf else (hh_ if a == 3 * Lf else ((2 if hh_ == 0 else -1) if a == 3 * Lf + 1 else -1))
+                    if cc == col:
+                        stash[:, (ft_enc + (u >> 1)) * 32 + _acc_row(8 * (u & 1) + e, hh_)] = x[:, col].numpy()
+    for l in range(depth):
+        stash[:, ft_h[l] * 32:(ft_h[l] + NT) * 32] = hs[l].detach().numpy()
+        stash[:, ft_dz[l] * 32:(ft_dz[l] + NT) * 32] = zs[l].grad.numpy()
+    stash[:, ft_dzh * 32:ft_dzh * 32 + 3] = zc.grad.numpy(); stash[:, ft_dzh * 32 + 3] = zsg.grad.numpy()[:, 0]
+    slabs = np.zeros(pl.slab_floats)
+    covered = {}
+    for jb in jobs:
+        a0, nat, b0, nbt, wa, t0, ntl, off, cls, hb = jb[0], jb[4], jb[2], jb[5], jb[6], jb[7], jb[8], jb[9], jb[10], jb[11]
+        assert ntl > 0 and wa in (1, 2, 4, 8)
+        rows = slice(t0 * 32, (t0 + ntl) * 32)
+        A = stash[rows, a0 * 32:(a0 + nat) * 32]; B = stash[rows, b0 * 32:(b0 + nbt) * 32]
+        slabs[off:off + nat * 32 * nbt * 32] = (A.T @ B).reshape(-1)
+        if hb:
+            slabs[off + nat * 32 * nbt * 32:off + nat * 32 * nbt * 32 + nat * 32] = A.sum(0)
+        covered.setdefault(cls, []).append((t0, ntl))
+    for cls, spans in covered.items():                               # every class covers every tile exactly once
+        spans.sort()
+        assert spans[0][0] == 0 and all(spans[i][0] + spans[i][1] == spans[i + 1][0] for i in range(len(spans) - 1))
+        assert spans[-1][0] + spans[-1][1] == tiles
+    ncls = red[0]
+    E = red[260:].reshape(-1, 2)
+    got = np.zeros(len(E))
+    for i, (elem, cls) in enumerate(E):
+        s0, stride, n = red[1 + 4 * cls], red[1 + 4 * cls + 1], red[1 + 4 * cls + 2]
+        got[i] = sum(slabs[s0 + elem + c * stride] for c in range(n))
+    want = np.concatenate([p.grad.reshape(-1).numpy() for p in params])
+    np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-9)
 
 
 def test_bf16_mode_rejects_generic_input_width():

@@ -228,6 +228,8 @@ class ModelState:
                     view.copy_(p.data)
                     p.data = view
         self.packed_key = None
+        if self.bf16 is not None:
+            self.bf16.key = None
 
     def repack(self, key=None) -> None:
         if key is not None and key == self.packed_key:

@@ -69,7 +69,9 @@ class FlatAdam(torch.optim.Optimizer):
         _l.call("tnerf_adam_step", st.flat.data_ptr(), st.grad.data_ptr(), self._m.data_ptr(), self._v.data_ptr(), st.n_params,
                 float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), self._t, float(grad_scale),
                 torch.cuda.current_stream(st.device).cuda_stream)
-        st.packed_key = None
+        st.packed_key = None                     # the packed copies (fp32 fragments, bf16 stream) are stale now
+        if st.bf16 is not None:
+            st.bf16.key = None
         for p in self._params:
             self.state[p]["step"] = torch.tensor(float(self._t))
         return None
