@@ -221,7 +221,7 @@ __device__ __forceinline__ void tn16w_issue(const unsigned char* tile_base, int 
         const bool isa = f < nfa;
         const int fo = isa ? f : f - nfa;
         const unsigned char* src = tile_base + ((int64_t)(isa ? a_ft0 : b_ft0) * 2 + fo) * 1024;
-        tn16_glds(src, lane16, lds_slot + (isa ? 0u : 16384u) + (uint32_t)fo * 1024u);
+        tn16_glds_nt(src, lane16, lds_slot + (isa ? 0u : 16384u) + (uint32_t)fo * 1024u);
     }
 }
 

@@ -26,6 +26,14 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define TN16_SLOT (TN16_STAGE * 1024)          // bytes per stage
 #define TN16_RING (TN16_NS * TN16_SLOT)
 #define TN16_PF 4                              // A-fragment prefetch distance (ds_read -> MFMA), in fragments
+#ifndef TN16_LEAD
+#define TN16_LEAD 6                            // stages in flight behind the published one (LEAD + 2 <= TN16_NS)
+#endif
+#ifndef TN16_MIN_STORES
+#define TN16_MIN_STORES 8                      // lower bound on the stores a training kernel issues in LEAD consecutive stages
+#endif
+#define TN16_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(n) : "memory")
+static_assert(TN16_LEAD + 2 <= TN16_NS && 2 * TN16_LEAD + TN16_MIN_STORES <= 63, "ring / vmcnt budget");
 #define TN16_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 
 // two fp32 -> one dword of two bf16 (RNE).  hipcc has no builtin for the PACKED form on gfx950 and scalarises a vector
@@ -63,6 +71,17 @@ __device__ __forceinline__ void tn16_glds(const unsigned char* src, uint32_t vof
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(src), "s"(lds_dst) : "memory");
 }
+// the same for data that is read exactly once (the training stash in the weight-gradient kernel): non-temporal
+__device__ __forceinline__ void tn16_glds_nt(const unsigned char* src, uint32_t voff, uint32_t lds_dst) {
+    uint32_t keep;
+#ifdef TN16_WGRAD_NT
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(src), "s"(lds_dst) : "memory");
+#else
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(src), "s"(lds_dst) : "memory");
+#endif
+}
 
 // DMA this wave's eighth (2 fragments) of the next stage of the stream into the next ring slot.
 __device__ __forceinline__ void tn16_issue_stage(Pipe16& p) {
@@ -73,19 +92,21 @@ __device__ __forceinline__ void tn16_issue_stage(Pipe16& p) {
     p.dst_off += TN16_SLOT; if (p.dst_off == TN16_RING) p.dst_off = 0;
 }
 
-// Twice per stage.  The workgroup-wide step — wait for this wave's DMA of stage k+1 (stages k+2, k+3 stay in flight),
-// barrier (stage k+1 is now readable by everyone; the slot of stage k-4 is free), issue stage k+4 — is taken by waves
+// Twice per stage.  The workgroup-wide step — wait for this wave's DMA of stage k+1 (stages k+2 .. k+LEAD stay in
+// flight), barrier (stage k+1 is now readable by everyone; the slot of stage k-1 is free), issue stage k+LEAD+1 — is taken by waves
 // 0..3 at the start of stage k and by waves 4..7 (p.lag) in the MIDDLE of stage k-1: the two waves of a SIMD thus run
 // half a stage (one n-tile of a 256-wide layer) out of phase, and one's epilogue / encoder / compositing arithmetic
 // overlaps the other's MFMAs instead of both leaving the pipe idle at the same time.
-// STORES: the caller interleaves global stores (training stash) with the stream.  vmcnt retires in issue order, so the
-// wait may leave 2 more operations outstanding — every 3 consecutive stages of the training kernels issue at least
-// two stores — instead of draining stores that were issued a few hundred cycles ago.
+// STORES: the caller interleaves global stores (training stash) with the stream.  vmcnt retires in issue order and a
+// store stays counted until it reaches L2, so waiting for the DMA of stage k+1 also waits for every older store: the
+// DMA therefore runs TN16_LEAD stages ahead (its wait then only covers stores that are microseconds old), and the
+// wait leaves TN16_MIN_STORES more operations outstanding — fewer than the stores any LEAD consecutive stages of the
+// training kernels issue (>= 2 per n-tile).
 template <bool MID, bool STORES>
 __device__ __forceinline__ void tn16_boundary(Pipe16& p) {
     if (p.lag == MID) {
-        if constexpr (STORES) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else                  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if constexpr (STORES) TN16_WAIT_VM(2 * (TN16_LEAD - 1) + TN16_MIN_STORES);
+        else                  TN16_WAIT_VM(2 * (TN16_LEAD - 1));
         __builtin_amdgcn_s_barrier();
         tn16_issue_stage(p);
     }
@@ -139,22 +160,26 @@ __device__ __forceinline__ void tn16_stash_tile(const unsigned char* lds, uint32
         p1[i] = __builtin_amdgcn_perm(__float_as_uint(h1), __float_as_uint(l1), 0x07060302u);
     }
     unsigned char* dst = st.frag + (int64_t)ft * TN16_FT_BYTES;       // uniform
-    *reinterpret_cast<u32x4*>(dst + lane16) = p0;
-    *reinterpret_cast<u32x4*>(dst + 1024 + lane16) = p1;
+#ifndef TN16_DBG_NO_STASH_STORES            // diagnostic builds only: time the kernels without the stash traffic
+    // non-temporal: 1.1 GB per kernel that nothing re-reads before the weight-gradient kernel (measured: -12 % step time)
+    __builtin_nontemporal_store(p0, reinterpret_cast<u32x4*>(dst + lane16));
+    __builtin_nontemporal_store(p1, reinterpret_cast<u32x4*>(dst + 1024 + lane16));
+#else
+    if (p0[0] == 0x12345678u && p1[3] == 0x9abcdef0u) *reinterpret_cast<u32x4*>(dst + lane16) = p0;
+#endif
 }
 
 // 16 ReLU sign bits of an n-tile from its packed outputs (dword q of lo|hi = registers 2q, 2q+1): bit r <-> register r.
+// The halves are non-negative bf16 (<= 0x7FFF) after the ReLU, so half + 0x7FFF carries into its bit 15 exactly when
+// the half is non-zero, and never into the neighbouring half.
 __device__ __forceinline__ unsigned tn16_sign_bits(const u32x4& lo, const u32x4& hi) {
-    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-    const u16x2 one = {1, 1};
     unsigned am = 0;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         const unsigned w = q < 4 ? lo[q] : hi[q - 4];
-        const unsigned t1 = __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(u16x2, w), one));
-        am |= t1 << (2 * q);                                        // low half -> bit 2q, high half -> bit 16 + 2q
+        am = ((w + 0x7FFF7FFFu) & 0x80008000u) | (am >> 2);        // dword q ends at bits 2q+1 (low half) and 17+2q (high half)
     }
-    return (am & 0xFFFFu) | (am >> 15);
+    return ((am >> 1) & 0x5555u) | ((am >> 16) & 0xAAAAu);
 }
 
 // One layer for the wave's 32-sample tile.
@@ -287,8 +312,9 @@ __device__ __forceinline__ void tn16_prologue(Pipe16& p, unsigned char* lds, con
 #pragma unroll
     for (int i = 0; i < 2; ++i) p.voff[i] = lane * 16 + wave * 2048 + i * 1024;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    tn16_issue_stage(p); tn16_issue_stage(p); tn16_issue_stage(p); tn16_issue_stage(p);
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i <= TN16_LEAD; ++i) tn16_issue_stage(p);
+    TN16_WAIT_VM(2 * TN16_LEAD);
     __builtin_amdgcn_s_barrier();
     p.va_cur = p.lane16; p.va_nxt = p.lane16; p.nxt_off = 0;                  // the first boundary moves va_cur onto slot 0
 #pragma unroll
