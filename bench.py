@@ -17,7 +17,10 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
                  kernel time measured live with HIP events on the launch stream,
   cpu_baseline — the CPU oracle (a port of the reference's fp32 CPU path) timed on this box's host cores on a
                  bounded sample (rank 0, N=1 only),
-  kernels / psnr — per-kernel times and the PSNR reached (context, not part of the contract).
+  kernels / psnr — per-kernel times and the PSNR reached (context, not part of the contract),
+  bf16         — BASELINE.json configs[3]: the same step with bf16 weights/activations on MFMA (fp32 accumulate,
+                 fp32 compositing, fp32 master weights), same data stream: step time, per-kernel times and the
+                 PSNR difference against the fp32 run above.  Context only: the headline stays fp32.
 """
 import argparse
 import json
@@ -38,6 +41,8 @@ import torch.distributed as dist   # noqa: E402
 L_FREQS, HIDDEN, DEPTH, SKIP = 6, 256, 8, 4
 RAYS, SAMPLES, NEAR, FAR, LR = 4096, 64, 2.0, 6.0, 5e-4
 PEAK_F32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: 256 CU x 2.4 GHz x 256 FLOP/clk/CU
+PEAK_BF16_MFMA_TFLOPS = 2516.6      # 16x the fp32 MFMA rate (v_mfma_f32_32x32x16_bf16: 32 cycles per 32768 FLOP per SIMD)
+PEAK_HBM_GBS = 8000.0
 IN_DIM = 6 * L_FREQS + 3
 MACS_PER_SAMPLE = IN_DIM * HIDDEN + (DEPTH - 1) * HIDDEN * HIDDEN + IN_DIM * HIDDEN + 4 * HIDDEN   # 479,744
 FLOPS_FWD_PER_RAY = 2 * MACS_PER_SAMPLE * SAMPLES                                                   # 61,407,232
@@ -103,6 +108,7 @@ def main():
     ap.add_argument("--psnr-steps", type=int, default=1000, help="extra untimed steps before reporting PSNR (rank 0 context)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--philox", action="store_true", help="draw the jitter in-kernel (Philox) instead of torch.rand")
+    ap.add_argument("--no-bf16", action="store_true", help="skip the bf16-mode section (BASELINE.json configs[3])")
     ap.add_argument("--ray-tables", action="store_true",
                     help="gather rays/targets from precomputed (N,HW,3) tables like the reference loop (train.py:94-112) "
                          "instead of generating them in the kernel from pose + pixel index")
@@ -137,16 +143,20 @@ def main():
     focal = float(scene["focal"])
     N, H, W, _ = images.shape
 
-    torch.manual_seed(0)                                   # identical initial weights on every rank
     encoder = PositionalEncoding(L_FREQS, True).to(dev)
-    model = nerf_mod.TinyNeRF(encoder.out_dim, HIDDEN, DEPTH, SKIP).to(dev)
-    with torch.no_grad():
-        # nn.Linear's default init leaves the sigma head at exactly 0 after its ReLU for this 8x256 model
-        # (SURVEY.md §7-7): every weight and every gradient would be a zero and the MFMA kernels would be
-        # timed on zeros (which clock higher).  Nudge the bias so the network is alive, as the fixtures do.
-        model.sigma[0].bias += 0.5
-    opt = trainer.FlatAdam(model, lr=LR)
-    tr = trainer.FusedTrainer(model, opt, NEAR, FAR, SAMPLES)
+
+    def make_trainer(precision):
+        torch.manual_seed(0)                               # identical initial weights on every rank (and in both modes)
+        mdl = nerf_mod.TinyNeRF(encoder.out_dim, HIDDEN, DEPTH, SKIP).to(dev)
+        with torch.no_grad():
+            # nn.Linear's default init leaves the sigma head at exactly 0 after its ReLU for this 8x256 model
+            # (SURVEY.md §7-7): every weight and every gradient would be a zero and the MFMA kernels would be
+            # timed on zeros (which clock higher).  Nudge the bias so the network is alive, as the fixtures do.
+            mdl.sigma[0].bias += 0.5
+        op = trainer.FlatAdam(mdl, lr=LR)
+        return mdl, op, trainer.FusedTrainer(mdl, op, NEAR, FAR, SAMPLES, precision=precision)
+
+    model, opt, tr = make_trainer("fp32")
 
     import rays as rays_mod
     all_o, all_d = [], []
@@ -157,8 +167,10 @@ def main():
     pixels = images.view(N, H * W, 3)
     gen = torch.Generator(device=dev); gen.manual_seed(1234)          # same draws on every rank; rank takes its shard
     state = {"step": 0}
+    run = {"tr": tr}
 
     def one_step():
+        tr = run["tr"]
         s = state["step"]; state["step"] += 1
         img_i = s % N
         inds = torch.randint(0, H * W, (world * RAYS,), device=dev, generator=gen)[rank * RAYS:(rank + 1) * RAYS]
@@ -257,6 +269,81 @@ def main():
             img = train_mod.render_one(model, encoder, H, W, focal, poses[N - 1], dev, n_samples=SAMPLES, near=NEAR, far=FAR)
             full = float(mse2psnr(torch.mean((img - images[N - 1]) ** 2)))
             out["psnr"] = {"train_minibatch_db": mb, "full_image_view105_db": full, "after_steps": state["step"]}
+
+    # ---- bf16 mode (BASELINE.json configs[3]): same initial weights, same pixel / jitter stream, same step counts
+    if not args.no_bf16:
+        model16, opt16, tr16 = make_trainer("bf16")
+        run["tr"] = tr16
+        gen.manual_seed(1234); state["step"] = 0
+        for _ in range(args.warmup):
+            one_step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            one_step()
+        fence()
+        dt16 = time.perf_counter() - t0
+        if use_dist:
+            t = torch.tensor([dt16], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt16 = float(t.item())
+        b16 = {"dtype": "bf16 operands, fp32 accumulate / compositing / master weights", "ms_per_step": dt16 / args.steps * 1e3,
+               "value": world * RAYS * args.steps / dt16, "unit": "rays/s", "speedup_vs_fp32_step": dt / dt16}
+        if rank == 0:
+            import ctypes as C
+            st = model16.hip_state(); b = st.repack_bf16(); bp = b.train_plan(RAYS, SAMPLES)
+            inds = torch.randint(0, H * W, (RAYS,), device=dev, generator=gen)
+            ro, rd = all_o[0, inds].contiguous(), all_d[0, inds].contiguous()
+            u = torch.rand(RAYS, SAMPLES, device=dev, generator=gen)
+            ztab = ops.depth_table(NEAR, FAR, SAMPLES, dev)
+            comp = torch.empty(RAYS, 3, device=dev); gws = torch.full((RAYS, 3), 1e-4, device=dev)
+            dep = torch.empty(RAYS, 1, device=dev); acc_ = torch.empty(RAYS, 1, device=dev)
+            sp = torch.cuda.current_stream(dev).cuda_stream
+            common = (C.byref(st.desc), b.packed.data_ptr(), ro.data_ptr(), rd.data_ptr(), RAYS, SAMPLES, ztab.data_ptr(), 1, u.data_ptr(), 0, 0, 1)
+            calls = {
+                "render_fwd": lambda: lib.call("tnerf_render_fused_bf16", *common, comp.data_ptr(), dep.data_ptr(), acc_.data_ptr(), sp),
+                "train_fwd": lambda: lib.call("tnerf_train_fwd_fused_bf16", *common, comp.data_ptr(), bp.stash.data_ptr(), sp),
+                "dgrad": lambda: lib.call("tnerf_train_dgrad_fused_bf16", *common, gws.data_ptr(), bp.stash.data_ptr(), sp),
+                "wgrad": lambda: lib.call("tnerf_wgrad_bf16", C.byref(st.desc), bp.stash.data_ptr(), bp.n_tiles, bp.jobs.data_ptr(), bp.n_jobs, bp.slabs.data_ptr(), sp),
+            }
+            fl = algorithmic_flops()
+            # algorithmic HBM bytes of the stash streams: bf16 activations / activation gradients
+            m = RAYS * SAMPLES
+            x_bytes = m * (64 + DEPTH * HIDDEN) * 2; dz_bytes = m * (DEPTH * HIDDEN + 32) * 2
+            hbm = {"train_fwd": x_bytes, "dgrad": dz_bytes, "wgrad": x_bytes + dz_bytes + m * ((DEPTH - 1) * HIDDEN) * 0}
+            kern16 = {}
+            for name, fn in calls.items():
+                fn(); torch.cuda.synchronize()
+                evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
+                for a_, b_ in evs:
+                    a_.record(); fn(); b_.record()
+                torch.cuda.synchronize()
+                ms = float(np.mean([a_.elapsed_time(b_) for a_, b_ in evs]))
+                kern16[name] = {"ms": ms, "tflops": fl[name] / (ms * 1e-3) / 1e12,
+                                "mfma_frac": fl[name] / (ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS}
+                if name in hbm:
+                    kern16[name]["stash_gbs"] = hbm[name] / (ms * 1e-3) / 1e9
+                    kern16[name]["hbm_frac"] = hbm[name] / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS
+            b16["kernels"] = kern16
+        if args.psnr_steps > 0:
+            losses = []
+            for i in range(args.psnr_steps):
+                loss, _ = one_step()
+                if i >= args.psnr_steps - 20:
+                    losses.append(loss.clone())
+            if rank == 0:
+                mb = float(mse2psnr(torch.stack(losses).mean() * world))
+                img = train_mod.render_one(model16, encoder, H, W, focal, poses[N - 1], dev, n_samples=SAMPLES, near=NEAR, far=FAR)
+                full = float(mse2psnr(torch.mean((img - images[N - 1]) ** 2)))
+                st16 = model16._ensure_packed()
+                img16 = ops.render_camera_fused_bf16(st16, poses[N - 1], H, W, focal, 0, H * W, NEAR, FAR, SAMPLES)[0].reshape(H, W, 3).clamp(0, 1)
+                b16["psnr"] = {"train_minibatch_db": mb, "full_image_view105_db": full, "after_steps": state["step"],
+                               "full_image_rendered_in_bf16_db": float(mse2psnr(torch.mean((img16 - images[N - 1]) ** 2))),
+                               "max_abs_rgb_bf16_vs_fp32_render": float((img16 - img).abs().max())}
+                if "psnr" in out:
+                    b16["psnr"]["delta_full_image_db_vs_fp32"] = full - out["psnr"]["full_image_view105_db"]
+        out["bf16"] = b16
+        run["tr"] = tr
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(scene)
