@@ -52,6 +52,7 @@ class Config:
     depth: int = 4
     skip_at: int = 2
     data_path: str = "data/tiny_nerf_data.npz"
+    precision: str = "fp32"     # "bf16": bf16 weights/activations on MFMA, fp32 accumulate/compositing/master weights (fused only)
 
 
 def write_png(path: str, img_u8: np.ndarray) -> None:
@@ -75,16 +76,22 @@ def _fusable(model, encoder) -> bool:
 @torch.no_grad()
 def render_one(model: nn.Module, encoder: nn.Module, H: int, W: int, focal: float, pose: torch.Tensor,
                device: torch.device, n_samples: int = 64, near: float = 2.0, far: float = 6.0,
-               chunk: int = 8192) -> torch.Tensor:
+               chunk: int = 8192, *, precision: str = "fp32") -> torch.Tensor:
     """Full image for one pose, chunked over rays, clamped to [0,1].   [reference src/train.py:36-59]
-    Each chunk is ONE fused kernel (pose in, colours out) when model/encoder are this package's."""
+    Each chunk is ONE fused kernel (pose in, colours out) when model/encoder are this package's.
+    precision="bf16" (keyword-only addition): the bf16-MFMA kernel of BASELINE cfg 4."""
     model.eval()
     parts = []
     fused = _fusable(model, encoder)
+    if precision not in ("fp32", "bf16") or (precision == "bf16" and not fused):
+        raise ValueError(f"render_one: precision={precision!r} needs this package's TinyNeRF + PositionalEncoding")
     if fused:      # rays are generated inside the fused kernel: no get_rays launch, no (HW,3) tables
         st, pose_d = model._ensure_packed(), pose.to(device)
+        render = ops.render_camera_fused_bf16 if precision == "bf16" else ops.render_camera_fused
+        key = tuple(p._version for p in model._param_list())
         for i in range(0, H * W, chunk):
-            comp, _, _ = ops.render_camera_fused(st, pose_d, H, W, focal, i, min(chunk, H * W - i), near, far, n_samples)
+            kw = dict(key=key) if precision == "bf16" else {}
+            comp, _, _ = render(st, pose_d, H, W, focal, i, min(chunk, H * W - i), near, far, n_samples, **kw)
             parts.append(comp)
         return torch.cat(parts, dim=0).reshape(H, W, 3).clamp(0.0, 1.0)
     rays_o, rays_d = get_rays(H, W, focal, pose.to(device), device=device)
@@ -141,8 +148,10 @@ def main(cfg: Config):
     model = TinyNeRF(in_dim=encoder.out_dim, hidden=cfg.hidden, depth=cfg.depth, skip_at=cfg.skip_at).to(device)
     if cfg.fused:
         optimizer = _trainer.FlatAdam(model, lr=cfg.lr)
-        step_fn = _trainer.FusedTrainer(model, optimizer, cfg.near, cfg.far, cfg.n_samples)
+        step_fn = _trainer.FusedTrainer(model, optimizer, cfg.near, cfg.far, cfg.n_samples, precision=cfg.precision)
     else:
+        if cfg.precision != "fp32":
+            raise SystemExit("--precision bf16 needs the fused step (--fused)")
         optimizer = torch.optim.Adam(model.parameters(), lr=cfg.lr)
 
     start_step = 0
