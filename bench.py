@@ -307,10 +307,18 @@ def main():
                 "wgrad": lambda: lib.call("tnerf_wgrad_bf16", C.byref(st.desc), bp.stash.data_ptr(), bp.n_tiles, bp.jobs.data_ptr(), bp.n_jobs, bp.slabs.data_ptr(), sp),
             }
             fl = algorithmic_flops()
-            # algorithmic HBM bytes of the stash streams: bf16 activations / activation gradients
-            m = RAYS * SAMPLES
-            x_bytes = m * (64 + DEPTH * HIDDEN) * 2; dz_bytes = m * (DEPTH * HIDDEN + 32) * 2
-            hbm = {"train_fwd": x_bytes, "dgrad": dz_bytes, "wgrad": x_bytes + dz_bytes + m * ((DEPTH - 1) * HIDDEN) * 0}
+            # algorithmic HBM bytes of the stash streams: 2 KB per (32-sample tile, 32-feature tile) of bf16
+            # activations / activation gradients; the forward also writes the ReLU bits and the head outputs
+            NT = HIDDEN // 32
+            tiles = RAYS * ((SAMPLES + 31) // 32)
+            wg_tiles = (NT + 2) + (DEPTH - 1) * 2 * NT + ((NT + 2) if SKIP else 0) + (1 + NT)     # sum over job classes of A + B feature tiles
+            hbm = {"train_fwd": tiles * ((2 + DEPTH * NT) * 2048 + DEPTH * (HIDDEN // 64) * 256 + 512),
+                   "dgrad": tiles * (DEPTH * NT + 1) * 2048,
+                   "wgrad": tiles * wg_tiles * 2048}
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic_bf16.json")))
+            except (OSError, ValueError):
+                pmc = {}
             kern16 = {}
             for name, fn in calls.items():
                 fn(); torch.cuda.synchronize()
@@ -322,9 +330,13 @@ def main():
                 kern16[name] = {"ms": ms, "tflops": fl[name] / (ms * 1e-3) / 1e12,
                                 "mfma_frac": fl[name] / (ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS}
                 if name in hbm:
-                    kern16[name]["stash_gbs"] = hbm[name] / (ms * 1e-3) / 1e9
+                    kern16[name]["algorithmic_hbm_bytes"] = hbm[name]
+                    kern16[name]["hbm_gbs"] = hbm[name] / (ms * 1e-3) / 1e9
                     kern16[name]["hbm_frac"] = hbm[name] / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS
+                    kern16[name]["traffic"] = pmc.get(name, {}).get("hbm_bytes")
             b16["kernels"] = kern16
+            b16["roofline"] = {"bound": "hbm", "kernel": "wgrad", "achieved": kern16["wgrad"]["hbm_gbs"], "peak": PEAK_HBM_GBS,
+                               "unit": "GB/s", "frac": kern16["wgrad"]["hbm_frac"], "traffic": kern16["wgrad"]["traffic"]}
         if args.psnr_steps > 0:
             losses = []
             for i in range(args.psnr_steps):
