@@ -194,10 +194,10 @@ int tn16_launch_dgrad(const Fwd16Args& a, hipStream_t stream, const char* who) {
     const dim3 grid((unsigned)(groups < n_cu ? groups : n_cu)), block(512);
     const size_t lds_bytes = TN16_SEL_OFF(a.n.n_bias) + 2048;
     if (a.n.hidden == 256) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dgrad16<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        { static size_t set_ = 0; if (set_ < lds_bytes) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dgrad16<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); set_ = lds_bytes; } }
         hipLaunchKernelGGL((k_dgrad16<256>), grid, block, lds_bytes, stream, a);
     } else {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dgrad16<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        { static size_t set_ = 0; if (set_ < lds_bytes) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dgrad16<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); set_ = lds_bytes; } }
         hipLaunchKernelGGL((k_dgrad16<128>), grid, block, lds_bytes, stream, a);
     }
     TN_HIP_CHECK_LAUNCH(who);
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad16(Wgrad16Args a) {
 int tn16_launch_wgrad(const Net16& n, const unsigned char* stash, const int32_t* jobs, int64_t n_jobs, float* slabs, hipStream_t stream) {
     Wgrad16Args a{stash, jobs, slabs, n.n_ft};
     const size_t lds_bytes = TN16W_NS * TN16W_SLOT;
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad16), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    { static size_t set_ = 0; if (set_ < lds_bytes) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad16), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); set_ = lds_bytes; } }
     hipLaunchKernelGGL(k_wgrad16, dim3((unsigned)n_jobs), dim3(512), lds_bytes, stream, a);
     TN_HIP_CHECK_LAUNCH("tnerf_wgrad_bf16");
     return TNERF_OK;

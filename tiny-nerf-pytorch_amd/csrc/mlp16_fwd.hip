@@ -130,7 +130,7 @@ int tn16_launch_fwd(const Fwd16Args& a, bool train, hipStream_t stream, const ch
     const size_t lds_bytes = TN16_SEL_OFF(a.n.n_bias) + 2048;
 #define TN16_CASE(H_, T_)                                                                                                        \
     if (a.n.hidden == H_ && train == T_) {                                                                                        \
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_render16<H_, T_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
+        { static size_t set_ = 0; if (set_ < lds_bytes) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_render16<H_, T_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); set_ = lds_bytes; } } \
         hipLaunchKernelGGL((k_render16<H_, T_>), grid, block, lds_bytes, stream, a);                                              \
         TN_HIP_CHECK_LAUNCH(who);                                                                                                 \
         return TNERF_OK;                                                                                                          \
