@@ -160,13 +160,9 @@ __device__ __forceinline__ void tn16_stash_tile(const unsigned char* lds, uint32
         p1[i] = __builtin_amdgcn_perm(__float_as_uint(h1), __float_as_uint(l1), 0x07060302u);
     }
     unsigned char* dst = st.frag + (int64_t)ft * TN16_FT_BYTES;       // uniform
-#ifndef TN16_DBG_NO_STASH_STORES            // diagnostic builds only: time the kernels without the stash traffic
     // non-temporal: 1.1 GB per kernel that nothing re-reads before the weight-gradient kernel (measured: -12 % step time)
     __builtin_nontemporal_store(p0, reinterpret_cast<u32x4*>(dst + lane16));
     __builtin_nontemporal_store(p1, reinterpret_cast<u32x4*>(dst + 1024 + lane16));
-#else
-    if (p0[0] == 0x12345678u && p1[3] == 0x9abcdef0u) *reinterpret_cast<u32x4*>(dst + lane16) = p0;
-#endif
 }
 
 // 16 ReLU sign bits of an n-tile from its packed outputs (dword q of lo|hi = registers 2q, 2q+1): bit r <-> register r.
