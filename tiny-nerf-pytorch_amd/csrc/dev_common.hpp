@@ -142,6 +142,17 @@ __device__ __forceinline__ const float* tn_stash_at(const float* stash, int64_t 
     return stash + ((m >> 5) * rows) * 32 + (m & 31);
 }
 
+// ---------------------------------------------------------------------------------------- LDS-DMA
+// global_load_lds_dwordx4: 64 lanes x 16 B from (wave-uniform base + per-lane 32-bit offset) straight into LDS at
+// lds_dst + lane * 16 (wave-uniform destination, lane-linear image), no VGPR round trip.  Issued from inline asm: hipcc
+// neither counts it in its s_waitcnt bookkeeping nor drains it at barriers — the caller waits with a counted vmcnt and
+// publishes with a barrier.  M0 (the DMA's LDS base) is compiler-reserved: saved and restored around the load.
+__device__ __forceinline__ void tn_glds16(const void* src, uint32_t voff, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(src), "s"(lds_dst) : "memory");
+}
+
 // ------------------------------------------------------------------------------------- ray source
 // Where a fused kernel gets ray r from:
 //   tables : rays_o / rays_d [n,3] (what get_rays precomputed, reference src/train.py:94-101), row = index ? index[r] : r

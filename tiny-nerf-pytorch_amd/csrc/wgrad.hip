@@ -6,8 +6,8 @@
 // (8 waves, two per SIMD) owns one (A rows x B rows) block of up to 256x256 outputs for one chunk
 // of samples: the 8 waves split it 4x2 / 8x1 / 1x8 (<= 2x4 tiles of 32x32 = 128 accumulator
 // registers per wave).  Per 32-sample step the workgroup stages [rows][32] of A and B through LDS
-// in whole 128-byte lines (global -> registers -> LDS, next block in flight during the MFMAs),
-// XOR-swizzled so that the ds_read_b128 fragment reads are bank-conflict free.  Each workgroup
+// in whole 128-byte lines by LDS-DMA (global_load_lds_dwordx4, no VGPR round trip, the next block in flight during
+// the MFMAs), XOR-swizzled — on the source address — so that the ds_read_b128 fragment reads are bank-conflict free.  Each workgroup
 // writes its partial block to its own slab; a gather-reduce kernel sums the slabs in a fixed
 // order into the flat gradient (deterministic: no float atomics).
 #include "mlp_core.hpp"
@@ -31,8 +31,6 @@ __device__ __forceinline__ void wgrad_body(const float* __restrict__ stash, int6
     const int wa = wave % WA, wb = wave / WA;
     const int a_t0 = wa * TA, b_t0 = wb * TB;                  // first tile of this wave
     const int rows_a = n_at * 32, rows_b = n_bt * 32, rows = rows_a + rows_b;
-    constexpr int MAXLD = (2 * WG_LDS_ROWS) / 64;              // 8 row-groups of 64 rows (512 threads x 16 B = 64 lines)
-
     f32x16 acc[TA][TB];
 #pragma unroll
     for (int i = 0; i < TA; ++i)
@@ -44,45 +42,51 @@ __device__ __forceinline__ void wgrad_body(const float* __restrict__ stash, int6
 #pragma unroll
     for (int i = 0; i < TA; ++i) bsum[i] = 0.0f;
 
-    // staging: thread -> (row within a 64-row group = tid>>3, 16-byte chunk = tid&7).  Rows that do not exist
-    // (head: 4 of 32, enc: 40 of 64) are clamped to a valid row for the load and zeroed when the block is written
-    // to LDS, so the loads are unconditional and all stay in flight behind the MFMAs.
-    const int srow = tid >> 3, schunk = tid & 7;
-    const int ngroups = (rows + 63) / 64;
-    f32x4 stage[MAXLD];
-    auto stage_load = [&](int blk) TN_INLINE_LAMBDA {
-        const float* blkbase = stash + (int64_t)blk * stash_rows * 32 + schunk * 4;
-        tn_static_for<MAXLD>([&](auto gc) TN_INLINE_LAMBDA {
-            constexpr int g = decltype(gc)::value;
-            if (g < ngroups) {                                                // wave-uniform
-                const int row = g * 64 + srow;                                // combined A|B row (A and B never share a wave: 32 | rows_a)
-                const bool isA = row < rows_a;
-                const int lr = isA ? row : row - rows_a;
-                const int lim = (isA ? a_rows : b_rows) - 1;
-                stage[g] = *reinterpret_cast<const f32x4*>(blkbase + ((isA ? a_row0 : b_row0) + (lr < lim ? lr : lim)) * 32);
-            }
+    // Staging by LDS-DMA: the rows [A | B] of a block are cut into pieces of 8 rows (1 KB of LDS = one wave-wide
+    // global_load_lds_dwordx4); wave w moves pieces w, w+8, ...  Lane l of a piece fills row (l>>3), chunk position l&7,
+    // i.e. it fetches source chunk (l&7) ^ ((row>>1)&7) of that row: the XOR swizzle is applied on the source address,
+    // the LDS image stays lane-linear.  Rows that do not exist (head: 4 of 32, enc: 40 of 64) are clamped to a valid
+    // row: they only feed slab rows / columns that the reduce table never references.
+    const uint32_t lds0 = (uint32_t)(uintptr_t)lds;
+    constexpr int MAXP = (2 * WG_LDS_ROWS) / 64;               // pieces per wave
+    const int npieces = rows / 8;
+    uint32_t voff[MAXP], pdst[MAXP];
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i) {
+        const int pc = wave + 8 * i;
+        const int cr = 8 * pc + (lane >> 3);                    // combined row
+        const bool isA = cr < rows_a;
+        const int lr = isA ? cr : cr - rows_a;
+        const int lim = (isA ? a_rows : b_rows) - 1;
+        const int srow_ = (int)(isA ? a_row0 : b_row0) + (lr < lim ? lr : lim);
+        voff[i] = (uint32_t)srow_ * 128u + (uint32_t)(((lane & 7) ^ ((lr >> 1) & 7)) << 4);
+        const int lr0 = (8 * pc < rows_a) ? 8 * pc : 8 * pc - rows_a;       // first row of the piece (wave-uniform)
+        pdst[i] = ((8 * pc < rows_a) ? 0u : (uint32_t)(WG_LDS_ROWS * 128)) + (uint32_t)lr0 * 128u;
+    }
+    auto stage_dma = [&](int blk, int buf) TN_INLINE_LAMBDA {
+        const float* blkbase = stash + (int64_t)blk * stash_rows * 32;
+        const uint32_t slot = lds0 + (uint32_t)buf * (2 * WG_LDS_ROWS * 128);
+        tn_static_for<MAXP>([&](auto ic) TN_INLINE_LAMBDA {
+            constexpr int i = decltype(ic)::value;
+            if (wave + 8 * i < npieces) tn_glds16(blkbase, voff[i], slot + __builtin_amdgcn_readfirstlane(pdst[i]));   // wave-uniform
         });
     };
-    auto stage_store = [&](int blk, int buf) TN_INLINE_LAMBDA {
+    // The last block of the batch may hold fewer than 32 samples: the slots behind M were never written by the
+    // forward / dgrad kernels.  Each lane clears them in the 16 bytes it has just DMA'd (after its own vmcnt wait).
+    auto clear_tail = [&](int blk, int buf) TN_INLINE_LAMBDA {
+        const int nvalid = (int)(M - (int64_t)blk * 32);         // 1..31 here
         float* base = lds + buf * (2 * WG_LDS_ROWS * 32);
-        const int64_t m0 = (int64_t)blk * 32 + schunk * 4;
-        const bool tail = (int64_t)blk * 32 + 32 > M;                        // wave-uniform: only the last block can be ragged
-        const int nvalid = (int)((M - m0) < 0 ? 0 : ((M - m0) > 4 ? 4 : (M - m0)));
-        tn_static_for<MAXLD>([&](auto gc) TN_INLINE_LAMBDA {
-            constexpr int g = decltype(gc)::value;
-            if (g < ngroups) {
-                const int row = g * 64 + srow;
-                if (row < rows) {
-                    const bool isA = row < rows_a;
-                    const int lr = isA ? row : row - rows_a;
-                    f32x4 v = stage[g];
-                    if (lr >= (isA ? a_rows : b_rows)) v = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (tail) {
-                        v[0] = nvalid > 0 ? v[0] : 0.f; v[1] = nvalid > 1 ? v[1] : 0.f;
-                        v[2] = nvalid > 2 ? v[2] : 0.f; v[3] = nvalid > 3 ? v[3] : 0.f;
-                    }
-                    *reinterpret_cast<f32x4*>(base + (isA ? 0 : WG_LDS_ROWS * 32) + wg_lds_off(lr, schunk)) = v;
-                }
+        tn_static_for<MAXP>([&](auto ic) TN_INLINE_LAMBDA {
+            constexpr int i = decltype(ic)::value;
+            if (wave + 8 * i < npieces) {
+                const int pc = wave + 8 * i, cr = 8 * pc + (lane >> 3);
+                const int lr = cr < rows_a ? cr : cr - rows_a;
+                const int s0 = (((lane & 7) ^ ((lr >> 1) & 7)) << 2);           // first sample of this lane's chunk
+                f32x4* q = reinterpret_cast<f32x4*>(base + (__builtin_amdgcn_readfirstlane(pdst[i]) >> 2) + lane * 4);
+                f32x4 v = *q;
+                v[0] = s0 + 0 < nvalid ? v[0] : 0.f; v[1] = s0 + 1 < nvalid ? v[1] : 0.f;
+                v[2] = s0 + 2 < nvalid ? v[2] : 0.f; v[3] = s0 + 3 < nvalid ? v[3] : 0.f;
+                *q = v;
             }
         });
     };
@@ -90,12 +94,15 @@ __device__ __forceinline__ void wgrad_body(const float* __restrict__ stash, int6
     const int frow = lane & 31, fh = lane >> 5;
     const bool active = (a_t0 < n_at) && (b_t0 < n_bt);
     const bool do_bias = job[JOB_HAS_BIAS] && wb == 0;
+    auto is_tail = [&](int blk) TN_INLINE_LAMBDA { return (int64_t)blk * 32 + 32 > M; };          // wave-uniform
 
-    if (nblk > 0) { stage_load(blk0); stage_store(blk0, 0); }
-    __syncthreads();
+    // two LDS slots: block b is read from slot b&1 while block b+1 lands in the other one
+    if (nblk > 0) stage_dma(blk0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (nblk > 0 && is_tail(blk0)) { clear_tail(blk0, 0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+    __builtin_amdgcn_s_barrier();
+    if (nblk > 1) stage_dma(blk0 + 1, 1);
     for (int b = 0; b < nblk; ++b) {
-        const bool more = b + 1 < nblk;
-        if (more) stage_load(blk0 + b + 1);
         if (active) {
             const float* A = lds + (b & 1) * (2 * WG_LDS_ROWS * 32);
             const float* B = A + WG_LDS_ROWS * 32;
@@ -119,8 +126,12 @@ __device__ __forceinline__ void wgrad_body(const float* __restrict__ stash, int6
                         for (int j = 0; j < TB; ++j) acc[i][j] = TN_MFMA(fa[i][p], fb[j][p], acc[i][j]);
             }
         }
-        if (more) stage_store(blk0 + b + 1, (b + 1) & 1);
-        __syncthreads();
+        // this wave's share of block b+1 has landed (issued one block ago); after the barrier everybody's has, and
+        // everybody is done reading slot b&1, which block b+2 may now overwrite
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (b + 1 < nblk && is_tail(blk0 + b + 1)) { clear_tail(blk0 + b + 1, (b + 1) & 1); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+        __builtin_amdgcn_s_barrier();
+        if (b + 2 < nblk) stage_dma(blk0 + b + 2, b & 1);
     }
 
     // epilogue: partial block -> this workgroup's slab  [n_at*32][n_bt*32] then bias [n_at*32]
