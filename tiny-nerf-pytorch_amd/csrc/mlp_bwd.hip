@@ -51,7 +51,7 @@ __device__ __forceinline__ void tn_bwd_tile(const BwdArgs& a, const float (&dzh)
                 constexpr int r = decltype(rc)::value;
                 const float v = ((mb[t / 2] >> ((t & 1) * 16 + r)) & 1u) ? acc[r] : 0.0f;   // ReLU backward: output > 0
                 dz[t * 16 + r] = v;
-                zrow[(32 * t + (r & 3) + 8 * (r >> 2)) * 32] = v;
+                TN_STASH_STORE(&zrow[(32 * t + (r & 3) + 8 * (r >> 2)) * 32], v);
             });
         });
     }
@@ -66,7 +66,7 @@ __device__ __forceinline__ void tn_bwd_tile(const BwdArgs& a, const float (&dzh)
                 constexpr int r = decltype(rc)::value;
                 const float v = ((mb[t / 2] >> ((t & 1) * 16 + r)) & 1u) ? acc[r] : 0.0f;
                 dznext[t * 16 + r] = v;
-                zrow[(32 * t + (r & 3) + 8 * (r >> 2)) * 32] = v;
+                TN_STASH_STORE(&zrow[(32 * t + (r & 3) + 8 * (r >> 2)) * 32], v);
             });
         });
         tn_static_for<HID / 2>([&](auto ic) TN_INLINE_LAMBDA { dz[decltype(ic)::value] = dznext[decltype(ic)::value]; });

@@ -20,6 +20,12 @@
 #ifndef TN_PFDIST
 #define TN_PFDIST 6
 #endif
+// The training stash (2.2 GB per kernel at cfg 2) is written once and read once, by the next kernel but one.
+#ifdef TN_STASH_TEMPORAL
+#define TN_STASH_STORE(ptr, v) (*(ptr) = (v))
+#else
+#define TN_STASH_STORE(ptr, v) __builtin_nontemporal_store((v), (ptr))
+#endif
 #define TN_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
 // Compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>).  The hot loops

@@ -37,7 +37,7 @@ __device__ __forceinline__ void tn_mlp_tile(const FwdArgs& a, const float (&enc)
     if (TRAIN) {
         tn_static_for<NE>([&](auto sc_) TN_INLINE_LAMBDA {
             constexpr int st = decltype(sc_)::value;
-            pl[(L.enc_row0 + 2 * st - 3 * h) * 32] = enc[st];          // row enc_row0 + 2 st + h
+            TN_STASH_STORE(&pl[(L.enc_row0 + 2 * st - 3 * h) * 32], enc[st]);          // row enc_row0 + 2 st + h
         });
     }
 
@@ -59,7 +59,7 @@ __device__ __forceinline__ void tn_mlp_tile(const FwdArgs& a, const float (&enc)
                     const float v = fmaxf(acc[r], 0.0f);
                     hcur[t * 16 + r] = v;
                     if (TRAIN) mb[t / 2] |= (v > 0.0f) ? (1u << ((t & 1) * 16 + r)) : 0u;
-                    if (TRAIN) srow[(32 * t + (r & 3) + 8 * (r >> 2)) * 32] = v;
+                    if (TRAIN) TN_STASH_STORE(&srow[(32 * t + (r & 3) + 8 * (r >> 2)) * 32], v);
                 });
             });
         if (TRAIN) {
@@ -79,7 +79,7 @@ __device__ __forceinline__ void tn_mlp_tile(const FwdArgs& a, const float (&enc)
                 const float v = fmaxf(acc[r], 0.0f);
                 hnext[t * 16 + r] = v;
                 if (TRAIN) mb[t / 2] |= (v > 0.0f) ? (1u << ((t & 1) * 16 + r)) : 0u;
-                if (TRAIN) srow[(32 * t + (r & 3) + 8 * (r >> 2)) * 32] = v;
+                if (TRAIN) TN_STASH_STORE(&srow[(32 * t + (r & 3) + 8 * (r >> 2)) * 32], v);
             });
         };
         if (l == L.skip_at) tn_layer<HID, NE, true, true>(wrsrc, L.fw_bias[l], L.fw_enc[l], L.fw_hid[l], hcur, enc, lane, fin);

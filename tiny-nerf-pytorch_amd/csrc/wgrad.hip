@@ -106,7 +106,7 @@ __device__ __forceinline__ void wgrad_body(const float* __restrict__ stash, int6
         if (active) {
             const float* A = lds + (b & 1) * (2 * WG_LDS_ROWS * 32);
             const float* B = A + WG_LDS_ROWS * 32;
-#pragma unroll 1
+#pragma unroll 2
             for (int q = 0; q < 4; ++q) {
                 f32x4 fa[TA], fb[TB];
 #pragma unroll
