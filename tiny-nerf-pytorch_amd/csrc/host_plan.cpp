@@ -209,9 +209,9 @@ static int build_classes(const MlpLayout& L, int64_t M, int n_cu, std::vector<Jo
         int best = -1; double best_t = 0.0;
         for (size_t i = 0; i < cls.size(); ++i) {
             if (cls[i].chunks >= MB) continue;
-            // cycles per 32-sample block: 64 per MFMA step (16 steps per tile) + a fixed cost for staging the block
-            // through LDS and the barrier (measured ~3k cycles; it dominates the small enc / head classes)
-            const double t = ((double)cls[i].cost * 2210.0 + 1980.0) * (double)((MB + cls[i].chunks - 1) / cls[i].chunks);   // measured (tools/wgrad_probe.py): 19.7k / 6.4k / 4.3k cycles per block for 8 / 2 / 1 tiles per wave
+            // cycles per 32-sample block, measured (tools/wgrad_probe.py, LDS-DMA staging): 17.86k / 5.2k / 3.2k for
+            // 8 / 2 / 1 tiles per wave, i.e. ~2107 per tile (16 MFMA steps of 64 cycles, two waves per SIMD) + ~1000 fixed
+            const double t = ((double)cls[i].cost * 2107.0 + 1000.0) * (double)((MB + cls[i].chunks - 1) / cls[i].chunks);
             if (t > best_t) { best_t = t; best = (int)i; }
         }
         if (best < 0) break;
