@@ -49,7 +49,8 @@ __device__ __forceinline__ void tn_bwd_tile(const BwdArgs& a, const float (&dzh)
             acc = TN_MFMA(a4[2], b2, acc); acc = TN_MFMA(a4[3], b3, acc);
             tn_static_for<16>([&](auto rc) TN_INLINE_LAMBDA {
                 constexpr int r = decltype(rc)::value;
-                const float v = ((mb[t / 2] >> ((t & 1) * 16 + r)) & 1u) ? acc[r] : 0.0f;   // ReLU backward: output > 0
+                const float a_ = acc[r];                                                      // ReLU backward: output > 0
+                const float v = __int_as_float(__float_as_int(a_) & __builtin_amdgcn_sbfe((int)mb[t / 2], (t & 1) * 16 + r, 1));
                 dz[t * 16 + r] = v;
                 TN_STASH_STORE(&zrow[(32 * t + (r & 3) + 8 * (r >> 2)) * 32], v);
             });
@@ -64,7 +65,8 @@ __device__ __forceinline__ void tn_bwd_tile(const BwdArgs& a, const float (&dzh)
             constexpr int t = decltype(tc)::value;
             tn_static_for<16>([&](auto rc) TN_INLINE_LAMBDA {
                 constexpr int r = decltype(rc)::value;
-                const float v = ((mb[t / 2] >> ((t & 1) * 16 + r)) & 1u) ? acc[r] : 0.0f;
+                const float a_ = acc[r];
+                const float v = __int_as_float(__float_as_int(a_) & __builtin_amdgcn_sbfe((int)mb[t / 2], (t & 1) * 16 + r, 1));
                 dznext[t * 16 + r] = v;
                 TN_STASH_STORE(&zrow[(32 * t + (r & 3) + 8 * (r >> 2)) * 32], v);
             });

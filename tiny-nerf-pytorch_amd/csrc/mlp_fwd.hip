@@ -19,6 +19,17 @@
 #define TN_STAMP(k) do {} while (0)
 #endif
 
+// 16 ReLU sign bits (bit r <-> v[r] > 0) of an n-tile's non-negative outputs, merged into the low (ODD = 0) or high half
+// of a mask word.  v >= 0, so v's bit pattern + 0x7FFFFFFF carries into bit 31 exactly when v != 0; alignbit shifts
+// that bit into the word: 2 VALU per value instead of compare + select + or.
+template <int ODD>
+__device__ __forceinline__ uint32_t tn_sign_bits16(uint32_t word, const float* v) {
+    uint32_t m = 0u;
+#pragma unroll
+    for (int r = 15; r >= 0; --r) m = __builtin_amdgcn_alignbit(m, __float_as_uint(v[r]) + 0x7FFFFFFFu, 31);
+    return ODD ? (word | (m << 16)) : m;
+}
+
 // The MLP for one 32-sample tile.  enc: network input registers.  m: this lane's sample index in the
 // stash / output (valid if `valid`).  Returns the 4 head outputs (r,g,b after sigmoid; sigma after
 // ReLU) in out4 — meaningful on lane-half 0 only.
@@ -53,14 +64,13 @@ __device__ __forceinline__ void tn_mlp_tile(const FwdArgs& a, const float (&enc)
         tn_layer<HID, NE, false, true>(wrsrc, L.fw_bias[0], L.fw_enc[0], 0, hnext, enc, lane,
             [&](auto tc, const f32x16& acc) TN_INLINE_LAMBDA {
                 constexpr int t = decltype(tc)::value;
-                if (TRAIN && (t & 1) == 0) mb[t / 2] = 0u;
                 tn_static_for<16>([&](auto rc) TN_INLINE_LAMBDA {
                     constexpr int r = decltype(rc)::value;
                     const float v = fmaxf(acc[r], 0.0f);
                     hcur[t * 16 + r] = v;
-                    if (TRAIN) mb[t / 2] |= (v > 0.0f) ? (1u << ((t & 1) * 16 + r)) : 0u;
                     if (TRAIN) TN_STASH_STORE(&srow[(32 * t + (r & 3) + 8 * (r >> 2)) * 32], v);
                 });
+                if (TRAIN) mb[t / 2] = tn_sign_bits16<t & 1>(mb[t / 2], &hcur[t * 16]);
             });
         if (TRAIN) {
 #pragma unroll
@@ -73,14 +83,13 @@ __device__ __forceinline__ void tn_mlp_tile(const FwdArgs& a, const float (&enc)
         float* __restrict__ srow = TRAIN ? pl + L.h_row0[l] * 32 : nullptr;
         auto fin = [&](auto tc, const f32x16& acc) TN_INLINE_LAMBDA {
             constexpr int t = decltype(tc)::value;
-            if (TRAIN && (t & 1) == 0) mb[t / 2] = 0u;
             tn_static_for<16>([&](auto rc) TN_INLINE_LAMBDA {
                 constexpr int r = decltype(rc)::value;
                 const float v = fmaxf(acc[r], 0.0f);
                 hnext[t * 16 + r] = v;
-                if (TRAIN) mb[t / 2] |= (v > 0.0f) ? (1u << ((t & 1) * 16 + r)) : 0u;
                 if (TRAIN) TN_STASH_STORE(&srow[(32 * t + (r & 3) + 8 * (r >> 2)) * 32], v);
             });
+            if (TRAIN) mb[t / 2] = tn_sign_bits16<t & 1>(mb[t / 2], &hnext[t * 16]);
         };
         if (l == L.skip_at) tn_layer<HID, NE, true, true>(wrsrc, L.fw_bias[l], L.fw_enc[l], L.fw_hid[l], hcur, enc, lane, fin);
         else                tn_layer<HID, NE, true, false>(wrsrc, L.fw_bias[l], 0, L.fw_hid[l], hcur, enc, lane, fin);
