@@ -11,10 +11,9 @@
 // (consumption order, 16 KB stages) flows HBM/L2 -> LDS ring (LDS-DMA, global_load_lds_dwordx4: no VGPR round trip)
 // -> ds_read_b128 (one per MFMA: half of the LDS bandwidth) -> MFMA.  The second wave of a SIMD fills the MFMA pipe
 // while the first does its encoder / epilogue / compositing arithmetic.
-// One raw s_barrier per stage publishes the stage after the one being consumed; three stages are in flight behind it,
-// tracked with a counted s_waitcnt vmcnt (the DMA is issued from inline asm so that hipcc neither drains it with
-// vmcnt(0) at the barrier nor serialises the ds_reads behind it).
-//
+// One raw s_barrier per stage publishes the stage after the one being consumed; TN16_LEAD more stages are in flight
+// behind it, tracked with a counted s_waitcnt vmcnt (the DMA is issued from inline asm — tn_glds16, dev_common.hpp —
+// so that hipcc neither drains it with vmcnt(0) at the barrier nor serialises the ds_reads behind it).
 #pragma once
 #include "mlp_core.hpp"
 
@@ -66,15 +65,11 @@ struct Pipe16 {
     uint32_t voff[2];            // lane * 16 + wave * 2048 + i * 1024
 };
 
-__device__ __forceinline__ void tn16_glds(const unsigned char* src, uint32_t voff, uint32_t lds_dst) { tn_glds16(src, voff, lds_dst); }
-// (a non-temporal variant of the DMA for the once-read training stash in the weight-gradient kernel measured 5 % slower)
-__device__ __forceinline__ void tn16_glds_nt(const unsigned char* src, uint32_t voff, uint32_t lds_dst) { tn_glds16(src, voff, lds_dst); }
-
 // DMA this wave's eighth (2 fragments) of the next stage of the stream into the next ring slot.
 __device__ __forceinline__ void tn16_issue_stage(Pipe16& p) {
     const unsigned char* s = p.src + p.src_off;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) tn16_glds(s, p.voff[i], p.lds_dst0 + p.dst_off + i * 1024);
+    for (int i = 0; i < 2; ++i) tn_glds16(s, p.voff[i], p.lds_dst0 + p.dst_off + i * 1024);
     p.src_off += TN16_SLOT; if (p.src_off == p.stream_bytes) p.src_off = 0;
     p.dst_off += TN16_SLOT; if (p.dst_off == TN16_RING) p.dst_off = 0;
 }
