@@ -24,7 +24,7 @@ __device__ __forceinline__ void tn16_layer_bwd(Pipe16& p, const unsigned char* l
         tn_static_for<KPT>([&](auto sc) TN_INLINE_LAMBDA {
             constexpr int s = decltype(sc)::value;
             constexpr int F = t * KPT + s;
-            if constexpr (F % (TN16_STAGE / 2) == 0) tn16_boundary<(F % TN16_STAGE) != 0, true>(p);
+            if constexpr (F % TN16_STAGE == 0) tn16_boundary<true>(p);
             const bf16x8 afrag = p.afr[F % TN16_PF];
             {
                 constexpr int o = (F % TN16_STAGE) + TN16_PF;

@@ -10,7 +10,7 @@
 // workgroup (two per SIMD, one 32-sample tile each, ~230 registers) share one copy of the weights: the fragment STREAM
 // (consumption order, 16 KB stages) flows HBM/L2 -> LDS ring (LDS-DMA, global_load_lds_dwordx4: no VGPR round trip)
 // -> ds_read_b128 (one per MFMA: half of the LDS bandwidth) -> MFMA.  The second wave of a SIMD fills the MFMA pipe
-// while the first does its encoder / epilogue / compositing arithmetic.
+// while the first does its encoder / epilogue / compositing arithmetic or waits at the barrier.
 // One raw s_barrier per stage publishes the stage after the one being consumed; TN16_LEAD more stages are in flight
 // behind it, tracked with a counted s_waitcnt vmcnt (the DMA is issued from inline asm — tn_glds16, dev_common.hpp —
 // so that hipcc neither drains it with vmcnt(0) at the barrier nor serialises the ds_reads behind it).
@@ -60,7 +60,6 @@ struct Pipe16 {
     const unsigned char* src;    // packed fragment stream
     uint32_t src_off, stream_bytes;
     uint32_t dst_off;            // ring offset of the slot the next DMA fills
-    bool lag;                    // waves 4..7: workgroup barriers are taken half a stage late
     uint32_t lds_dst0;           // absolute LDS address of ring + wave * 2048
     uint32_t voff[2];            // lane * 16 + wave * 2048 + i * 1024
 };
@@ -74,29 +73,25 @@ __device__ __forceinline__ void tn16_issue_stage(Pipe16& p) {
     p.dst_off += TN16_SLOT; if (p.dst_off == TN16_RING) p.dst_off = 0;
 }
 
-// Twice per stage.  The workgroup-wide step — wait for this wave's DMA of stage k+1 (stages k+2 .. k+LEAD stay in
-// flight), barrier (stage k+1 is now readable by everyone; the slot of stage k-1 is free), issue stage k+LEAD+1 — is taken by waves
-// 0..3 at the start of stage k and by waves 4..7 (p.lag) in the MIDDLE of stage k-1: the two waves of a SIMD thus run
-// half a stage (one n-tile of a 256-wide layer) out of phase, and one's epilogue / encoder / compositing arithmetic
-// overlaps the other's MFMAs instead of both leaving the pipe idle at the same time.
+// Start of stage k: wait for this wave's DMA of stage k+1 (stages k+2 .. k+LEAD stay in flight), barrier (stage k+1
+// is now readable by everyone; the slot of stage k-1 is free), issue stage k+LEAD+1.
 // STORES: the caller interleaves global stores (training stash) with the stream.  vmcnt retires in issue order and a
 // store stays counted until it reaches L2, so waiting for the DMA of stage k+1 also waits for every older store: the
 // DMA therefore runs TN16_LEAD stages ahead (its wait then only covers stores that are microseconds old), and the
 // wait leaves TN16_MIN_STORES more operations outstanding — fewer than the stores any LEAD consecutive stages of the
 // training kernels issue (>= 2 per n-tile).
-template <bool MID, bool STORES>
+// (Measured and dropped: waves 4..7 taking the barrier half a stage late so that the two waves of a SIMD run out of
+// phase — 2 % slower for inference, 6 % for dgrad.  Ablation of the inference kernel, 0.259 ms: barrier 0.020,
+// DMA issue + vmcnt wait 0.029.)
+template <bool STORES>
 __device__ __forceinline__ void tn16_boundary(Pipe16& p) {
-    if (p.lag == MID) {
-        if constexpr (STORES) TN16_WAIT_VM(2 * (TN16_LEAD - 1) + TN16_MIN_STORES);
-        else                  TN16_WAIT_VM(2 * (TN16_LEAD - 1));
-        __builtin_amdgcn_s_barrier();
-        tn16_issue_stage(p);
-    }
-    if constexpr (!MID) {
-        p.va_cur = p.va_nxt;
-        p.nxt_off += TN16_SLOT; if (p.nxt_off == TN16_RING) p.nxt_off = 0;
-        p.va_nxt = p.lane16 + p.nxt_off;
-    }
+    if constexpr (STORES) TN16_WAIT_VM(2 * (TN16_LEAD - 1) + TN16_MIN_STORES);
+    else                  TN16_WAIT_VM(2 * (TN16_LEAD - 1));
+    __builtin_amdgcn_s_barrier();
+    tn16_issue_stage(p);
+    p.va_cur = p.va_nxt;
+    p.nxt_off += TN16_SLOT; if (p.nxt_off == TN16_RING) p.nxt_off = 0;
+    p.va_nxt = p.lane16 + p.nxt_off;
 }
 
 // Where a training kernel puts the current tile's records (layout: tnerf_internal.h).
@@ -163,7 +158,7 @@ __device__ __forceinline__ unsigned tn16_sign_bits(const u32x4& lo, const u32x4&
 // One layer for the wave's 32-sample tile.
 //   KIND 0: first layer (input k-steps only)   1: hidden   2: skip layer (hidden + input k-steps)   3: heads
 // The epilogue of an n-tile (bias add in fp32, round to bf16, ReLU on the packed pair) follows its last MFMA; the MFMA
-// pipe is kept busy meanwhile by the SIMD's other wave, which runs half a stage out of phase (tn16_boundary).
+// pipe is kept busy meanwhile by the SIMD's other wave.
 // vb: per-lane LDS byte offset of this layer's biases (+ 16 h).  KIND 3 leaves the raw head accumulator in `acc`.
 // TRAIN: also stash the layer's output tiles (transposed, feature tiles ft0 + t) and its ReLU sign bits (layer l).
 template <int HID, int KIND, bool TRAIN = false>
@@ -181,7 +176,7 @@ __device__ __forceinline__ void tn16_layer(Pipe16& p, const unsigned char* lds, 
         tn_static_for<KPT>([&](auto sc) TN_INLINE_LAMBDA {
             constexpr int s = decltype(sc)::value;
             constexpr int F = t * KPT + s;
-            if constexpr (F % (TN16_STAGE / 2) == 0) tn16_boundary<(F % TN16_STAGE) != 0, TRAIN>(p);
+            if constexpr (F % TN16_STAGE == 0) tn16_boundary<TRAIN>(p);
             const bf16x8 afrag = p.afr[F % TN16_PF];
             {
                 constexpr int o = (F % TN16_STAGE) + TN16_PF;
@@ -285,7 +280,7 @@ __device__ __forceinline__ void tn16_prologue(Pipe16& p, unsigned char* lds, con
     }
     p.lane16 = lane * 16;
     p.src = src; p.src_off = 0; p.stream_bytes = (uint32_t)n_stage * TN16_SLOT;
-    p.dst_off = 0; p.lag = wave >= 4;
+    p.dst_off = 0;
     p.lds_dst0 = (uint32_t)(uintptr_t)lds + wave * 2048;
 #pragma unroll
     for (int i = 0; i < 2; ++i) p.voff[i] = lane * 16 + wave * 2048 + i * 1024;
