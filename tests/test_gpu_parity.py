@@ -712,3 +712,27 @@ def test_bf16_trainer_tracks_fp32_training(mods, dev):
     print("held-out PSNR after 300 steps:", out)
     assert out["fp32"] >= 15.0, out
     assert abs(out["fp32"] - out["bf16"]) <= 0.5, out
+
+
+@pytest.mark.parametrize("arch", [(15, 128, 1, 0), (39, 128, 2, 1), (63, 256, 3, 2), (27, 256, 5, 0)])
+def test_bf16_other_architectures(mods, dev, arch):
+    """Shallow / skip-less / L=2..10 networks through the bf16 render and train kernels (the weight stream is then only
+    a few stages long and wraps inside the DMA look-ahead)."""
+    in_dim, hidden, depth, skip = arch
+    cfg = dict(in_dim=in_dim, hidden=hidden, depth=depth, skip_at=skip, L=(in_dim - 3) // 6)
+    params = _lively_params(cfg, seed=5)
+    model = make_model(mods, cfg, params, dev)
+    st = model._ensure_packed()
+    g = torch.Generator().manual_seed(9)
+    R, S = 77, 40
+    d = torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=-1)
+    o = -4.0 * d + 0.2 * torch.randn(R, 3, generator=g)
+    tgt, t = torch.rand(R, 3, generator=g), torch.rand(R, S, generator=g)
+    want = O.render_rays_bf16(params, skip, cfg["L"], o, d, 2.0, 6.0, S, t_rand=t)[0]
+    got = mods["ops"].render_rays_fused_bf16(st, o.to(dev), d.to(dev), 2.0, 6.0, S, randomized=True, t_rand=t.to(dev))[0]
+    assert float((got.cpu() - want).abs().max()) <= 2e-3
+    l16, _, g16 = O.loss_and_grads_bf16(params, skip, cfg["L"], o, d, tgt, 2., 6., S, t)
+    loss, comp, flat = _bf16_step_grads(mods, dev, model, st, o.to(dev), d.to(dev), tgt.to(dev), t.to(dev), S)
+    w16 = torch.cat([x.reshape(-1) for x in g16])
+    assert abs(loss - float(l16)) <= 2e-3 * float(l16)
+    assert float((flat - w16).norm() / w16.norm()) <= 1e-2, arch
