@@ -63,13 +63,18 @@ __device__ __forceinline__ void wgrad_body(const float* __restrict__ stash, int6
         const int lr0 = (8 * pc < rows_a) ? 8 * pc : 8 * pc - rows_a;       // first row of the piece (wave-uniform)
         pdst[i] = ((8 * pc < rows_a) ? 0u : (uint32_t)(WG_LDS_ROWS * 128)) + (uint32_t)lr0 * 128u;
     }
-    auto stage_dma = [&](int blk, int buf) TN_INLINE_LAMBDA {
+    // pieces [P0, P1) of this wave's share of block `blk` -> slot `buf`
+    auto stage_dma_part = [&](int blk, int buf, auto p0c, auto p1c) TN_INLINE_LAMBDA {
+        constexpr int P0 = decltype(p0c)::value, P1 = decltype(p1c)::value;
         const float* blkbase = stash + (int64_t)blk * stash_rows * 32;
         const uint32_t slot = lds0 + (uint32_t)buf * (2 * WG_LDS_ROWS * 128);
-        tn_static_for<MAXP>([&](auto ic) TN_INLINE_LAMBDA {
-            constexpr int i = decltype(ic)::value;
+        tn_static_for<P1 - P0>([&](auto ic) TN_INLINE_LAMBDA {
+            constexpr int i = P0 + decltype(ic)::value;
             if (wave + 8 * i < npieces) tn_glds16(blkbase, voff[i], slot + __builtin_amdgcn_readfirstlane(pdst[i]));   // wave-uniform
         });
+    };
+    auto stage_dma = [&](int blk, int buf) TN_INLINE_LAMBDA {
+        stage_dma_part(blk, buf, std::integral_constant<int, 0>{}, std::integral_constant<int, MAXP>{});
     };
     // The last block of the batch may hold fewer than 32 samples: the slots behind M were never written by the
     // forward / dgrad kernels.  Each lane clears them in the 16 bytes it has just DMA'd (after its own vmcnt wait).
@@ -96,23 +101,33 @@ __device__ __forceinline__ void wgrad_body(const float* __restrict__ stash, int6
     const bool do_bias = job[JOB_HAS_BIAS] && wb == 0;
     auto is_tail = [&](int blk) TN_INLINE_LAMBDA { return (int64_t)blk * 32 + 32 > M; };          // wave-uniform
 
-    // two LDS slots: block b is read from slot b&1 while block b+1 lands in the other one
+    // Two LDS slots: block b is read from slot b&1 while block b+1 lands in the other one.  Issuing its 8 DMAs costs a
+    // wave several hundred cycles during which it feeds no MFMA: waves 0..3 issue theirs behind the fragment groups
+    // q = 0, 1 of block b, waves 4..7 (their SIMD partners) behind q = 2, 3, so that a SIMD always has one wave on the
+    // matrix pipe.  The last pieces still have a quarter of a block (> 4k cycles) to land.
+    const bool late = wave >= 4;
     if (nblk > 0) stage_dma(blk0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (nblk > 0 && is_tail(blk0)) { clear_tail(blk0, 0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
     __builtin_amdgcn_s_barrier();
-    if (nblk > 1) stage_dma(blk0 + 1, 1);
     for (int b = 0; b < nblk; ++b) {
-        if (active) {
-            const float* A = lds + (b & 1) * (2 * WG_LDS_ROWS * 32);
-            const float* B = A + WG_LDS_ROWS * 32;
-#pragma unroll 2
-            for (int q = 0; q < 4; ++q) {
-                f32x4 fa[TA], fb[TB];
+        const bool more = b + 1 < nblk;
+        const float* A = lds + (b & 1) * (2 * WG_LDS_ROWS * 32);
+        const float* B = A + WG_LDS_ROWS * 32;
+        tn_static_for<4>([&](auto qc) TN_INLINE_LAMBDA {
+            constexpr int q = decltype(qc)::value;
+            f32x4 fa[TA], fb[TB];
+            if (active) {
 #pragma unroll
                 for (int i = 0; i < TA; ++i) fa[i] = *reinterpret_cast<const f32x4*>(A + wg_lds_off((a_t0 + i) * 32 + frow, 2 * q + fh));
 #pragma unroll
                 for (int j = 0; j < TB; ++j) fb[j] = *reinterpret_cast<const f32x4*>(B + wg_lds_off((b_t0 + j) * 32 + frow, 2 * q + fh));
+            }
+            if (more && late == (q >= 2)) {
+                if constexpr ((q & 1) == 0) stage_dma_part(blk0 + b + 1, (b + 1) & 1, std::integral_constant<int, 0>{}, std::integral_constant<int, MAXP / 2>{});
+                else                        stage_dma_part(blk0 + b + 1, (b + 1) & 1, std::integral_constant<int, MAXP / 2>{}, std::integral_constant<int, MAXP>{});
+            }
+            if (active) {
                 if (do_bias) {
 #pragma unroll
                     for (int i = 0; i < TA; ++i) bsum[i] += (fa[i][0] + fa[i][1]) + (fa[i][2] + fa[i][3]);
@@ -125,13 +140,12 @@ __device__ __forceinline__ void wgrad_body(const float* __restrict__ stash, int6
 #pragma unroll
                         for (int j = 0; j < TB; ++j) acc[i][j] = TN_MFMA(fa[i][p], fb[j][p], acc[i][j]);
             }
-        }
-        // this wave's share of block b+1 has landed (issued one block ago); after the barrier everybody's has, and
-        // everybody is done reading slot b&1, which block b+2 may now overwrite
+        });
+        // this wave's share of block b+1 has landed; after the barrier everybody's has, and everybody is done reading
+        // slot b&1, which block b+2 may overwrite
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (b + 1 < nblk && is_tail(blk0 + b + 1)) { clear_tail(blk0 + b + 1, (b + 1) & 1); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+        if (more && is_tail(blk0 + b + 1)) { clear_tail(blk0 + b + 1, (b + 1) & 1); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
         __builtin_amdgcn_s_barrier();
-        if (b + 2 < nblk) stage_dma(blk0 + b + 2, b & 1);
     }
 
     // epilogue: partial block -> this workgroup's slab  [n_at*32][n_bt*32] then bias [n_at*32]
