@@ -1,6 +1,6 @@
 """bf16 training gradients at a batch large enough for several passes per workgroup; table and camera ray sources."""
 import os, sys, ctypes as C
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tiny-nerf-pytorch_amd"), os.path.join(ROOT, "tiny-nerf-pytorch_amd", "src"), os.path.join(ROOT, "tests")]
 import torch
 from conftest import load_golden, golden_params

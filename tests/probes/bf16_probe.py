@@ -1,6 +1,7 @@
-"""GPU probe of the bf16 render kernel: parity against the CPU restatement and timing against the fp32 kernel."""
+"""Checker script (uses the CPU oracle, hence under tests/; run by hand on the GPU box, not collected by pytest).
+GPU probe of the bf16 render kernel: parity against the CPU restatement and timing against the fp32 kernel."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tiny-nerf-pytorch_amd"), os.path.join(ROOT, "tiny-nerf-pytorch_amd", "src"), os.path.join(ROOT, "tests")]
 import torch
 from conftest import load_golden, golden_params

@@ -1,6 +1,7 @@
-"""GPU probe of the bf16 training step: gradients against the CPU restatement, per-kernel timing, PSNR after N steps."""
+"""Checker script (uses the CPU oracle, hence under tests/; run by hand on the GPU box, not collected by pytest).
+GPU probe of the bf16 training step: gradients against the CPU restatement, per-kernel timing, PSNR after N steps."""
 import os, sys, time, ctypes as C
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tiny-nerf-pytorch_amd"), os.path.join(ROOT, "tiny-nerf-pytorch_amd", "src"), os.path.join(ROOT, "tests")]
 import torch
 from conftest import load_golden, golden_params

@@ -3,7 +3,7 @@ import os, sys, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tiny-nerf-pytorch_amd"), os.path.join(ROOT, "tiny-nerf-pytorch_amd", "src"), os.path.join(ROOT, "tests")]
 import torch
-from oracle import tnerf_oracle as O
+import rays as rays_mod
 import nerf
 from tnerf import ops, lib as L
 
@@ -14,9 +14,9 @@ with torch.no_grad():
 st = m._ensure_packed()
 R, S = int(os.environ.get("R", "4096")), 64
 pose = torch.eye(4); pose[2, 3] = 4.0
-ro, rd = O.pinhole_rays(100, 100, 138.88887889922103, pose)
-idx = torch.randint(0, 10000, (R,), generator=torch.Generator().manual_seed(0))
-o, d = ro[idx].contiguous().to(dev), rd[idx].contiguous().to(dev)
+ro, rd = rays_mod.get_rays(100, 100, 138.88887889922103, pose.to(dev))
+idx = torch.randint(0, 10000, (R,), generator=torch.Generator().manual_seed(0)).to(dev)
+o, d = ro[idx].contiguous(), rd[idx].contiguous()
 tgt = torch.rand(R, 3, device=dev); t = torch.rand(R, S, device=dev)
 b = st.repack_bf16(); bp = b.train_plan(R, S)
 ztab = ops.depth_table(2.0, 6.0, S, dev)
