@@ -77,7 +77,7 @@ __device__ __forceinline__ void tn_bwd_tile(const BwdArgs& a, const float (&dzh)
 
 // ------------------------------------------------------------------------------ MLP only
 template <int HID>
-__global__ __launch_bounds__(256, 1) void k_mlp_bwd(BwdArgs a) {
+__global__ __launch_bounds__(256, HID == 128 ? 2 : 1) void k_mlp_bwd(BwdArgs a) {
     const int lane = tn_lane();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t m0 = ((int64_t)blockIdx.x * 4 + wave) * 32;
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_bwd(BwdArgs a) {
 // with rgb/sigma read from the forward's stash and only dL/dcomp_rgb upstream), then the dgrad chain
 // for the segment's two 32-sample tiles.
 template <int HID>
-__global__ __launch_bounds__(256, 1) void k_train_bwd(BwdArgs a) {
+__global__ __launch_bounds__(256, HID == 128 ? 2 : 1) void k_train_bwd(BwdArgs a) {
     const int lane = tn_lane();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t ray = (int64_t)blockIdx.x * 4 + wave;

@@ -123,7 +123,7 @@ __device__ __forceinline__ void tn_mlp_tile(const FwdArgs& a, const float (&enc)
 
 // ------------------------------------------------------------------------------ MLP only
 template <int HID, int NE, bool TRAIN>
-__global__ __launch_bounds__(256, 1) void k_mlp_fwd(FwdArgs a) {
+__global__ __launch_bounds__(256, HID == 128 ? 2 : 1) void k_mlp_fwd(FwdArgs a) {
     const int lane = tn_lane();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_fwd(FwdArgs a) {
 
 // ------------------------------------------------------------------------------ fused rays
 template <int HID, int NE, bool TRAIN>
-__global__ __launch_bounds__(256, 1) void k_render_fused(FwdArgs a) {
+__global__ __launch_bounds__(256, HID == 128 ? 2 : 1) void k_render_fused(FwdArgs a) {
     const int lane = tn_lane();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t ray = (int64_t)blockIdx.x * 4 + wave;
