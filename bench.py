@@ -101,6 +101,11 @@ def cpu_baseline(scene, seconds_budget=20.0):
 
 
 def main():
+    # The contract is ONE JSON line on stdout.  Libraries chat on fd 1 (RCCL prints a 5-line version banner at
+    # communicator creation): point fd 1 at stderr for the duration of the run and restore it for the final print.
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -360,10 +365,13 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(scene)
     fence()
-    if rank == 0:
-        print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()
+    sys.stdout.flush()
+    os.dup2(saved_stdout, 1)
+    os.close(saved_stdout)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
