@@ -72,9 +72,15 @@ class FlatAdam(torch.optim.Optimizer):
         st.packed_key = None                     # the packed copies (fp32 fragments, bf16 stream) are stale now
         if st.bf16 is not None:
             st.bf16.key = None
+        return None          # the per-parameter "step" scalars are refreshed lazily (state_dict), not 2*depth+4 times per step
+
+    def _refresh_steps(self):
         for p in self._params:
-            self.state[p]["step"] = torch.tensor(float(self._t))
-        return None
+            self.state[p]["step"].fill_(float(self._t))
+
+    def state_dict(self):
+        self._refresh_steps()
+        return super().state_dict()
 
 
 class FusedTrainer:
