@@ -280,7 +280,7 @@ int tnerf_render_fused_cam_bf16(const tnerf_mlp_desc* d, const void* packed16, c
  * weights.  The stash is organised by tiles of 32 sample slots (n_tiles = n_rays * ceil(n_samples / 32)). */
 typedef struct tnerf_bf16_train_plan {
     int64_t n_tiles;
-    int64_t stash_bytes;        /* bf16 activations / activation gradients (the chain kernels' operand records), ReLU bits, head outputs */
+    int64_t stash_bytes;        /* bf16 activations / activation gradients (in the weight-gradient kernel's operand order), ReLU bits, head outputs */
     int64_t slab_floats;        /* fp32 weight-gradient partial slabs (one per wgrad workgroup)                           */
     int64_t job_ints;           /* wgrad job table (int32)                                                                */
     int64_t reduce_ints;        /* slab -> flat-gradient gather table (int32), same format as tnerf_plan_fill's           */

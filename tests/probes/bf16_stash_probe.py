@@ -77,20 +77,33 @@ def acc_row(r, h):
 
 
 def decode(ft0, ntile_f):
-    """-> [M = ntiles*32, ntile_f*32] matrix (sample slot, feature).  A record holds the chain kernels' B operands:
-    lane (j, h) element e of k-step u = feature 32 tf + acc_row(8u+e, h) of sample slot j."""
+    """-> [M = ntiles*32, ntile_f*32] matrix (sample slot, feature)."""
     out = torch.zeros(ntiles * 32, ntile_f * 32)
     for tf in range(ntile_f):
         rec = frag[:ntiles, ft0 + tf]                      # [tile, u, lane, e]
         for u in range(2):
             for lane in range(64):
-                j, hh = lane & 31, lane >> 5
+                c, hh = lane & 31, lane >> 5
                 for e in range(8):
-                    out[torch.arange(ntiles) * 32 + j, tf * 32 + acc_row(8 * u + e, hh)] = rec[:, u, lane, e]
+                    out[torch.arange(ntiles) * 32 + acc_row(8 * u + e, hh), tf * 32 + c] = rec[:, u, lane, e]
     return out
 
 
 ft_enc, ft_h, ft_dz, ft_dzh = 0, [2 + NT * l for l in range(depth)], [2 + NT * depth + NT * l for l in range(depth)], 2 + 2 * NT * depth
+got = decode(ft_h[0], NT)
+print("H_0 nnz got/want", int((got != 0).sum()), int((hs[0] != 0).sum()), "sum", float(got.sum()), float(hs[0].sum()))
+print("tile0 sorted match:", torch.equal(torch.sort(got[:32].reshape(-1))[0], torch.sort(hs[0][:32].reshape(-1))[0]))
+print("got[0,:8]", got[0, :8].tolist()); print("want[0,:8]", hs[0][0, :8].tolist())
+print("got[:8,0]", got[:8, 0].tolist()); print("want[:8,0]", hs[0][:8, 0].tolist())
+# where does want[0, 0..3] appear in tile 0's record?
+rec0 = frag[0, ft_h[0]]
+for f in range(4):
+    v = float(hs[0][0, f])
+    loc = (rec0 == v).nonzero()
+    print(f"want[sample 0, feature {f}] = {v}: found at (u, lane, e) = {loc[:4].tolist()}")
+for smp in (1, 5):
+    v = float(hs[0][smp, 2])
+    print(f"want[sample {smp}, feature 2] = {v}: found at {(rec0 == v).nonzero()[:4].tolist()}")
 for l in range(depth):
     got = decode(ft_h[l], NT)
     print(f"H_{l}: max err {float((got - hs[l]).abs().max()):.3e} (max |want| {float(hs[l].abs().max()):.3e})")

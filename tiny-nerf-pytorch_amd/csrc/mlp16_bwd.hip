@@ -1,10 +1,9 @@
 // bf16 mode, backward of the train step (what autograd derives from volume.py:18-42 and nerf.py:34-40):
 //   k_dgrad16 : composite backward (fp32) + the dgrad chain dH_{l-1} = W_l^T dZ_l on bf16 MFMA with the transposed
-//               weight stream shared through LDS (mlp16_core.hpp), dZ_l rounded to bf16 and stashed for the
-//               weight-gradient kernel;
-//   k_wgrad16 : dW_l = dZ_l^T H_{l-1} over all sample tiles: both operands stream HBM -> LDS (DMA) as the chain kernels
-//               stored them (lane = sample), are transposed by two MFMAs per 32x32 tile against constant selectors
-//               (the kernel is HBM-bound: the matrix pipe has the time) and contracted over the samples; fp32
+//               weight stream shared through LDS (mlp16_core.hpp), dZ_l rounded to bf16 and stashed as the
+//               K = samples operand of the weight-gradient MFMAs;
+//   k_wgrad16 : dW_l = dZ_l^T H_{l-1} over all sample tiles: both operands stream HBM -> LDS (DMA) -> MFMA with no
+//               transposition anywhere (the forward / dgrad kernels already wrote them sample-major per lane); fp32
 //               accumulators -> per-workgroup slabs -> the deterministic slab reduction of the fp32 path.
 #include "mlp16_core.hpp"
 #include "mlp16_args.hpp"
@@ -15,7 +14,7 @@
 template <int HID, int KINDB>
 __device__ __forceinline__ void tn16_layer_bwd(Pipe16& p, const unsigned char* lds, const bf16x8 (&zin)[HID / 16], const bf16x8& zh,
                                                bf16x8 (&zout)[HID / 16], f32x16& acc, const uint32_t (&mw)[HID / 64],
-                                               const Stash16& st, int ft0) {
+                                               const Stash16& st, uint32_t sel_off, int ft0) {
     constexpr int NT = HID / 32, KH = HID / 16;
     constexpr int KPT = KINDB == 0 ? 1 : KH;
     constexpr int NF = KINDB == 0 ? TN16_STAGE : NT * KH;        // fragments of the stream this layer consumes
@@ -52,7 +51,7 @@ __device__ __forceinline__ void tn16_layer_bwd(Pipe16& p, const unsigned char* l
             }
             zout[2 * t] = __builtin_bit_cast(bf16x8, w0);
             zout[2 * t + 1] = __builtin_bit_cast(bf16x8, w1);
-            tn16_stash_tile(p.lane16, st, ft0 + t, zout[2 * t], zout[2 * t + 1]);
+            tn16_stash_tile(lds, sel_off, p.lane16, st, ft0 + t, zout[2 * t], zout[2 * t + 1], acc);
         }
     });
 }
@@ -68,7 +67,7 @@ __device__ __forceinline__ void tn16_load_mask(uint32_t (&mw)[HID / 64], const S
 // dzh[4]: this lane's head gradients (r,g,b,sigma pre-activation); zero for slots past S.
 template <int HID>
 __device__ __forceinline__ void tn16_bwd_tile(Pipe16& p, const unsigned char* lds, const Net16& n, int h, const float (&dzh)[4],
-                                              const Stash16& st) {
+                                              const Stash16& st, uint32_t sel_off) {
     constexpr int KH = HID / 16;
     const int depth = n.depth;
     bf16x8 X[KH], Y[KH];
@@ -80,23 +79,23 @@ __device__ __forceinline__ void tn16_bwd_tile(Pipe16& p, const unsigned char* ld
     const bf16x8 zh = __builtin_bit_cast(bf16x8, zw);
     {
         const u32x4 zero = {0u, 0u, 0u, 0u};
-        tn16_stash_tile(p.lane16, st, n.ft_dzh, zh, __builtin_bit_cast(bf16x8, zero));
+        tn16_stash_tile(lds, sel_off, p.lane16, st, n.ft_dzh, zh, __builtin_bit_cast(bf16x8, zero), acc);
     }
     // heads^T: dZ_{depth-1} = (W_head^T dZ_head) * (H_{depth-1} > 0)
     if (depth > 1) tn16_load_mask<HID>(mwn, st, depth - 2, p.lane16);
-    tn16_layer_bwd<HID, 0>(p, lds, X, zh, X, acc, mw, st, n.ft_dz[depth - 1]);
+    tn16_layer_bwd<HID, 0>(p, lds, X, zh, X, acc, mw, st, sel_off, n.ft_dz[depth - 1]);
     // hidden layers, last to first: dZ_l (X) -> dZ_{l-1} (Y) and back
     int l = depth - 1;
     while (l >= 1) {
 #pragma unroll
         for (int i = 0; i < HID / 64; ++i) mw[i] = mwn[i];
         if (l >= 2) tn16_load_mask<HID>(mwn, st, l - 2, p.lane16);
-        tn16_layer_bwd<HID, 1>(p, lds, X, zh, Y, acc, mw, st, n.ft_dz[l - 1]);
+        tn16_layer_bwd<HID, 1>(p, lds, X, zh, Y, acc, mw, st, sel_off, n.ft_dz[l - 1]);
         if (--l < 1) break;
 #pragma unroll
         for (int i = 0; i < HID / 64; ++i) mw[i] = mwn[i];
         if (l >= 2) tn16_load_mask<HID>(mwn, st, l - 2, p.lane16);
-        tn16_layer_bwd<HID, 1>(p, lds, Y, zh, X, acc, mw, st, n.ft_dz[l - 1]);
+        tn16_layer_bwd<HID, 1>(p, lds, Y, zh, X, acc, mw, st, sel_off, n.ft_dz[l - 1]);
         --l;
     }
 }
@@ -108,8 +107,9 @@ __global__ __launch_bounds__(512, 2) void k_dgrad16(Fwd16Args a) {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int j = lane & 31, h = lane >> 5;
     const int S = a.sa.S;
+    const uint32_t sel_off = TN16_SEL_OFF(a.n.n_bias);
     Pipe16 p;
-    tn16_prologue(p, lds, a.packed, a.n, a.packed + (int64_t)a.n.n_frag * 1024, a.n.n_bw_stage, lane, wave);
+    tn16_prologue(p, lds, a.packed, a.n, a.packed + (int64_t)a.n.n_frag * 1024, a.n.n_bw_stage, lane, wave, true);
 
     const int64_t n_groups = (a.R + 7) / 8;
     const int TPR = (S + 31) / 32;
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(512, 2) void k_dgrad16(Fwd16Args a) {
                 st.frag = a.stash + (tile * a.n.n_ft) * TN16_FT_BYTES;
                 st.mask = const_cast<unsigned char*>(mask0) + tile * (64 * (HID / 64) * 4);
                 st.mask_lstride = (a.n_tiles + 1) * (64 * (HID / 64) * 4);
-                tn16_bwd_tile<HID>(p, lds, a.n, h, dzh, st);
+                tn16_bwd_tile<HID>(p, lds, a.n, h, dzh, st, sel_off);
             }
         }
     }
@@ -192,7 +192,7 @@ int tn16_launch_dgrad(const Fwd16Args& a, hipStream_t stream, const char* who) {
     if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
     const int64_t groups = (a.R + 7) / 8;
     const dim3 grid((unsigned)(groups < n_cu ? groups : n_cu)), block(512);
-    const size_t lds_bytes = TN16_RING + (size_t)((a.n.n_bias + 3) / 4 * 4) * 4;
+    const size_t lds_bytes = TN16_SEL_OFF(a.n.n_bias) + 2048;
     if (a.n.hidden == 256) {
         { static size_t set_ = 0; if (set_ < lds_bytes) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dgrad16<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); set_ = lds_bytes; } }
         hipLaunchKernelGGL((k_dgrad16<256>), grid, block, lds_bytes, stream, a);
@@ -240,67 +240,22 @@ __device__ __forceinline__ void tn16w_body(const Wgrad16Args& a, const int32_t* 
     const int64_t tile_bytes = (int64_t)a.n_ft * TN16_FT_BYTES;
     auto tile_ptr = [&](int k) TN_INLINE_LAMBDA { const int kk = k < nt ? k : nt - 1; return a.stash + (t0 + kk) * tile_bytes; };
 
-    f32x16 acc[TA][TB];
-    float bsum[TA];                                          // bias gradient: this lane's feature summed over its 16 sample slots
+    f32x16 acc[TA][TB], accb[TA];
     const f32x16 zero = {};
 #pragma unroll
-    for (int i = 0; i < TA; ++i) { bsum[i] = 0.0f;
+    for (int i = 0; i < TA; ++i) { accb[i] = zero;
 #pragma unroll
         for (int jx = 0; jx < TB; ++jx) acc[i][jx] = zero; }
-    const bf16x8 sel0 = tn16_selector(0, lane), sel1 = tn16_selector(1, lane);
+    const u32x4 ones_w = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+    const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_w);
 
-    // The records hold the chain kernels' B operands (lane = sample).  Every wave transposes its share of a block's
-    // feature tiles (tile w and w+8 of the n_at + n_bt) IN PLACE in the LDS slot — two MFMAs against the selectors and
-    // 8 packs per tile — one block ahead of the block being contracted, on MFMA time the HBM-bound
-    // stream leaves idle; the per-block barrier publishes DMA and transposition together.
-    const int ntl = n_at + n_bt;
-    // split in two so that the contraction's MFMAs can sit between the transposing MFMAs and the packs that wait for them
-    auto transpose_begin = [&](int k, f32x16 (&d)[2]) TN_INLINE_LAMBDA {
-        const unsigned char* slot = lds + (k & (TN16W_NS - 1)) * TN16W_SLOT + lane16;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int tl = wave + 8 * q;                                        // wave-uniform
-            if (tl < ntl) {
-                const unsigned char* rec = slot + (tl < n_at ? tl * 2048 : 16384 + (tl - n_at) * 2048);
-                const f32x16 z = {};
-                d[q] = TN16_MFMA(*reinterpret_cast<const bf16x8*>(rec), sel0, z);
-                d[q] = TN16_MFMA(*reinterpret_cast<const bf16x8*>(rec + 1024), sel1, d[q]);
-            }
-        }
-    };
-    auto transpose_end = [&](int k, const f32x16 (&d)[2]) TN_INLINE_LAMBDA {
-        unsigned char* slot = lds + (k & (TN16W_NS - 1)) * TN16W_SLOT + lane16;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int tl = wave + 8 * q;
-            if (tl < ntl) {
-                unsigned char* rec = slot + (tl < n_at ? tl * 2048 : 16384 + (tl - n_at) * 2048);
-                u32x4 p0, p1;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {                                   // exact: the values are bf16-representable
-                    const float l0 = d[q][2 * i], h0 = d[q][2 * i + 1], l1 = d[q][8 + 2 * i], h1 = d[q][8 + 2 * i + 1];
-                    p0[i] = __builtin_amdgcn_perm(__float_as_uint(h0), __float_as_uint(l0), 0x07060302u);
-                    p1[i] = __builtin_amdgcn_perm(__float_as_uint(h1), __float_as_uint(l1), 0x07060302u);
-                }
-                *reinterpret_cast<u32x4*>(rec) = p0;
-                *reinterpret_cast<u32x4*>(rec + 1024) = p1;
-            }
-        }
-    };
-    auto transpose_share = [&](int k) TN_INLINE_LAMBDA { f32x16 d[2]; transpose_begin(k, d); transpose_end(k, d); };
-    // tiles 0..3 in flight; tile 0 landed, published, transposed, published again; tile 1 landed
+    // tiles 0..3 in flight; tile 0 landed and published
 #pragma unroll
     for (int k = 0; k < TN16W_NS; ++k) tn16w_issue<PER>(tile_ptr(k), a_ft0, b_ft0, nfa, nf, wave, lane16, lds0 + k * TN16W_SLOT);
     if constexpr (PER == 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    transpose_share(0);
-    if constexpr (PER == 4) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
     for (int k = 0; k < nt; ++k) {
         const unsigned char* slot = lds + (k & (TN16W_NS - 1)) * TN16W_SLOT + lane16;
-        f32x16 dtr[2];
-        if (k + 1 < nt) transpose_begin(k + 1, dtr);                            // raw block k+1 was published by the last barrier
-        __builtin_amdgcn_sched_barrier(0);
         if (active) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -313,19 +268,12 @@ __device__ __forceinline__ void tn16w_body(const Wgrad16Args& a, const int32_t* 
                 for (int i = 0; i < TA; ++i) {
 #pragma unroll
                     for (int jx = 0; jx < TB; ++jx) acc[i][jx] = TN16_MFMA(af[i], bfr[jx], acc[i][jx]);
-                    if (has_bias && wb == 0) {                                   // row sums of dZ^T (fp32, from the exact bf16 values)
-                        const u32x4 w = __builtin_bit_cast(u32x4, af[i]);
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) bsum[i] += __uint_as_float(w[q] << 16) + __uint_as_float(w[q] & 0xFFFF0000u);
-                    }
+                    if (has_bias && wb == 0) accb[i] = TN16_MFMA(af[i], ones, accb[i]);      // row sums: every column = sum over the samples
                 }
             }
         }
-        __builtin_amdgcn_sched_barrier(0);
-        if (k + 1 < nt) transpose_end(k + 1, dtr);
-        // own DMA of tile k+2 done (k+3 stays in flight) and own transposed writes of tile k+1 done; after the barrier
-        // everyone may read both, and slot k is free
-        if constexpr (PER == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+        // own DMA of tile k+1 done (k+2, k+3 stay in flight); after the barrier everyone may read it and slot k is free
+        if constexpr (PER == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         tn16w_issue<PER>(tile_ptr(k + TN16W_NS), a_ft0, b_ft0, nfa, nf, wave, lane16, lds0 + (k & (TN16W_NS - 1)) * TN16W_SLOT);
     }
@@ -341,9 +289,9 @@ __device__ __forceinline__ void tn16w_body(const Wgrad16Args& a, const int32_t* 
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 slab[(int64_t)(32 * (at0 + i) + TN_ACC_ROW(r, h)) * ld + 32 * (bt0 + jx) + c] = acc[i][jx][r];
-        if (has_bias && wb == 0) {
-            const float tot = bsum[i] + __shfl_xor(bsum[i], 32, 64);            // the two lane halves hold different sample slots
-            if (h == 0) slab[(int64_t)n_at * 32 * ld + 32 * (at0 + i) + c] = tot;
+        if (has_bias && wb == 0 && c == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) slab[(int64_t)n_at * 32 * ld + 32 * (at0 + i) + TN_ACC_ROW(r, h)] = accb[i][r];
         }
     }
 }

@@ -100,28 +100,46 @@ struct Stash16 {              // all wave-uniform: the lane term is added as a 3
     unsigned char* mask;      // mask region + tile * 64 * (hidden/64) * 4                (layer 0)
     int64_t mask_lstride;     // bytes between layers
 };
-// Store the k-step pair (b0, b1) — the two packed B operands that hold a 32-feature tile of the wave's 32 samples — as
-// record `ft` of the current tile, as they are (lane = sample, element = feature slot).  The weight-gradient kernel,
-// which is HBM-bound and has MFMA time to spare, transposes them in LDS (k_wgrad16) before it contracts them.
-__device__ __forceinline__ void tn16_stash_tile(uint32_t lane16, const Stash16& st, int ft, const bf16x8& b0, const bf16x8& b1) {
-    unsigned char* dst = st.frag + (int64_t)ft * TN16_FT_BYTES;       // uniform
-    // non-temporal: 1.1 GB per kernel that nothing re-reads before the weight-gradient kernel (measured: -12 % step time)
-    __builtin_nontemporal_store(__builtin_bit_cast(u32x4, b0), reinterpret_cast<u32x4*>(dst + lane16));
-    __builtin_nontemporal_store(__builtin_bit_cast(u32x4, b1), reinterpret_cast<u32x4*>(dst + 1024 + lane16));
+#define TN16_SEL_OFF(n_bias) (TN16_RING + (uint32_t)(((n_bias) + 3) / 4 * 4) * 4)   // LDS byte offset of the selector pair
+
+// Selector B operands of the transposing MFMAs (2 x 64 lanes x 16 B in LDS): sel_u[k-slot (h,e)][col c] = (c == TN_ACC_ROW(8u+e, h)).
+// A x sel_0 + A' x sel_1 turns two packed k-steps (lane = sample, element = feature slot) into a 32 x 32 tile with the
+// FEATURE on the lane and the 32 samples in the 16 accumulator registers: the K = samples operand of the weight-gradient
+// MFMAs.  The products are exact (x * 1 + 0), so the transposed tile holds the very bf16 values the forward used.
+__device__ __forceinline__ void tn16_write_selectors(unsigned char* lds, uint32_t sel_off, int lane) {
+    const int c = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        unsigned short v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (c == TN_ACC_ROW(8 * u + e, hh)) ? (unsigned short)0x3F80 : (unsigned short)0;
+        u32x4 w;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[i] = (unsigned)v[2 * i] | ((unsigned)v[2 * i + 1] << 16);
+        *reinterpret_cast<u32x4*>(lds + sel_off + u * 1024 + lane * 16) = w;
+    }
 }
 
-// Selector B operands of the transposing MFMAs in k_wgrad16: sel_u[k-slot (h,e)][col c] = (c == TN_ACC_ROW(8u+e, h)).
-// r0 x sel_0 + r1 x sel_1 turns two packed k-steps (lane = sample, element = feature slot) into a 32 x 32 tile with the
-// FEATURE on the lane and the 32 samples in the 16 accumulator registers — the K = samples operand of the
-// weight-gradient MFMAs: k-step u of the result = registers 8u .. 8u+7, i.e. lane (c, h) element e = feature c of sample
-// slot TN_ACC_ROW(8u+e, h).  The products are exact (x * 1 + 0): the operand holds the very bf16 values that were stored.
-__device__ __forceinline__ bf16x8 tn16_selector(int u, int lane) {
-    const int c = lane & 31, hh = lane >> 5;
-    u32x4 w;
+// Transpose the k-step pair (b0, b1) and store it as feature tile `ft` of the current tile's stash record.
+__device__ __forceinline__ void tn16_stash_tile(const unsigned char* lds, uint32_t sel_off, uint32_t lane16, const Stash16& st, int ft,
+                                                const bf16x8& b0, const bf16x8& b1, f32x16& d) {
+    const bf16x8 s0 = *reinterpret_cast<const bf16x8*>(lds + sel_off + lane16);
+    const bf16x8 s1 = *reinterpret_cast<const bf16x8*>(lds + sel_off + 1024 + lane16);
+    const f32x16 z = {};
+    d = TN16_MFMA(b0, s0, z);
+    d = TN16_MFMA(b1, s1, d);
+    // (vector elements are copied to scalars first: __builtin_bit_cast applied directly to d[i] reads element 0)
+    u32x4 p0, p1;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-        w[i] = ((c == TN_ACC_ROW(8 * u + 2 * i, hh)) ? 0x3F80u : 0u) | ((c == TN_ACC_ROW(8 * u + 2 * i + 1, hh)) ? 0x3F800000u : 0u);
-    return __builtin_bit_cast(bf16x8, w);
+    for (int i = 0; i < 4; ++i) {                                   // exact: the values are bf16-representable
+        const float l0 = d[2 * i], h0 = d[2 * i + 1], l1 = d[8 + 2 * i], h1 = d[8 + 2 * i + 1];
+        p0[i] = __builtin_amdgcn_perm(__float_as_uint(h0), __float_as_uint(l0), 0x07060302u);
+        p1[i] = __builtin_amdgcn_perm(__float_as_uint(h1), __float_as_uint(l1), 0x07060302u);
+    }
+    unsigned char* dst = st.frag + (int64_t)ft * TN16_FT_BYTES;       // uniform
+    // non-temporal: 1.1 GB per kernel that nothing re-reads before the weight-gradient kernel (measured: -12 % step time)
+    __builtin_nontemporal_store(p0, reinterpret_cast<u32x4*>(dst + lane16));
+    __builtin_nontemporal_store(p1, reinterpret_cast<u32x4*>(dst + 1024 + lane16));
 }
 
 // 16 ReLU sign bits of an n-tile from its packed outputs (dword q of lo|hi = registers 2q, 2q+1): bit r <-> register r.
@@ -142,12 +160,12 @@ __device__ __forceinline__ unsigned tn16_sign_bits(const u32x4& lo, const u32x4&
 // The epilogue of an n-tile (bias add in fp32, round to bf16, ReLU on the packed pair) follows its last MFMA; the MFMA
 // pipe is kept busy meanwhile by the SIMD's other wave.
 // vb: per-lane LDS byte offset of this layer's biases (+ 16 h).  KIND 3 leaves the raw head accumulator in `acc`.
-// TRAIN: also stash the layer's output tiles (feature tiles ft0 + t) and its ReLU sign bits (layer l).
+// TRAIN: also stash the layer's output tiles (transposed, feature tiles ft0 + t) and its ReLU sign bits (layer l).
 template <int HID, int KIND, bool TRAIN = false>
 __device__ __forceinline__ void tn16_layer(Pipe16& p, const unsigned char* lds, uint32_t vb,
                                            const bf16x8 (&bin)[HID / 16], const bf16x8 (&enc)[TN16_KE],
                                            bf16x8 (&bout)[HID / 16], f32x16& acc,
-                                           const Stash16& st = Stash16{}, int ft0 = 0, int l = 0) {
+                                           const Stash16& st = Stash16{}, uint32_t sel_off = 0, int ft0 = 0, int l = 0) {
     constexpr int NT = KIND == 3 ? 1 : HID / 32, KH = HID / 16;
     constexpr int KPT = KIND == 0 ? TN16_KE : (KIND == 1 ? KH : (KIND == 2 ? KH + TN16_KE : TN16_STAGE));
     constexpr int KUSE = KIND == 3 ? KH : KPT;                 // k-steps with MFMAs (the head stage is zero-padded)
@@ -198,7 +216,7 @@ __device__ __forceinline__ void tn16_layer(Pipe16& p, const unsigned char* lds, 
             if constexpr (TRAIN) {
                 const unsigned m16 = tn16_sign_bits(w0, w1);
                 if constexpr ((t & 1) == 0) mb[t / 2] = m16; else mb[t / 2] |= m16 << 16;
-                tn16_stash_tile(p.lane16, st, ft0 + t, bout[2 * t], bout[2 * t + 1]);
+                tn16_stash_tile(lds, sel_off, p.lane16, st, ft0 + t, bout[2 * t], bout[2 * t + 1], acc);
             }
         }
     });
@@ -250,14 +268,15 @@ __device__ __forceinline__ void tn16_encode(float px, float py, float pz, int Lf
     });
 }
 
-// Workgroup prologue shared by the bf16 chain kernels: biases -> LDS, the first LEAD+1 stages
+// Workgroup prologue shared by the bf16 kernels: biases (and the transposition selectors) -> LDS, the first four stages
 // of the stream starting at `src` in flight, stage 0 published, the first fragments in registers.
 __device__ __forceinline__ void tn16_prologue(Pipe16& p, unsigned char* lds, const unsigned char* packed, const Net16& n,
-                                              const unsigned char* src, int n_stage, int lane, int wave) {
+                                              const unsigned char* src, int n_stage, int lane, int wave, bool selectors) {
     {
         float* bl = reinterpret_cast<float*>(lds + TN16_RING);
         const float* bg = reinterpret_cast<const float*>(packed + n.bias_off);
         for (int i = threadIdx.x; i < n.n_bias; i += 512) bl[i] = bg[i];
+        if (selectors && wave == 0) tn16_write_selectors(lds, TN16_SEL_OFF(n.n_bias), lane);
     }
     p.lane16 = lane * 16;
     p.src = src; p.src_off = 0; p.stream_bytes = (uint32_t)n_stage * TN16_SLOT;

@@ -8,24 +8,24 @@
 // The network for one 32-sample tile: enc -> res[4] (r,g,b after sigmoid; sigma after ReLU; lane-half 0 only).
 template <int HID, bool TRAIN>
 __device__ __forceinline__ void tn16_mlp_tile(Pipe16& p, const unsigned char* lds, const Net16& n, int h,
-                                              const bf16x8 (&enc)[TN16_KE], float (&res)[4], const Stash16& st) {
+                                              const bf16x8 (&enc)[TN16_KE], float (&res)[4], const Stash16& st, uint32_t sel_off) {
     constexpr int KH = HID / 16;
     const int depth = n.depth, skip_at = n.skip_at;
     const uint32_t vb0 = TN16_RING + 16u * h;                                   // + layer * HID * 4
     bf16x8 X[KH], Y[KH];
     f32x16 acc;
     if constexpr (TRAIN) {                                                      // the network input, as wgrad's B operand
-        tn16_stash_tile(p.lane16, st, n.ft_enc, enc[0], enc[1]);
-        tn16_stash_tile(p.lane16, st, n.ft_enc + 1, enc[2], enc[3]);
+        tn16_stash_tile(lds, sel_off, p.lane16, st, n.ft_enc, enc[0], enc[1], acc);
+        tn16_stash_tile(lds, sel_off, p.lane16, st, n.ft_enc + 1, enc[2], enc[3], acc);
     }
-    tn16_layer<HID, 0, TRAIN>(p, lds, vb0, X, enc, X, acc, st, n.ft_h[0], 0);
+    tn16_layer<HID, 0, TRAIN>(p, lds, vb0, X, enc, X, acc, st, sel_off, n.ft_h[0], 0);
     int l = 1;
     while (l < depth) {
-        if (l == skip_at) tn16_layer<HID, 2, TRAIN>(p, lds, vb0 + l * HID * 4, X, enc, Y, acc, st, n.ft_h[l], l);
-        else              tn16_layer<HID, 1, TRAIN>(p, lds, vb0 + l * HID * 4, X, enc, Y, acc, st, n.ft_h[l], l);
+        if (l == skip_at) tn16_layer<HID, 2, TRAIN>(p, lds, vb0 + l * HID * 4, X, enc, Y, acc, st, sel_off, n.ft_h[l], l);
+        else              tn16_layer<HID, 1, TRAIN>(p, lds, vb0 + l * HID * 4, X, enc, Y, acc, st, sel_off, n.ft_h[l], l);
         if (++l >= depth) break;
-        if (l == skip_at) tn16_layer<HID, 2, TRAIN>(p, lds, vb0 + l * HID * 4, Y, enc, X, acc, st, n.ft_h[l], l);
-        else              tn16_layer<HID, 1, TRAIN>(p, lds, vb0 + l * HID * 4, Y, enc, X, acc, st, n.ft_h[l], l);
+        if (l == skip_at) tn16_layer<HID, 2, TRAIN>(p, lds, vb0 + l * HID * 4, Y, enc, X, acc, st, sel_off, n.ft_h[l], l);
+        else              tn16_layer<HID, 1, TRAIN>(p, lds, vb0 + l * HID * 4, Y, enc, X, acc, st, sel_off, n.ft_h[l], l);
         ++l;
     }
     if ((depth - 1) & 1) tn16_layer<HID, 3, TRAIN>(p, lds, 0, Y, enc, Y, acc);
@@ -44,8 +44,9 @@ __global__ __launch_bounds__(512, 2) void k_render16(Fwd16Args a) {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int j = lane & 31, h = lane >> 5;
     const int S = a.sa.S, Lf = a.n.Lf;
+    const uint32_t sel_off = TN16_SEL_OFF(a.n.n_bias);
     Pipe16 p;
-    tn16_prologue(p, lds, a.packed, a.n, a.packed, a.n.n_stage, lane, wave);
+    tn16_prologue(p, lds, a.packed, a.n, a.packed, a.n.n_stage, lane, wave, TRAIN);
 
     // Every wave of the workgroup runs the same number of network passes (the stage barriers are workgroup-wide):
     // rays beyond R are computed on a clamped index and stored nowhere (training: into the dump tile).
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(512, 2) void k_render16(Fwd16Args a) {
                     st.mask_lstride = (a.n_tiles + 1) * (64 * (HID / 64) * 4);
                 }
                 float res[4];
-                tn16_mlp_tile<HID, TRAIN>(p, lds, a.n, h, enc, res, st);
+                tn16_mlp_tile<HID, TRAIN>(p, lds, a.n, h, enc, res, st, sel_off);
                 if constexpr (TRAIN) {
                     f32x4* o4 = reinterpret_cast<f32x4*>(a.stash + TN16_STASH_FRAG_BYTES(a.n, a.n_tiles) + TN16_STASH_MASK_BYTES(a.n, a.n_tiles)) + (tile * 32 + j);
                     const bool live = s < S;                                   // slots past S: zero outputs
@@ -126,7 +127,7 @@ int tn16_launch_fwd(const Fwd16Args& a, bool train, hipStream_t stream, const ch
     if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
     const int64_t groups = (a.R + 7) / 8;
     const dim3 grid((unsigned)(groups < n_cu ? groups : n_cu)), block(512);
-    const size_t lds_bytes = TN16_RING + (size_t)((a.n.n_bias + 3) / 4 * 4) * 4;
+    const size_t lds_bytes = TN16_SEL_OFF(a.n.n_bias) + 2048;
 #define TN16_CASE(H_, T_)                                                                                                        \
     if (a.n.hidden == H_ && train == T_) {                                                                                        \
         { static size_t set_ = 0; if (set_ < lds_bytes) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_render16<H_, T_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); set_ = lds_bytes; } } \

@@ -52,13 +52,10 @@ struct MlpLayout {
 // k-tile t: hidden/16 k-steps, fragment row 32t+i <-> input feature, k-slot (s,h,e) <-> output feature as above.
 //
 // bf16 training stash, organised by TILES of 32 sample slots (tile = ray * ceil(S/32) + sb/32; slots past S are zero):
-//   fragments: tile * n_ft + ft  ->  2 KB = [k-step u: 2][lane 64][8 bf16]: the two packed B operands of the chain
-//              kernels that hold feature tile ft' of the tile's 32 samples — lane (j, h) element e of k-step u = value of
-//              feature 32 ft' + TN_ACC_ROW(8u+e, h) for sample slot j.  The weight-gradient kernel transposes a record
-//              in LDS (two MFMAs against selector matrices) into its K = samples operands: lane (c, h) element e of
-//              k-step u = feature 32 ft' + c of sample slot TN_ACC_ROW(8u+e, h).
-//              ft: ft_enc + {0,1} (input slots: tile T = u>>1 of slot (u,h,e), transposed column c = TN_ACC_ROW(8(u&1)+e, h)),
-//                  ft_h[l] + t (H_l), ft_dz[l] + t (dZ_l), ft_dzh (transposed rows 0..3 = d r,g,b,sigma pre-activation)
+//   fragments: tile * n_ft + ft  ->  2 KB = [k-step u: 2][lane 64][8 bf16], the K = SAMPLES operand of the weight-gradient
+//              MFMAs: lane (c, h) element e = value of feature (32 ft' + c) for sample slot TN_ACC_ROW(8u+e, h).
+//              ft: ft_enc + {0,1} (input slots: tile T = u>>1, c = TN_ACC_ROW(8(u&1)+e, h) of slot (u,h,e)),
+//                  ft_h[l] + t (H_l), ft_dz[l] + t (dZ_l), ft_dzh (rows 0..3 = d r,g,b,sigma pre-activation)
 //   masks    : [layer][tile][lane 64][hidden/64 words]: bit (t&1)*16 + r of word t/2 <-> H_l[feature 32t + TN_ACC_ROW(r,h)] > 0
 //   out4     : [tile][slot 32][4] fp32 head outputs (r,g,b after sigmoid, sigma after ReLU)
 // One extra ("dump") tile follows the real ones in every region: waves that pad the last workgroup store there.
