@@ -15,7 +15,8 @@ from nerf import TinyNeRF                          # noqa: E402
 from train import render_one, write_png            # noqa: E402
 
 
-def main(ckpt_path="checkpoints/tinynerf_latest.pth", out_dir="outputs"):
+def main(ckpt_path="checkpoints/tinynerf_latest.pth", out_dir="outputs", precision="fp32"):
+    """precision="bf16" (an addition): render the frames with the bf16-MFMA kernel (BASELINE cfg 4), ~9x faster."""
     device = torch.device("cuda")
     d = load_scene("data/tiny_nerf_data.npz")
     H, W, focal = d["images"].shape[1], d["images"].shape[2], float(d["focal"])
@@ -33,7 +34,7 @@ def main(ckpt_path="checkpoints/tinynerf_latest.pth", out_dir="outputs"):
     for k, pose in enumerate(spiral_poses(poses[0], n_frames=60, radius=0.3)):
         if k % world != rank:
             continue
-        img = render_one(model, encoder, H, W, focal, pose, device, n_samples=64, near=2.0, far=6.0)
+        img = render_one(model, encoder, H, W, focal, pose, device, n_samples=64, near=2.0, far=6.0, precision=precision)
         frames.append((img.cpu().numpy() * 255).astype(np.uint8))
     if world > 1:
         gathered = [None] * world
