@@ -252,7 +252,7 @@ __device__ __forceinline__ void tn16w_body(const Wgrad16Args& a, const int32_t* 
     // tiles 0..3 in flight; tile 0 landed and published
 #pragma unroll
     for (int k = 0; k < TN16W_NS; ++k) tn16w_issue<PER>(tile_ptr(k), a_ft0, b_ft0, nfa, nf, wave, lane16, lds0 + k * TN16W_SLOT);
-    if constexpr (PER == 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    TN16_WAIT_VM(3 * PER);
     __builtin_amdgcn_s_barrier();
     for (int k = 0; k < nt; ++k) {
         const unsigned char* slot = lds + (k & (TN16W_NS - 1)) * TN16W_SLOT + lane16;
@@ -273,7 +273,7 @@ __device__ __forceinline__ void tn16w_body(const Wgrad16Args& a, const int32_t* 
             }
         }
         // own DMA of tile k+1 done (k+2, k+3 stay in flight); after the barrier everyone may read it and slot k is free
-        if constexpr (PER == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        TN16_WAIT_VM(2 * PER);
         __builtin_amdgcn_s_barrier();
         tn16w_issue<PER>(tile_ptr(k + TN16W_NS), a_ft0, b_ft0, nfa, nf, wave, lane16, lds0 + (k & (TN16W_NS - 1)) * TN16W_SLOT);
     }
@@ -304,10 +304,14 @@ __global__ __launch_bounds__(512, 2) void k_wgrad16(Wgrad16Args a) {
     const int n_at = job[JOB_N_AT], n_bt = job[JOB_N_BT], WA = job[JOB_WA];
     const int ta = (n_at + WA - 1) / WA, tb = (n_bt + 8 / WA - 1) / (8 / WA);
     if (job[JOB_MBLKN] <= 0) return;
+    // PER = DMA pieces per wave and sample tile = ceil(2 (n_at + n_bt) / 8)
+    const int nf = 2 * (n_at + n_bt);
     if (ta == 2 && tb == 4)      tn16w_body<2, 4, 4>(a, job, lds, lane, wave);      // 8 x 8 tiles: 32 fragments per sample tile
-    else if (ta == 1 && tb == 2) tn16w_body<1, 2, 3>(a, job, lds, lane, wave);      // 8 x 2 (input): 20
+    else if (ta == 1 && tb == 2) { if (nf <= 16) tn16w_body<1, 2, 2>(a, job, lds, lane, wave);       // 4 x 4 (128-wide layers): 16
+                                   else          tn16w_body<1, 2, 3>(a, job, lds, lane, wave); }     // 8 x 2 (input): 20
     else if (ta == 2 && tb == 1) tn16w_body<2, 1, 4>(a, job, lds, lane, wave);
-    else                         tn16w_body<1, 1, 4>(a, job, lds, lane, wave);      // heads 1 x 8: 18; 128-wide layers
+    else { if (nf <= 16)         tn16w_body<1, 1, 2>(a, job, lds, lane, wave);      // 4 x 2 input / 1 x 4 heads of 128-wide nets: 12 / 10
+           else                  tn16w_body<1, 1, 3>(a, job, lds, lane, wave); }    // heads 1 x 8: 18
 }
 
 int tn16_launch_wgrad(const Net16& n, const unsigned char* stash, const int32_t* jobs, int64_t n_jobs, float* slabs, hipStream_t stream) {
