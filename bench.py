@@ -1,28 +1,36 @@
 #!/usr/bin/env python3
 """bench.py — rays/s of the TinyNeRF train step on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--scaling weak|strong]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
+Started from a plain shell with --gpus N > 1, the parent process (before any GPU call) spawns N fresh rank processes
+of itself (tnerf/launch.py: RANK/LOCAL_RANK/WORLD_SIZE, MASTER_ADDR=127.0.0.1, a free MASTER_PORT) and relays rank 0's
+line; under torch.distributed.run the environment is already set and nothing is spawned.
+
 A "step" is one pass of the training hot path over one batch (reference src/train.py:108-128):
-randint pixel indices -> gather rays/targets -> jitter draw -> fused forward (sample, encode, 8x256 MLP,
+randint pixel indices -> rays of those pixels -> jitter draw -> fused forward (sample, encode, 8x256 MLP,
 composite) -> MSE -> backward (dgrad chain, weight-gradient GEMMs, slab reduce) -> [RCCL all-reduce] -> Adam.
 Workload (BASELINE.json configs[1]): 100x100 scene, 106 views, L=6 (39 inputs), 8x256 ReLU MLP skip 4,
-64 samples/ray, 4096 rays per GPU per step, fp32.  Data: seeded synthetic scene (the dataset blob is not
-available offline), resident in HBM before the timed region.  N>1: one process per GPU, each with its own
-4096 rays (weak scaling), one all-reduce(SUM) of the 1.93 MB flat gradient per step.
+64 samples/ray, 4096 rays per GPU per step (weak; --scaling strong: 4096 rays in total), fp32.  Data: seeded
+synthetic scene (the dataset blob is not available offline), resident in HBM before the timed region.  N>1: one
+process per GPU, rays sharded over ranks, one all-reduce(SUM) of the 1.93 MB flat gradient per step.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline     — the dominant kernel's algorithmic FLOP/s against the fp32 MFMA peak (157.3 TFLOP/s),
                  kernel time measured live with HIP events on the launch stream,
   cpu_baseline — the CPU oracle (a port of the reference's fp32 CPU path) timed on this box's host cores on a
-                 bounded sample (rank 0, N=1 only),
+                 bounded sample (rank 0, N=1 only): all cores and one thread,
   kernels / psnr — per-kernel times and the PSNR reached (context, not part of the contract),
-  bf16         — BASELINE.json configs[3]: the same step with bf16 weights/activations on MFMA (fp32 accumulate,
-                 fp32 compositing, fp32 master weights), same data stream: step time, per-kernel times and the
-                 PSNR difference against the fp32 run above.  Context only: the headline stays fp32.
+  rccl_ranks / allreduce — the size of the process group after a real all-reduce and the measured cost of the
+                 gradient all-reduce (N>1, or TNERF_FORCE_DIST=1 with one rank),
+  bf16         — BASELINE.json configs[3]: the same step with bf16 weights/activations on MFMA,
+  ref_default  — the reference's hard-coded model (L=10, 4x128, skip 2, 2048 rays; reference src/train.py:78-79),
+  cfg3 / cfg5  — BASELINE.json configs[2] / [4]: 400x400 S=128 (full-image render + train step) and 800x800 S=256
+                 random-pose render.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -34,27 +42,47 @@ for p in (ROOT, PKG, os.path.join(PKG, "src")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-import numpy as np          # noqa: E402
-import torch                # noqa: E402
-import torch.distributed as dist   # noqa: E402
-
 L_FREQS, HIDDEN, DEPTH, SKIP = 6, 256, 8, 4
 RAYS, SAMPLES, NEAR, FAR, LR = 4096, 64, 2.0, 6.0, 5e-4
 PEAK_F32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: 256 CU x 2.4 GHz x 256 FLOP/clk/CU
 PEAK_BF16_MFMA_TFLOPS = 2516.6      # 16x the fp32 MFMA rate (v_mfma_f32_32x32x16_bf16: 32 cycles per 32768 FLOP per SIMD)
 PEAK_HBM_GBS = 8000.0
-IN_DIM = 6 * L_FREQS + 3
-MACS_PER_SAMPLE = IN_DIM * HIDDEN + (DEPTH - 1) * HIDDEN * HIDDEN + IN_DIM * HIDDEN + 4 * HIDDEN   # 479,744
-FLOPS_FWD_PER_RAY = 2 * MACS_PER_SAMPLE * SAMPLES                                                   # 61,407,232
 
 
-def algorithmic_flops():
-    """Per 4096-ray launch of each MFMA kernel."""
-    m = RAYS * SAMPLES
-    fwd = 2 * MACS_PER_SAMPLE * m
-    dgrad = 2 * ((DEPTH - 1) * HIDDEN * HIDDEN + 4 * HIDDEN) * m       # no gradient flows into the encoder
-    wgrad = 2 * MACS_PER_SAMPLE * m
-    return {"render_fwd": fwd, "train_fwd": fwd, "dgrad": dgrad, "wgrad": wgrad}
+def mlp_macs(in_dim, hidden, depth, skip):
+    """MACs per sample: forward, dgrad (no gradient flows into the encoder), wgrad."""
+    fwd = in_dim * hidden + (depth - 1) * hidden * hidden + (in_dim * hidden if skip else 0) + 4 * hidden
+    dgrad = (depth - 1) * hidden * hidden + 4 * hidden
+    return fwd, dgrad, fwd
+
+
+def algorithmic_flops(rays=RAYS, samples=SAMPLES, in_dim=6 * L_FREQS + 3, hidden=HIDDEN, depth=DEPTH, skip=SKIP):
+    """Per launch of each MFMA kernel."""
+    m = rays * samples
+    f, d, w = mlp_macs(in_dim, hidden, depth, skip)
+    return {"render_fwd": 2 * f * m, "train_fwd": 2 * f * m, "dgrad": 2 * d * m, "wgrad": 2 * w * m}
+
+
+def kernel_source_sha():
+    """Identity of the kernels a PMC capture belongs to: sha256 over csrc/ sources (profiles/*traffic*.json carry it)."""
+    h = hashlib.sha256()
+    d = os.path.join(PKG, "csrc")
+    for n in sorted(os.listdir(d)):
+        if n.endswith((".hip", ".hpp", ".h", ".cpp")):
+            h.update(n.encode()); h.update(open(os.path.join(d, n), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def measured_traffic(name):
+    """HBM bytes per launch from a PMC capture of THIS kernel source (tools/traffic_capture.py writes the file);
+    None when no capture of the current sources is committed — never a number from other kernels."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", name)))
+        if t.get("kernel_source_sha") == kernel_source_sha():
+            return t
+    except (OSError, ValueError):
+        pass
+    return None
 
 
 def host_cores() -> int:
@@ -70,72 +98,109 @@ def host_cores() -> int:
 
 
 def cpu_baseline(scene, seconds_budget=20.0):
-    """CPU oracle (port of the reference's fp32 CPU path) on the same workload, bounded sample."""
+    """CPU oracle (port of the reference's fp32 CPU path) on the same workload, bounded sample: all host cores on whole
+    4096-ray steps, then ONE thread on 512-ray steps (SURVEY §8d CPU protocol)."""
+    import numpy as np
+    import torch
     from oracle import tnerf_oracle as O
-    torch.set_num_threads(host_cores())
-    g = torch.Generator().manual_seed(0)
-    params = O.mlp_init(IN_DIM, HIDDEN, DEPTH, SKIP, g)
-    params[2 * DEPTH + 1] += 0.5                       # sigma bias nudge, as on the GPU side
-    adam = O.AdamState(params, lr=LR)
+    in_dim = 6 * L_FREQS + 3
     images, poses, focal = torch.from_numpy(scene["images"]), torch.from_numpy(scene["poses"]), float(scene["focal"])
     N, H, W, _ = images.shape
     ro_all, rd_all = O.pinhole_rays(H, W, focal, poses[0])
     pix = images[0].reshape(-1, 3)
-    times = []
-    t_start = time.time()
-    for it in range(6):
-        inds = torch.randint(0, H * W, (RAYS,), generator=g)
-        u = torch.rand(RAYS, SAMPLES, generator=g)
-        t0 = time.time()
-        _, _, grads = O.loss_and_grads(params, SKIP, L_FREQS, ro_all[inds], rd_all[inds], pix[inds], NEAR, FAR, SAMPLES, u)
-        adam.step(params, grads)
-        dt = time.time() - t0
-        if it > 0:
-            times.append(dt)
-        if time.time() - t_start > seconds_budget and len(times) >= 2:
-            break
-    med = float(np.median(times))
-    return {"value": RAYS / med, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{len(times)} train steps of {RAYS} rays x {SAMPLES} samples after 1 warm-up (median {med:.2f} s/step), "
-                      f"oracle/tnerf_oracle.py in PyTorch CPU fp32, torch {torch.__version__}"}
+
+    def run(threads, rays, max_iters, budget):
+        torch.set_num_threads(threads)
+        g = torch.Generator().manual_seed(0)
+        params = O.mlp_init(in_dim, HIDDEN, DEPTH, SKIP, g)
+        params[2 * DEPTH + 1] += 0.5                       # sigma bias nudge, as on the GPU side
+        adam = O.AdamState(params, lr=LR)
+        times, t_start = [], time.time()
+        for it in range(max_iters):
+            inds = torch.randint(0, H * W, (rays,), generator=g)
+            u = torch.rand(rays, SAMPLES, generator=g)
+            t0 = time.time()
+            _, _, grads = O.loss_and_grads(params, SKIP, L_FREQS, ro_all[inds], rd_all[inds], pix[inds], NEAR, FAR, SAMPLES, u)
+            adam.step(params, grads)
+            if it > 0:
+                times.append(time.time() - t0)
+            if time.time() - t_start > budget and len(times) >= 2:
+                break
+        return float(np.median(times)), len(times)
+
+    med, n = run(host_cores(), RAYS, 6, seconds_budget)
+    cores = torch.get_num_threads()
+    r1 = 512
+    med1, n1 = run(1, r1, 4, 10.0)
+    torch.set_num_threads(cores)
+    return {"value": RAYS / med, "unit": "rays/s", "cores": cores, "kind": "port",
+            "sample": f"{n} train steps of {RAYS} rays x {SAMPLES} samples after 1 warm-up (median {med:.2f} s/step), "
+                      f"oracle/tnerf_oracle.py in PyTorch CPU fp32, torch {torch.__version__}",
+            "one_thread": {"value": r1 / med1, "unit": "rays/s", "cores": 1,
+                           "sample": f"{n1} train steps of {r1} rays x {SAMPLES} samples after 1 warm-up (median {med1:.2f} s/step)"}}
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: 4096 rays per GPU per step; strong: 4096 rays per step in total (SURVEY §8e)")
+    ap.add_argument("--psnr-steps", type=int, default=1000, help="extra untimed steps before reporting PSNR (rank 0 context)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--philox", action="store_true", help="draw the jitter in-kernel (Philox) instead of torch.rand")
+    ap.add_argument("--no-bf16", action="store_true", help="skip the bf16-mode section (BASELINE.json configs[3])")
+    ap.add_argument("--no-extra", action="store_true", help="skip the ref_default / cfg3 / cfg5 sections")
+    ap.add_argument("--ray-tables", action="store_true",
+                    help="gather rays/targets from precomputed (N,HW,3) tables like the reference loop (train.py:94-112) "
+                         "instead of generating them in the kernel from pose + pixel index")
+    return ap.parse_args(argv)
 
 
 def main():
+    args = parse_args()
+    from tnerf import launch
+    if args.gpus > 1 and not launch.under_launcher():
+        # plain `python bench.py --gpus N`: this parent never touches the GPU; N fresh rank processes do
+        sys.exit(launch.spawn_ranks(args.gpus, [os.path.abspath(__file__), *sys.argv[1:]]))
+    run(args)
+
+
+def run(args):
     # The contract is ONE JSON line on stdout.  Libraries chat on fd 1 (RCCL prints a 5-line version banner at
     # communicator creation): point fd 1 at stderr for the duration of the run and restore it for the final print.
     sys.stdout.flush()
     saved_stdout = os.dup(1)
     os.dup2(2, 1)
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--psnr-steps", type=int, default=1000, help="extra untimed steps before reporting PSNR (rank 0 context)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--philox", action="store_true", help="draw the jitter in-kernel (Philox) instead of torch.rand")
-    ap.add_argument("--no-bf16", action="store_true", help="skip the bf16-mode section (BASELINE.json configs[3])")
-    ap.add_argument("--ray-tables", action="store_true",
-                    help="gather rays/targets from precomputed (N,HW,3) tables like the reference loop (train.py:94-112) "
-                         "instead of generating them in the kernel from pose + pixel index")
-    args = ap.parse_args()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from tnerf import launch
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    rank, local, world = launch.read_env(args.gpus)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    n_dev = torch.cuda.device_count()
+    if local >= n_dev and not os.environ.get("TNERF_SHARE_GPU"):
+        raise SystemExit(f"rank {rank}: LOCAL_RANK={local} but only {n_dev} GPU(s) visible")
+    local_dev = local % n_dev                                             # TNERF_SHARE_GPU=1: rehearse N ranks on fewer cards (gloo)
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     use_dist = world > 1 or bool(os.environ.get("TNERF_FORCE_DIST"))      # the env var exercises RCCL init with one rank
+    backend = os.environ.get("TNERF_DIST_BACKEND", "nccl")                # "nccl" IS RCCL on ROCm
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
+        if "MASTER_PORT" not in os.environ:
+            os.environ["MASTER_PORT"] = str(launch.free_port())          # only reachable with one rank
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from tnerf import ops, trainer, lib
+    from tnerf import dist as tdist
     from data import make_synthetic_scene
     import nerf as nerf_mod
     import train as train_mod
@@ -148,169 +213,204 @@ def main():
     focal = float(scene["focal"])
     N, H, W, _ = images.shape
 
+    # rays of this rank: weak = RAYS each; strong = its shard of RAYS (every rank draws the same global batch)
+    R_global = world * RAYS if args.scaling == "weak" else RAYS
+    lo, hi = tdist.shard_bounds(R_global, rank, world)
+    R_local = hi - lo
+
     encoder = PositionalEncoding(L_FREQS, True).to(dev)
 
-    def make_trainer(precision):
+    def make_trainer(precision, L=L_FREQS, hidden=HIDDEN, depth=DEPTH, skip=SKIP, samples=SAMPLES):
         torch.manual_seed(0)                               # identical initial weights on every rank (and in both modes)
-        mdl = nerf_mod.TinyNeRF(encoder.out_dim, HIDDEN, DEPTH, SKIP).to(dev)
+        mdl = nerf_mod.TinyNeRF(6 * L + 3, hidden, depth, skip).to(dev)
         with torch.no_grad():
             # nn.Linear's default init leaves the sigma head at exactly 0 after its ReLU for this 8x256 model
             # (SURVEY.md §7-7): every weight and every gradient would be a zero and the MFMA kernels would be
             # timed on zeros (which clock higher).  Nudge the bias so the network is alive, as the fixtures do.
             mdl.sigma[0].bias += 0.5
         op = trainer.FlatAdam(mdl, lr=LR)
-        return mdl, op, trainer.FusedTrainer(mdl, op, NEAR, FAR, SAMPLES, precision=precision)
+        return mdl, op, trainer.FusedTrainer(mdl, op, NEAR, FAR, samples, precision=precision)
 
     model, opt, tr = make_trainer("fp32")
 
     import rays as rays_mod
-    all_o, all_d = [], []
-    for i in range(N):                                     # train.py:94-101
-        ro, rd = rays_mod.get_rays(H, W, focal, poses[i])
-        all_o.append(ro); all_d.append(rd)
-    all_o, all_d = torch.stack(all_o), torch.stack(all_d)
+    all_o = all_d = None
+    if args.ray_tables or rank == 0:
+        all_o, all_d = [], []
+        for i in range(N if args.ray_tables else 1):           # train.py:94-101 (rank 0 needs image 0 for the kernel timings)
+            ro, rd = rays_mod.get_rays(H, W, focal, poses[i])
+            all_o.append(ro); all_d.append(rd)
+        all_o, all_d = torch.stack(all_o), torch.stack(all_d)
     pixels = images.view(N, H * W, 3)
     gen = torch.Generator(device=dev); gen.manual_seed(1234)          # same draws on every rank; rank takes its shard
     state = {"step": 0}
-    run = {"tr": tr}
+    run_ = {"tr": tr, "R_global": R_global, "lo": lo, "hi": hi, "S": SAMPLES, "pixels": pixels, "poses": poses, "H": H, "W": W,
+            "focal": focal, "N": N}
 
     def one_step():
-        tr = run["tr"]
+        c = run_
+        tr = c["tr"]
         s = state["step"]; state["step"] += 1
-        img_i = s % N
-        inds = torch.randint(0, H * W, (world * RAYS,), device=dev, generator=gen)[rank * RAYS:(rank + 1) * RAYS]
-        kw = dict(global_rays=world * RAYS)
+        img_i = s % c["N"]
+        Rg, lo, hi, S = c["R_global"], c["lo"], c["hi"], c["S"]
+        inds = torch.randint(0, c["H"] * c["W"], (Rg,), device=dev, generator=gen)[lo:hi]
+        kw = dict(global_rays=Rg)
         if args.philox:
-            kw["philox"] = (1234, s * world * RAYS * SAMPLES + rank * RAYS * SAMPLES)
+            kw["philox"] = (1234, s * Rg * S + lo * S)
         else:
-            kw["t_rand"] = torch.rand(world * RAYS, SAMPLES, device=dev, generator=gen)[rank * RAYS:(rank + 1) * RAYS]
+            kw["t_rand"] = torch.rand(Rg, S, device=dev, generator=gen)[lo:hi]
         if args.ray_tables:
-            return tr.step(all_o[img_i, inds], all_d[img_i, inds], pixels[img_i, inds], **kw)
-        return tr.step_camera(poses[img_i], H, W, focal, inds, pixels[img_i], **kw)
+            return tr.step(all_o[img_i, inds], all_d[img_i, inds], c["pixels"][img_i, inds], **kw)
+        return tr.step_camera(c["poses"][img_i], c["H"], c["W"], c["focal"], inds, c["pixels"][img_i], **kw)
 
     def fence():
         if use_dist:
-            dist.barrier(device_ids=[local])
+            dist.barrier(device_ids=[local_dev]) if backend == "nccl" else dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        one_step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss, _ = one_step()
-    fence()
-    dt = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    ms_per_step = dt / args.steps * 1e3
-    value = world * RAYS * args.steps / dt
-
-    out = {"metric": "rays/s (train step)", "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
-           "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
-           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "config": {"workload": "train step: 100x100 synthetic Lego stand-in, 106 views, L=6 posenc, 8x256 ReLU MLP (skip 4), "
-                                  "64 samples/ray, 4096 rays per GPU per step, Adam, fp32 (BASELINE.json configs[1])",
-                      "rays_per_gpu": RAYS, "samples_per_ray": SAMPLES, "jitter": "philox-in-kernel" if args.philox else "torch.rand", "rays": "precomputed tables + gather" if args.ray_tables else "generated in-kernel from pose + pixel index",
-                      "parallelism": f"rays sharded x{world}, 1 all-reduce of {opt._st.n_params * 4} B per step" if world > 1 else "single GPU"}}
-
-    if rank == 0:
-        # ---- per-kernel times, live, HIP events on the launch stream (torch's current stream)
-        st = model.hip_state(); plan = st.plan(RAYS * SAMPLES)
-        import ctypes as C
-        img_i = 0
-        inds = torch.randint(0, H * W, (RAYS,), device=dev, generator=gen)
-        ro, rd, tgt = all_o[img_i, inds].contiguous(), all_d[img_i, inds].contiguous(), pixels[img_i, inds].contiguous()
-        u = torch.rand(RAYS, SAMPLES, device=dev, generator=gen)
-        ztab = ops.depth_table(NEAR, FAR, SAMPLES, dev)
-        comp = torch.empty(RAYS, 3, device=dev); gws = torch.full((RAYS, 3), 1e-4, device=dev)
-        model._ensure_packed()
-        sp = torch.cuda.current_stream(dev).cuda_stream
-        common = (C.byref(st.desc), st.packed.data_ptr(), ro.data_ptr(), rd.data_ptr(), RAYS, SAMPLES, ztab.data_ptr(), 1, u.data_ptr(), 0, 0, 1)
-        dep = torch.empty(RAYS, 1, device=dev); acc_ = torch.empty(RAYS, 1, device=dev)
-        calls = {
-            "render_fwd": lambda: lib.call("tnerf_render_fused", *common, comp.data_ptr(), dep.data_ptr(), acc_.data_ptr(), sp),
-            "train_fwd": lambda: lib.call("tnerf_train_fwd_fused", *common, comp.data_ptr(), plan.stash.data_ptr(), plan.Mp, sp),
-            "dgrad": lambda: lib.call("tnerf_train_dgrad_fused", *common, gws.data_ptr(), plan.stash.data_ptr(), plan.Mp, sp),
-            "wgrad": lambda: lib.call("tnerf_wgrad", C.byref(st.desc), plan.stash.data_ptr(), plan.Mp, RAYS * SAMPLES, plan.jobs.data_ptr(), plan.n_jobs, plan.slabs.data_ptr(), sp),
-            "reduce": lambda: lib.call("tnerf_wgrad_reduce", plan.slabs.data_ptr(), plan.reduce.data_ptr(), st.n_params, st.grad.data_ptr(), sp),
-        }
-        kern = {}
-        reps = max(5, min(20, args.steps))
-        for name, fn in calls.items():
-            fn(); torch.cuda.synchronize()
-            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
-            for a, b in evs:
-                a.record(); fn(); b.record()
-            torch.cuda.synchronize()
-            kern[name] = float(np.mean([a.elapsed_time(b) for a, b in evs]))          # ms
-        fl = algorithmic_flops()
-        step_kernels = ("train_fwd", "dgrad", "wgrad")
-        dom = max(step_kernels, key=lambda k: kern[k])
-        ach = fl[dom] / (kern[dom] * 1e-3) / 1e12
-        traffic = None
-        try:      # HBM bytes per launch from the committed PMC passes (profiles/r01_traffic.json; see its _note)
-            traffic = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))[dom]["hbm_bytes"]
-        except (OSError, KeyError, ValueError):
-            pass
-        out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                           "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
-                           "flops_per_launch": fl[dom], "ms_per_launch": kern[dom]}
-        out["kernels"] = {k: {"ms": kern[k], "tflops": (fl[k] / (kern[k] * 1e-3) / 1e12) if k in fl else None} for k in kern}
-        step_flops = sum(fl[k] for k in step_kernels)
-        out["step_mfma_frac"] = step_flops / (ms_per_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS
-
-    # ---- PSNR context: keep training (untimed), then report minibatch PSNR and a full-image PSNR
-    if args.psnr_steps > 0:
-        losses = []
-        for i in range(args.psnr_steps):
-            loss, _ = one_step()
-            if i >= args.psnr_steps - 20:
-                losses.append(loss.clone())
-        if rank == 0:
-            mb = float(mse2psnr(torch.stack(losses).mean() * world))          # each rank's loss is 1/world of the global mean
-            img = train_mod.render_one(model, encoder, H, W, focal, poses[N - 1], dev, n_samples=SAMPLES, near=NEAR, far=FAR)
-            full = float(mse2psnr(torch.mean((img - images[N - 1]) ** 2)))
-            out["psnr"] = {"train_minibatch_db": mb, "full_image_view105_db": full, "after_steps": state["step"]}
-
-    # ---- bf16 mode (BASELINE.json configs[3]): same initial weights, same pixel / jitter stream, same step counts
-    if not args.no_bf16:
-        model16, opt16, tr16 = make_trainer("bf16")
-        run["tr"] = tr16
-        gen.manual_seed(1234); state["step"] = 0
-        for _ in range(args.warmup):
+    def timed(n_warm, n_steps):
+        """W untimed steps, then EXACTLY K steps between barrier + synchronize fences; MAX over ranks (seconds)."""
+        for _ in range(n_warm):
             one_step()
         fence()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(n_steps):
             one_step()
         fence()
-        dt16 = time.perf_counter() - t0
+        dt = time.perf_counter() - t0
         if use_dist:
-            t = torch.tensor([dt16], dtype=torch.float64, device=dev)
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt16 = float(t.item())
-        b16 = {"dtype": "bf16 operands, fp32 accumulate / compositing / master weights", "ms_per_step": dt16 / args.steps * 1e3,
-               "value": world * RAYS * args.steps / dt16, "unit": "rays/s", "speedup_vs_fp32_step": dt / dt16}
-        if rank == 0:
-            import ctypes as C
-            st = model16.hip_state(); b = st.repack_bf16(); bp = b.train_plan(RAYS, SAMPLES)
-            inds = torch.randint(0, H * W, (RAYS,), device=dev, generator=gen)
-            ro, rd = all_o[0, inds].contiguous(), all_d[0, inds].contiguous()
-            u = torch.rand(RAYS, SAMPLES, device=dev, generator=gen)
-            ztab = ops.depth_table(NEAR, FAR, SAMPLES, dev)
-            comp = torch.empty(RAYS, 3, device=dev); gws = torch.full((RAYS, 3), 1e-4, device=dev)
-            dep = torch.empty(RAYS, 1, device=dev); acc_ = torch.empty(RAYS, 1, device=dev)
-            sp = torch.cuda.current_stream(dev).cuda_stream
-            common = (C.byref(st.desc), b.packed.data_ptr(), ro.data_ptr(), rd.data_ptr(), RAYS, SAMPLES, ztab.data_ptr(), 1, u.data_ptr(), 0, 0, 1)
+            dt = float(t.item())
+        return dt
+
+    def event_ms(fn, reps):
+        fn(); torch.cuda.synchronize()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        for a, b in evs:
+            a.record(); fn(); b.record()
+        torch.cuda.synchronize()
+        return float(np.mean([a.elapsed_time(b) for a, b in evs]))
+
+    dt = timed(args.warmup, args.steps)
+    ms_per_step = dt / args.steps * 1e3
+    value = R_global * args.steps / dt
+
+    out = {"metric": "rays/s (train step)", "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling,
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "train step: 100x100 synthetic Lego stand-in, 106 views, L=6 posenc, 8x256 ReLU MLP (skip 4), "
+                                  f"64 samples/ray, {'4096 rays per GPU' if args.scaling == 'weak' else '4096 rays in total'} per step, "
+                                  "Adam, fp32 (BASELINE.json configs[1])",
+                      "rays_per_step_global": R_global, "rays_per_gpu": R_local, "samples_per_ray": SAMPLES,
+                      "jitter": "philox-in-kernel" if args.philox else "torch.rand",
+                      "rays": "precomputed tables + gather" if args.ray_tables else "generated in-kernel from pose + pixel index",
+                      "parallelism": f"rays sharded x{world} ({args.scaling}), 1 all-reduce of {opt._st.n_params * 4} B per step" if world > 1 else "single GPU"}}
+
+    # ---- the exchange step on its own: group size after a real all-reduce, and what the all-reduce costs per step
+    if use_dist:
+        g = model.hip_state().grad
+        probe = torch.ones(1, device=dev)
+        dist.all_reduce(probe)
+        out["rccl_ranks"] = int(round(float(probe.item())))              # every rank contributed a 1
+        out["dist_backend"] = "rccl (torch.distributed nccl)" if backend == "nccl" else backend
+        keep = g.clone()
+        fence()
+        ar_ms = event_ms(lambda: dist.all_reduce(g), 50)
+        g.copy_(keep)
+        t = torch.tensor([ar_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        out["allreduce"] = {"bytes": int(g.numel() * 4), "us_per_step": float(t.item()) * 1e3, "ranks": dist.get_world_size(),
+                            "how": "50 back-to-back all-reduces of the flat gradient between HIP events, max over ranks"}
+    else:
+        out["rccl_ranks"] = 1
+
+    def kernel_section(st, R, S, precision):
+        """Per-kernel times (HIP events on the launch stream = torch's current stream) of the fused step's kernels."""
+        import ctypes as C
+        inds = torch.randint(0, H * W, (R,), device=dev, generator=gen)
+        ro, rd = all_o[0, inds].contiguous(), all_d[0, inds].contiguous()
+        u = torch.rand(R, S, device=dev, generator=gen)
+        ztab = ops.depth_table(NEAR, FAR, S, dev)
+        comp = torch.empty(R, 3, device=dev); gws = torch.full((R, 3), 1e-4, device=dev)
+        dep = torch.empty(R, 1, device=dev); acc_ = torch.empty(R, 1, device=dev)
+        sp = torch.cuda.current_stream(dev).cuda_stream
+        reps = max(5, min(20, args.steps))
+        if precision == "fp32":
+            plan = st.plan(R * S)
+            common = (C.byref(st.desc), st.packed.data_ptr(), ro.data_ptr(), rd.data_ptr(), R, S, ztab.data_ptr(), 1, u.data_ptr(), 0, 0, 1)
+            calls = {
+                "render_fwd": lambda: lib.call("tnerf_render_fused", *common, comp.data_ptr(), dep.data_ptr(), acc_.data_ptr(), sp),
+                "train_fwd": lambda: lib.call("tnerf_train_fwd_fused", *common, comp.data_ptr(), plan.stash.data_ptr(), plan.Mp, sp),
+                "dgrad": lambda: lib.call("tnerf_train_dgrad_fused", *common, gws.data_ptr(), plan.stash.data_ptr(), plan.Mp, sp),
+                "wgrad": lambda: lib.call("tnerf_wgrad", C.byref(st.desc), plan.stash.data_ptr(), plan.Mp, R * S, plan.jobs.data_ptr(), plan.n_jobs, plan.slabs.data_ptr(), sp),
+                "reduce": lambda: lib.call("tnerf_wgrad_reduce", plan.slabs.data_ptr(), plan.reduce.data_ptr(), st.n_params, st.grad.data_ptr(), sp),
+            }
+        else:
+            b = st.repack_bf16(); bp = b.train_plan(R, S)
+            common = (C.byref(st.desc), b.packed.data_ptr(), ro.data_ptr(), rd.data_ptr(), R, S, ztab.data_ptr(), 1, u.data_ptr(), 0, 0, 1)
             calls = {
                 "render_fwd": lambda: lib.call("tnerf_render_fused_bf16", *common, comp.data_ptr(), dep.data_ptr(), acc_.data_ptr(), sp),
                 "train_fwd": lambda: lib.call("tnerf_train_fwd_fused_bf16", *common, comp.data_ptr(), bp.stash.data_ptr(), sp),
                 "dgrad": lambda: lib.call("tnerf_train_dgrad_fused_bf16", *common, gws.data_ptr(), bp.stash.data_ptr(), sp),
                 "wgrad": lambda: lib.call("tnerf_wgrad_bf16", C.byref(st.desc), bp.stash.data_ptr(), bp.n_tiles, bp.jobs.data_ptr(), bp.n_jobs, bp.slabs.data_ptr(), sp),
             }
+        return {name: event_ms(fn, reps) for name, fn in calls.items()}
+
+    if rank == 0:
+        # ---- per-kernel times, live, HIP events on the launch stream (torch's current stream)
+        model._ensure_packed()
+        kern = kernel_section(model.hip_state(), RAYS, SAMPLES, "fp32")
+        fl = algorithmic_flops()
+        step_kernels = ("train_fwd", "dgrad", "wgrad")
+        dom = max(step_kernels, key=lambda k: kern[k])
+        ach = fl[dom] / (kern[dom] * 1e-3) / 1e12
+        cap = measured_traffic("r02_traffic.json")
+        out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                           "frac": ach / PEAK_F32_MFMA_TFLOPS,
+                           "traffic": cap[dom]["hbm_bytes"] if cap and dom in cap else None,
+                           "traffic_source": f"profiles/r02_traffic.json (PMC passes on kernel sources {cap['kernel_source_sha']})" if cap and dom in cap else None,
+                           "flops_per_launch": fl[dom], "ms_per_launch": kern[dom]}
+        out["kernels"] = {k: {"ms": kern[k], "tflops": (fl[k] / (kern[k] * 1e-3) / 1e12) if k in fl else None,
+                              "mfma_frac": (fl[k] / (kern[k] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS) if k in fl else None} for k in kern}
+        if args.scaling == "weak" or world == 1:
+            step_flops = sum(fl[k] for k in step_kernels)
+            out["step_mfma_frac"] = step_flops / (ms_per_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS
+            out["step_minus_big3_us"] = (ms_per_step - sum(kern[k] for k in step_kernels)) * 1e3
+
+    def psnr_block(mdl, extra=None):
+        """Keep training (untimed), then minibatch PSNR and a held-out full-image PSNR (rank 0)."""
+        losses = []
+        for i in range(args.psnr_steps):
+            loss, _ = one_step()
+            if i >= args.psnr_steps - 20:
+                losses.append(loss.clone())
+        mb = torch.stack(losses).mean()
+        if use_dist:
+            dist.all_reduce(mb)                                     # each rank's loss is its shard's share of the global mean
+        if rank != 0:
+            return None
+        img = train_mod.render_one(mdl, encoder, H, W, focal, poses[N - 1], dev, n_samples=SAMPLES, near=NEAR, far=FAR)
+        full = float(mse2psnr(torch.mean((img - images[N - 1]) ** 2)))
+        return {"train_minibatch_db": float(mse2psnr(mb)), "full_image_view105_db": full, "after_steps": state["step"]}, img
+
+    # ---- PSNR context
+    if args.psnr_steps > 0:
+        r = psnr_block(model)
+        if r:
+            out["psnr"] = r[0]; img_f32 = r[1]
+
+    # ---- bf16 mode (BASELINE.json configs[3]): same initial weights, same pixel / jitter stream, same step counts
+    if not args.no_bf16:
+        model16, opt16, tr16 = make_trainer("bf16")
+        run_["tr"] = tr16
+        gen.manual_seed(1234); state["step"] = 0
+        dt16 = timed(args.warmup, args.steps)
+        b16 = {"dtype": "bf16 operands, fp32 accumulate / compositing / master weights", "ms_per_step": dt16 / args.steps * 1e3,
+               "value": R_global * args.steps / dt16, "unit": "rays/s", "speedup_vs_fp32_step": dt / dt16}
+        if rank == 0:
+            st = model16.hip_state()
+            k16 = kernel_section(st, RAYS, SAMPLES, "bf16")
             fl = algorithmic_flops()
             # algorithmic HBM bytes of the stash streams (DESIGN.md §11): 2 KB per (32-sample tile, 32-feature tile) of bf16
             # activations / activation gradients; the forward also writes the ReLU bits and the head outputs
@@ -320,47 +420,119 @@ def main():
             hbm = {"train_fwd": tiles * ((2 + DEPTH * NT) * 2048 + DEPTH * (HIDDEN // 64) * 256 + 512),
                    "dgrad": tiles * (DEPTH * NT + 1) * 2048,
                    "wgrad": tiles * wg_tiles * 2048}
-            try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic_bf16.json")))
-            except (OSError, ValueError):
-                pmc = {}
+            cap16 = measured_traffic("r02_traffic_bf16.json") or {}
             kern16 = {}
-            for name, fn in calls.items():
-                fn(); torch.cuda.synchronize()
-                evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
-                for a_, b_ in evs:
-                    a_.record(); fn(); b_.record()
-                torch.cuda.synchronize()
-                ms = float(np.mean([a_.elapsed_time(b_) for a_, b_ in evs]))
-                kern16[name] = {"ms": ms, "tflops": fl[name] / (ms * 1e-3) / 1e12,
-                                "mfma_frac": fl[name] / (ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS}
+            for name, ms in k16.items():
+                kern16[name] = {"ms": ms, "tflops": fl[name] / (ms * 1e-3) / 1e12, "mfma_frac": fl[name] / (ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS}
                 if name in hbm:
-                    kern16[name]["algorithmic_hbm_bytes"] = hbm[name]
-                    kern16[name]["hbm_gbs"] = hbm[name] / (ms * 1e-3) / 1e9
-                    kern16[name]["hbm_frac"] = hbm[name] / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS
-                    kern16[name]["traffic"] = pmc.get(name, {}).get("hbm_bytes")
+                    kern16[name].update(algorithmic_hbm_bytes=hbm[name], hbm_gbs=hbm[name] / (ms * 1e-3) / 1e9,
+                                        hbm_frac=hbm[name] / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                                        traffic=cap16.get(name, {}).get("hbm_bytes") if isinstance(cap16.get(name), dict) else None)
             b16["kernels"] = kern16
             b16["roofline"] = {"bound": "hbm", "kernel": "wgrad", "achieved": kern16["wgrad"]["hbm_gbs"], "peak": PEAK_HBM_GBS,
                                "unit": "GB/s", "frac": kern16["wgrad"]["hbm_frac"], "traffic": kern16["wgrad"]["traffic"]}
+            if args.scaling == "weak" or world == 1:
+                b16["step_minus_big3_us"] = (b16["ms_per_step"] - sum(k16[k] for k in ("train_fwd", "dgrad", "wgrad"))) * 1e3
         if args.psnr_steps > 0:
-            losses = []
-            for i in range(args.psnr_steps):
-                loss, _ = one_step()
-                if i >= args.psnr_steps - 20:
-                    losses.append(loss.clone())
-            if rank == 0:
-                mb = float(mse2psnr(torch.stack(losses).mean() * world))
-                img = train_mod.render_one(model16, encoder, H, W, focal, poses[N - 1], dev, n_samples=SAMPLES, near=NEAR, far=FAR)
-                full = float(mse2psnr(torch.mean((img - images[N - 1]) ** 2)))
+            r = psnr_block(model16)
+            if r:
+                p16, img = r
                 st16 = model16._ensure_packed()
                 img16 = ops.render_camera_fused_bf16(st16, poses[N - 1], H, W, focal, 0, H * W, NEAR, FAR, SAMPLES)[0].reshape(H, W, 3).clamp(0, 1)
-                b16["psnr"] = {"train_minibatch_db": mb, "full_image_view105_db": full, "after_steps": state["step"],
-                               "full_image_rendered_in_bf16_db": float(mse2psnr(torch.mean((img16 - images[N - 1]) ** 2))),
-                               "max_abs_rgb_bf16_vs_fp32_render": float((img16 - img).abs().max())}
+                p16.update(full_image_rendered_in_bf16_db=float(mse2psnr(torch.mean((img16 - images[N - 1]) ** 2))),
+                           max_abs_rgb_bf16_vs_fp32_render=float((img16 - img).abs().max()))
                 if "psnr" in out:
-                    b16["psnr"]["delta_full_image_db_vs_fp32"] = full - out["psnr"]["full_image_view105_db"]
+                    p16["delta_full_image_db_vs_fp32"] = p16["full_image_view105_db"] - out["psnr"]["full_image_view105_db"]
+                b16["psnr"] = p16
         out["bf16"] = b16
-        run["tr"] = tr
+        run_["tr"] = tr
+        del model16, opt16, tr16
+
+    # ---- the other shapes of BASELINE.json / the reference, driver-visible (context; every rank takes part when N > 1)
+    if not args.no_extra:
+        def section(fn):
+            try:
+                return fn()
+            except Exception as e:                                   # a context section must not take the contract line down
+                return {"error": f"{type(e).__name__}: {e}"}
+
+        def train_shape(L, hidden, depth, skip, rays, samples, scene_t, steps, warm):
+            """ms/step of the fused train step for another (model, batch) shape, fp32 and bf16, this rank's share."""
+            res = {}
+            imgs, pss, fc = scene_t
+            n, h, w, _ = imgs.shape
+            Rg = world * rays if args.scaling == "weak" else rays
+            l0, h0 = tdist.shard_bounds(Rg, rank, world)
+            for prec in ("fp32", "bf16"):
+                mdl, op, t_ = make_trainer(prec, L, hidden, depth, skip, samples)
+                run_.update(tr=t_, R_global=Rg, lo=l0, hi=h0, S=samples, pixels=imgs.view(n, h * w, 3), poses=pss, H=h, W=w, focal=fc, N=n)
+                d_ = timed(warm, steps)
+                f, dg, wg = mlp_macs(6 * L + 3, hidden, depth, skip)
+                flops = 2 * (f + dg + wg) * (h0 - l0) * samples
+                peak = PEAK_F32_MFMA_TFLOPS if prec == "fp32" else PEAK_BF16_MFMA_TFLOPS
+                res[prec] = {"ms_per_step": d_ / steps * 1e3, "rays_per_s": Rg * steps / d_,
+                             "mfma_frac": flops / (d_ / steps) / 1e12 / peak}
+                del mdl, op, t_
+            run_.update(tr=tr, R_global=R_global, lo=lo, hi=hi, S=SAMPLES, pixels=pixels, poses=poses, H=H, W=W, focal=focal, N=N)
+            return res
+
+        def render_shape(mdl, enc, h, w, fc, pose_list, samples, prec):
+            """Full-image render (render_one_sharded: pixels sharded over ranks, all-gathered), rays/s over all poses."""
+            train_mod.render_one_sharded(mdl, enc, h, w, fc, pose_list[0], dev, n_samples=samples, near=NEAR, far=FAR, precision=prec)
+            fence()
+            t0 = time.perf_counter()
+            for p_ in pose_list:
+                img_ = train_mod.render_one_sharded(mdl, enc, h, w, fc, p_, dev, n_samples=samples, near=NEAR, far=FAR, precision=prec)
+            fence()
+            d_ = time.perf_counter() - t0
+            if use_dist:
+                t = torch.tensor([d_], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                d_ = float(t.item())
+            rays_s = h * w * len(pose_list) / d_
+            f, _, _ = mlp_macs(enc.out_dim, mdl.hidden, mdl.depth, mdl.skip_at)
+            peak = PEAK_F32_MFMA_TFLOPS if prec == "fp32" else PEAK_BF16_MFMA_TFLOPS
+            return {"ms_per_image": d_ / len(pose_list) * 1e3, "rays_per_s": rays_s, "images": len(pose_list),
+                    "mfma_frac": 2 * f * samples * rays_s / world / 1e12 / peak,
+                    "hbm_frac": 12.0 * rays_s / world / 1e9 / PEAK_HBM_GBS, "finite": bool(torch.isfinite(img_).all())}
+
+        scene_t = (images, poses, focal)
+        # the reference's own hard-coded model and batch (reference src/train.py:23,78-79): L=10, 4x128, skip 2, 2048 rays
+        out["ref_default"] = section(lambda: dict(
+            workload="train step: reference default model L=10 (63 inputs), 4x128 skip 2, 2048 rays x 64 samples, 100x100 scene",
+            **train_shape(10, 128, 4, 2, 2048, 64, scene_t, max(20, args.steps), 10)))
+
+        def cfg3():
+            sc = make_synthetic_scene(n_images=8, H=400, W=400, focal=4 * 138.88887889922103, seed=0)
+            st_ = (torch.from_numpy(sc["images"]).to(dev), torch.from_numpy(sc["poses"]).to(dev), float(sc["focal"]))
+            r = {"workload": "400x400 analytic re-render of the synthetic scene (8 views), 128 samples/ray, 8x256 L=6: train step of 4096 "
+                             "rays per GPU and full-image render of 160,000 rays sharded over the ranks (BASELINE.json configs[2])"}
+            r["train"] = train_shape(L_FREQS, HIDDEN, DEPTH, SKIP, RAYS, 128, st_, 10, 3)
+            r["render"] = {p_: render_shape(model, encoder, 400, 400, st_[2], [st_[1][i] for i in range(2)], 128, p_) for p_ in ("fp32", "bf16")}
+            return r
+        out["cfg3"] = section(cfg3)
+
+        def cfg5():
+            g5 = torch.Generator().manual_seed(5)
+            ps = []
+            for _ in range(8):                                       # SURVEY §8d cfg 5: seeded QR of N(0,1) 3x3, det +1, origin on the radius-4 sphere
+                q, r_ = torch.linalg.qr(torch.randn(3, 3, generator=g5))
+                q = q * torch.sign(torch.diagonal(r_))
+                if torch.det(q) < 0:
+                    q[:, 2] = -q[:, 2]
+                o = torch.nn.functional.normalize(torch.randn(3, generator=g5), dim=0) * 4.0
+                m = torch.eye(4); m[:3, :3] = q; m[:3, 3] = o
+                ps.append(m.to(dev))
+            torch.manual_seed(0)
+            m5 = nerf_mod.TinyNeRF(encoder.out_dim, HIDDEN, DEPTH, SKIP).to(dev)
+            with torch.no_grad():
+                m5.sigma[0].bias += 0.5
+            return {"workload": "800x800, 256 samples/ray, random poses, seed-0 weights with sigma bias +0.5, render only, 640,000 rays "
+                                "per image sharded over the ranks (BASELINE.json configs[4]); the fused kernel moves 12 B/ray of HBM, so "
+                                "the bound is MFMA, not HBM",
+                    "render": {"fp32": render_shape(m5, encoder, 800, 800, 4 * 138.88887889922103 * 2, ps[:2], 256, "fp32"),
+                               "bf16": render_shape(m5, encoder, 800, 800, 4 * 138.88887889922103 * 2, ps, 256, "bf16")}}
+        out["cfg5"] = section(cfg5)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(scene)

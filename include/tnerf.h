@@ -113,6 +113,15 @@ int tnerf_sample_encode_fwd(const float* rays_o, const float* rays_d, int64_t n_
                             float* enc, int32_t num_freqs, int32_t include_input,
                             tnerf_stream_t stream);
 
+/* stratified_samples with PER-RAY near / far ("tensors broadcastable to (N_rays, 1)", src/sampling.py:8,17).
+ * t_tab: device copy of tnerf_sample_tables' t_out (the fp32 torch.linspace(0,1,S)); near, far: [R] device floats.
+ * Bins of ray r: near_r*(1-t_i) + far_r*t_i, rounded op by op like the reference's broadcast; jitter as above.
+ * Outputs (one may be NULL): z_vals [R,S], pts [R,S,3]. */
+int tnerf_sample_per_ray_fwd(const float* rays_o, const float* rays_d, int64_t n_rays, int32_t n_samples,
+                             const float* t_tab, const float* near, const float* far,
+                             int32_t randomized, const float* t_rand, uint64_t philox_seed, uint64_t philox_offset,
+                             float* z_vals, float* pts, tnerf_stream_t stream);
+
 /* PositionalEncoding.forward on arbitrary points x [n,3] -> out [n, 6L(+3)]   [src/encoding.py:21-33] */
 int tnerf_posenc_fwd(const float* x, int64_t n, int32_t num_freqs, int32_t include_input,
                      float* out, tnerf_stream_t stream);

@@ -53,19 +53,38 @@ def pinhole_rays(H: int, W: int, focal: float, c2w: Tensor) -> Tuple[Tensor, Ten
     return rays_o, rays_d
 
 
+# ------------------------------------------------------------------- novel views
+def spiral_poses(c2w_ref: Tensor, n_frames: int = 60, radius: float = 0.3) -> Tensor:
+    """Camera path of the GIF: frame k is the reference pose moved by (radius cos a_k, radius sin a_k, 0) in its OWN
+    frame, a = linspace(0, 2 pi, n_frames) — both end points included, so the last frame repeats the first.
+    [src/camera.py:4-12]   Returns (n_frames, 4, 4)."""
+    frames = []
+    for a in torch.linspace(0, 2 * math.pi, n_frames):               # camera.py:7
+        shift = torch.eye(4, dtype=c2w_ref.dtype)
+        shift[:3, 3] = torch.tensor([radius * torch.cos(a), radius * torch.sin(a), 0.0], dtype=c2w_ref.dtype)   # camera.py:8-10
+        frames.append(c2w_ref @ shift)                               # camera.py:11
+    return torch.stack(frames, dim=0)
+
+
+def deal_frames(n_frames: int, rank: int, world: int) -> List[int]:
+    """Pose-parallel dealing of the novel-view frames (new): rank r renders frames r, r+world, ..."""
+    return list(range(rank, n_frames, world))
+
+
 # ----------------------------------------------------------------------- sampling
-def depth_bins(near: float, far: float, n_samples: int) -> Tensor:
+def depth_bins(near, far, n_samples: int) -> Tensor:
     """Un-jittered depths z_i = near(1-t_i) + far t_i, t = linspace(0,1,S).  [src/sampling.py:16-17]"""
     t = torch.linspace(0.0, 1.0, steps=n_samples)
     return near * (1.0 - t) + far * t
 
 
-def stratified(near: float, far: float, n_samples: int, rays_o: Tensor, rays_d: Tensor,
+def stratified(near, far, n_samples: int, rays_o: Tensor, rays_d: Tensor,
                t_rand: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
     """Depths + 3-D points along each ray.   [src/sampling.py:3-28]
 
     `t_rand` (R,S) in [0,1) replaces the reference's `torch.rand_like` draw
-    (sampling.py:24); None means randomized=False (sampling.py:20).
+    (sampling.py:24); None means randomized=False (sampling.py:20).  near / far: floats or
+    tensors broadcastable to (R,1) (sampling.py:8).
     """
     R = rays_o.shape[0]
     z = depth_bins(near, far, n_samples).expand(R, n_samples)

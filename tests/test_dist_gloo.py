@@ -3,6 +3,7 @@ single-process result.  The per-rank compute engine here is the
 engine is the HIP library; what is under test is the sharding / normalisation / all-reduce / gather logic
 of tiny-nerf-pytorch_amd/tnerf/dist.py that both share."""
 import os
+import sys
 import socket
 
 import pytest
@@ -87,3 +88,107 @@ def test_two_ranks_reproduce_single_process(tmp_path):
     assert abs(r["loss"] - r["loss_full"]) <= 1e-6 * r["loss_full"]
     assert r["same"]                                # parameters stay identical across ranks
     assert r["render"] <= 1e-6
+
+
+# ------------------------------------------------------------------------ round 2: launcher + dealing
+def test_round_robin_dealing_of_novel_view_frames():
+    """make_gif's pose-parallel dealing against the oracle's statement of it, and its inverse."""
+    for n in (0, 1, 7, 60):
+        for ws in (1, 2, 3, 8):
+            parts = [tdist.deal_round_robin(n, r, ws) for r in range(ws)]
+            assert parts == [O.deal_frames(n, r, ws) for r in range(ws)]
+            assert tdist.merge_round_robin([[f"f{k}" for k in p] for p in parts], n) == [f"f{k}" for k in range(n)]
+
+
+def test_rank_env_and_free_port():
+    from tnerf import launch
+    p1, p2 = launch.free_port(), launch.free_port()
+    assert 1024 <= p1 < 65536 and 1024 <= p2 < 65536
+    env = launch.rank_env(2, 4, p1, base={"PATH": "/bin", "RANK": "9"})
+    assert (env["RANK"], env["LOCAL_RANK"], env["WORLD_SIZE"], env["MASTER_ADDR"], env["MASTER_PORT"]) == ("2", "2", "4", "127.0.0.1", str(p1))
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and env["PATH"] == "/bin" and env["TNERF_SPAWNED"] == "1"
+    assert launch.under_launcher(env) and not launch.under_launcher({"PATH": "/bin"})
+    with pytest.raises(ValueError):
+        launch.rank_env(4, 4, p1)
+    with pytest.raises(ValueError):
+        launch.rank_env(0, 1, 0)
+
+
+_RANK_SCRIPT = r'''
+import json, os, sys
+import torch, torch.distributed as dist
+dist.init_process_group("gloo")          # env:// rendezvous from what spawn_ranks set
+t = torch.tensor([float(dist.get_rank() + 1)])
+dist.all_reduce(t)
+fail = int(sys.argv[2]) if len(sys.argv) > 2 else -1
+if dist.get_rank() == fail:
+    sys.exit(7)
+if dist.get_rank() == 0:
+    print(json.dumps({"sum": float(t), "world": dist.get_world_size(), "port": os.environ["MASTER_PORT"], "tag": sys.argv[1]}), flush=True)
+else:
+    print("noise from a non-zero rank must not reach stdout")
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.timeout(600)
+def test_spawn_ranks_relays_rank0_and_propagates_failure(tmp_path):
+    """`python bench.py --gpus N` / `python src/train.py --gpus N` from a plain shell go through launch.spawn_ranks: N fresh
+    processes with the torch.distributed environment, only rank 0 on stdout, a failing rank fails the job."""
+    import json, subprocess, sys, textwrap
+    from tnerf import launch
+    script = tmp_path / "rank.py"
+    script.write_text(_RANK_SCRIPT)
+    driver = textwrap.dedent(f"""
+        import sys
+        sys.path.insert(0, {os.path.dirname(os.path.dirname(launch.__file__))!r})
+        from tnerf import launch
+        sys.exit(launch.spawn_ranks(int(sys.argv[1]), [{str(script)!r}, *sys.argv[2:]], timeout=300))
+    """)
+    env = {k: v for k, v in os.environ.items() if k not in launch.ENV_KEYS}
+    r = subprocess.run([sys.executable, "-c", driver, "3", "hello"], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert not any("noise" in ln for ln in lines), lines           # only rank 0 owns stdout (gloo's own banner may precede its line)
+    out = json.loads(lines[-1])
+    assert out["sum"] == 6.0 and out["world"] == 3 and out["tag"] == "hello" and int(out["port"]) > 0
+    r = subprocess.run([sys.executable, "-c", driver, "2", "x", "1"], capture_output=True, text=True, env=env)
+    assert r.returncode == 7                                       # rank 1 exits 7 -> the job fails with its code
+
+
+def test_bench_and_train_cli_spawn_before_touching_the_gpu():
+    """bench.py / train.py with --gpus N from a plain shell must reach spawn_ranks (never init_process_group in the parent);
+    under a launcher they must not spawn again."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    from tnerf import launch
+    calls = []
+    orig_spawn, orig_run, orig_argv = launch.spawn_ranks, bench.run, sys.argv
+    saved = {k: os.environ.pop(k) for k in list(os.environ) if k in launch.ENV_KEYS}
+    try:
+        launch.spawn_ranks = lambda n, argv, **kw: calls.append(("spawn", n, list(argv))) or 0
+        bench.run = lambda args: calls.append(("run", args.gpus, args.scaling))
+        sys.argv = ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1", "--scaling", "strong"]
+        with pytest.raises(SystemExit) as e:
+            bench.main()
+        assert e.value.code == 0 and calls[-1][0] == "spawn" and calls[-1][1] == 4
+        assert calls[-1][2][0].endswith("bench.py") and calls[-1][2][1:] == sys.argv[1:]
+        os.environ.update(RANK="1", WORLD_SIZE="4", LOCAL_RANK="1")        # as a spawned / torchrun rank: run, do not spawn
+        bench.main()
+        assert calls[-1] == ("run", 4, "strong")
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+            os.environ.pop(k)
+        sys.argv = ["bench.py"]                                           # the driver's N=1 form
+        bench.main()
+        assert calls[-1] == ("run", 1, "weak")
+        assert launch.read_env(1) == (0, 0, 1)
+        os.environ.update(RANK="0", WORLD_SIZE="2")
+        with pytest.raises(SystemExit):
+            launch.read_env(4)                                            # --gpus disagrees with the launcher
+    finally:
+        launch.spawn_ranks, bench.run, sys.argv = orig_spawn, orig_run, orig_argv
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+            os.environ.pop(k, None)
+        os.environ.update(saved)

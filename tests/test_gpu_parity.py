@@ -259,7 +259,7 @@ def test_train_gradients_match_oracle(mods, dev, tag):
     worst_hip = max(relmax(p.grad.cpu().double(), gg) for p, gg in zip(plist, g64))
     worst_cpu = max(relmax(go.double(), gg) for go, gg in zip(grads_o, g64))
     print(f"[{tag}] grad rel err vs fp64: hip {worst_hip:.2e}, cpu-fp32 oracle {worst_cpu:.2e}")
-    assert worst_hip <= 4.0 * worst_cpu + 1e-5, (worst_hip, worst_cpu)
+    assert worst_hip <= 2.0 * worst_cpu + 1e-5, (worst_hip, worst_cpu)
     worst = max(relmax(p.grad.cpu(), go) for p, go in zip(plist, grads_o))
     assert worst <= 1e-2, worst                      # fp32 HIP vs fp32 oracle directly (each ~2e-3 from fp64)
     gn = torch.stack([p.grad.norm().cpu() for p in plist])
@@ -374,7 +374,8 @@ def test_fused_ragged_shapes_forward_and_gradients(mods, dev, tag, R, S):
     _, _, g64 = O.loss_and_grads([p.double() for p in params], cfg["skip_at"], cfg["L"], o.double(), d.double(), tgt.double(), 2.0, 6.0, S, u.double())
     e_hip = max(relmax(p.grad.cpu().double(), gg) for p, gg in zip(plist, g64))
     e_cpu = max(relmax(a.double(), gg) for a, gg in zip(g32, g64))
-    assert e_hip <= 8.0 * e_cpu + 2e-5, (e_hip, e_cpu)      # fp32 vs fp32, both judged against fp64
+    print(f"[{tag} R={R} S={S}] grad rel err vs fp64: hip {e_hip:.2e}, cpu-fp32 oracle {e_cpu:.2e}")
+    assert e_hip <= 2.0 * e_cpu + 2e-5, (e_hip, e_cpu)      # fp32 vs fp32, both judged against fp64
 
 
 def test_deterministic_render_of_large_sample_counts(mods, dev):
@@ -679,39 +680,44 @@ def test_bf16_train_large_batch_camera_and_determinism(mods, dev):
 
 
 def test_bf16_trainer_tracks_fp32_training(mods, dev):
-    """FusedTrainer(precision='bf16') against the fp32 trainer on the same data stream: the held-out PSNR after 300
-    steps agrees closely (SURVEY.md 8d cfg 4 asks |dPSNR| <= 0.1 dB at 2000 steps; tools/bf16_psnr_probe.py measures
-    that protocol, DESIGN.md quotes it)."""
+    """SURVEY.md 8d cfg 4's protocol: the BASELINE model (8x256, L=6, skip 4), 4096 rays x 64 samples, 2000 steps from the
+    same init on the same pixel / jitter stream in fp32 and in bf16 mode; |dPSNR| <= 0.1 dB on held-out views (8 poses of the
+    scene that are not in the training set, mean PSNR) and max |dRGB| <= 2e-2 between the bf16 and the fp32 render of
+    identical weights."""
     from data import make_synthetic_scene
     trainer, train_mod = mods["trainer"], mods["train"]
     scene = make_synthetic_scene(seed=0)
+    held = make_synthetic_scene(n_images=8, seed=1)                  # other cameras on the same scene
     images = torch.from_numpy(scene["images"]).to(dev); poses = torch.from_numpy(scene["poses"]).to(dev); focal = float(scene["focal"])
+    h_images = torch.from_numpy(held["images"]).to(dev); h_poses = torch.from_numpy(held["poses"]).to(dev)
     N, H, W, _ = images.shape
     pixels = images.view(N, H * W, 3)
     enc = mods["encoding"].PositionalEncoding(6, True).to(dev)
-    out = {}
+    out, worst_rgb = {}, 0.0
     for prec in ("fp32", "bf16"):
         torch.manual_seed(0)
-        model = mods["nerf"].TinyNeRF(39, 128, 4, 2).to(dev)
+        model = mods["nerf"].TinyNeRF(39, 256, 8, 4).to(dev)
         with torch.no_grad():
             model.sigma[0].bias += 0.5
         opt = trainer.FlatAdam(model, lr=5e-4)
         tr = trainer.FusedTrainer(model, opt, 2.0, 6.0, 64, precision=prec)
         gen = torch.Generator(device=dev); gen.manual_seed(7)
-        for s in range(300):
-            i = s % (N - 1)
-            inds = torch.randint(0, H * W, (2048,), device=dev, generator=gen)
-            u = torch.rand(2048, 64, device=dev, generator=gen)
-            loss, _ = tr.step_camera(poses[i], H, W, focal, inds, pixels[i], t_rand=u)
-        img = train_mod.render_one(model, enc, H, W, focal, poses[N - 1], dev, n_samples=64, near=2.0, far=6.0)
-        out[prec] = float(mods["utils"].mse2psnr(torch.mean((img - images[N - 1]) ** 2)))
-        # the bf16 render of the bf16-trained model is the same picture
-        if prec == "bf16":
-            img16 = train_mod.render_one(model, enc, H, W, focal, poses[N - 1], dev, n_samples=64, near=2.0, far=6.0, chunk=3000, precision="bf16")
-            assert float((img16 - img).abs().max()) <= 2e-2
-    print("held-out PSNR after 300 steps:", out)
-    assert out["fp32"] >= 15.0, out
-    assert abs(out["fp32"] - out["bf16"]) <= 0.5, out
+        for s in range(2000):
+            i = s % N
+            inds = torch.randint(0, H * W, (4096,), device=dev, generator=gen)
+            u = torch.rand(4096, 64, device=dev, generator=gen)
+            tr.step_camera(poses[i], H, W, focal, inds, pixels[i], t_rand=u)
+        ps = []
+        for k in range(h_poses.shape[0]):
+            img = train_mod.render_one(model, enc, H, W, focal, h_poses[k], dev, n_samples=64, near=2.0, far=6.0)
+            ps.append(float(mods["utils"].mse2psnr(torch.mean((img - h_images[k]) ** 2))))
+            img16 = train_mod.render_one(model, enc, H, W, focal, h_poses[k], dev, n_samples=64, near=2.0, far=6.0, chunk=3000, precision="bf16")
+            worst_rgb = max(worst_rgb, float((img16 - img).abs().max()))
+        out[prec] = sum(ps) / len(ps)
+    print(f"held-out PSNR after 2000 steps (mean of 8 unseen views): {out}, max |dRGB| bf16 vs fp32 render of identical weights {worst_rgb:.2e}")
+    assert out["fp32"] >= 24.0, out
+    assert abs(out["fp32"] - out["bf16"]) <= 0.1, out
+    assert worst_rgb <= 2e-2, worst_rgb
 
 
 @pytest.mark.parametrize("arch", [(15, 128, 1, 0), (39, 128, 2, 1), (63, 256, 3, 2), (27, 256, 5, 0)])

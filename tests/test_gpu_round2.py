@@ -1,0 +1,389 @@
+"""Round-2 GPU tests (through the C ABI, `pytest -m gpu`): the call-surface holes closed this round (per-ray near/far,
+two forwards before one backward, rebound parameters), the novel-view path, the reference training loop
+end to end (train.main with checkpoint / resume / preview), the RCCL entry points of the C ABI with one rank, and
+full-size property tests of BASELINE cfg 3 (400x400, S=128) and cfg 5 (800x800, S=256)."""
+import ctypes as C
+import math
+import os
+import struct
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, golden_params
+from oracle import tnerf_oracle as O
+
+pytestmark = pytest.mark.gpu
+RGB_TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def mods():
+    import rays, sampling, encoding, nerf, volume, utils, train, camera, data, make_gif   # drop-in call surface
+    from tnerf import ops, trainer, lib
+    lib.load()
+    return dict(rays=rays, sampling=sampling, encoding=encoding, nerf=nerf, volume=volume, utils=utils, train=train,
+                camera=camera, data=data, make_gif=make_gif, ops=ops, trainer=trainer, lib=lib)
+
+
+def make_model(mods, cfg, params, dev):
+    m = mods["nerf"].TinyNeRF(cfg["in_dim"], cfg["hidden"], cfg["depth"], cfg["skip_at"]).to(dev)
+    with torch.no_grad():
+        for p, v in zip(m.parameters(), params):
+            p.copy_(v.to(dev))
+    return m
+
+
+def relmax(a, b):
+    return float((a - b).abs().max()) / (float(b.abs().max()) + 1e-30)
+
+
+# ------------------------------------------------------------------------------ per-ray near / far
+def test_sample_bins_with_tensor_near_far_bit_exact(mods, dev):
+    """near / far as tensors broadcastable to (N_rays, 1) (reference src/sampling.py:8): bins bit-exact."""
+    g = load_golden("sampling_per_ray")
+    ro, rd = g["rays_o"].to(dev), g["rays_d"].to(dev)
+    near, far = g["near"].to(dev), g["far"].to(dev)
+    for S in (64, 33):
+        z, pts = mods["sampling"].stratified_samples(near, far, S, ro, rd, randomized=False)
+        assert torch.equal(z.cpu(), g[f"z_det_{S}"]) and torch.equal(pts[:16].cpu(), g[f"pts_det_{S}"])
+        z, pts = mods["ops"].sample_along_rays_per_ray(near, far, S, ro, rd, True, t_rand=g[f"u_{S}"].to(dev))
+        assert torch.equal(z.cpu(), g[f"z_rand_{S}"]) and torch.equal(pts[:16].cpu(), g[f"pts_rand_{S}"])
+    # a 0-dim CPU tensor mixed with a python float, jitter drawn by the drop-in with torch.rand like the reference's rand_like
+    torch.manual_seed(9)
+    z, pts = mods["sampling"].stratified_samples(torch.tensor(g["near0"]), g["far0"], 64, ro, rd, randomized=True)
+    torch.manual_seed(9)
+    u = torch.rand(ro.shape[0], 64, device=dev)
+    zo, po = O.stratified(torch.tensor(g["near0"]), g["far0"], 64, ro.cpu(), rd.cpu(), u.cpu())
+    assert torch.equal(z.cpu(), zo) and torch.equal(pts.cpu(), po)
+    z, pts = mods["ops"].sample_along_rays_per_ray(torch.tensor(g["near0"]), g["far0"], 64, ro, rd, True, t_rand=g["u_mixed"].to(dev))
+    assert torch.equal(z.cpu(), g["z_mixed"]) and torch.equal(pts[:16].cpu(), g["pts_mixed"])
+    with pytest.raises(RuntimeError):                                     # not broadcastable to (R,1): torch's own error
+        mods["sampling"].stratified_samples(torch.zeros(3, device=dev), 6.0, 64, ro, rd)
+
+
+# ------------------------------------------------------------- two forwards before one backward
+@pytest.mark.parametrize("tag", ["4x128", "8x256"])
+def test_two_forwards_of_equal_size_then_one_backward(mods, dev, tag):
+    """Two batches of the same size summed into one loss (the reference nn.Module supports it): each autograd node keeps
+    its own activation stash; gradients equal the oracle's for the summed loss — both for TinyNeRF.forward on its own
+    and for the fused ray path."""
+    cfg, params = golden_params(tag)
+    g = load_golden(f"mlp_{tag}")
+    x = g["x"]
+    xa, xb = x[:1024], x[1024:2048]
+    ga = torch.Generator().manual_seed(5)
+    wa, wb = torch.randn(1024, 3, generator=ga) * 0.1, torch.randn(1024, 3, generator=ga) * 0.1
+    sa, sb = torch.randn(1024, 1, generator=ga) * 0.1, torch.randn(1024, 1, generator=ga) * 0.1
+    leaves = [p.clone().requires_grad_(True) for p in params]
+    ra, siga = O.mlp_forward(leaves, xa, cfg["skip_at"]); rb, sigb = O.mlp_forward(leaves, xb, cfg["skip_at"])
+    go = torch.autograd.grad((ra * wa).sum() + (siga * sa).sum() + (rb * wb).sum() + (sigb * sb).sum(), leaves)
+    model = make_model(mods, cfg, params, dev)
+    r1, s1 = model(xa.to(dev))
+    r2, s2 = model(xb.to(dev))                                            # same M: would have overwritten the first stash
+    with torch.no_grad():
+        r_val, _ = model(xa.to(dev))                                      # an inference forward in between changes nothing
+    ((r1 * wa.to(dev)).sum() + (s1 * sa.to(dev)).sum() + (r2 * wb.to(dev)).sum() + (s2 * sb.to(dev)).sum()).backward()
+    assert torch.equal(r_val, r1.detach())
+    worst = max(relmax(p.grad.cpu(), q) for p, q in zip(model.parameters(), go))
+    assert worst <= 2e-5, worst
+    # fused rays: two ray batches of equal size, one loss
+    gs = load_golden(f"step_{tag}")
+    images, poses, focal = gs["images"], gs["poses"], gs["focal"]
+    N, H, W, _ = images.shape
+    ro_all, rd_all = O.pinhole_rays(H, W, focal, poses[0])
+    u = gs["u"][0]; S = u.shape[-1]
+    i1, i2 = gs["inds"][0][:128], gs["inds"][1][:128]
+    tgt = images.reshape(N, H * W, 3)[0]
+    leaves = [p.clone().requires_grad_(True) for p in params]
+    c1, _, _, _ = O.render_rays(leaves, cfg["skip_at"], cfg["L"], ro_all[i1], rd_all[i1], 2.0, 6.0, S, u[:128])
+    c2, _, _, _ = O.render_rays(leaves, cfg["skip_at"], cfg["L"], ro_all[i2], rd_all[i2], 2.0, 6.0, S, u[128:256])
+    go = torch.autograd.grad(((c1 - tgt[i1]) ** 2).mean() + ((c2 - tgt[i2]) ** 2).mean(), leaves)
+    model = make_model(mods, cfg, params, dev)
+    st, plist = model._ensure_packed(), model._param_list()
+    f1, _, _ = mods["ops"].render_rays_fused(st, plist, ro_all[i1].to(dev), rd_all[i1].to(dev), 2.0, 6.0, S, True, t_rand=u[:128].to(dev))
+    f2, _, _ = mods["ops"].render_rays_fused(st, plist, ro_all[i2].to(dev), rd_all[i2].to(dev), 2.0, 6.0, S, True, t_rand=u[128:256].to(dev))
+    assert float((f1.detach().cpu() - c1.detach()).abs().max()) <= RGB_TOL
+    loss = ((f1 - tgt[i1].to(dev)) ** 2).mean() + ((f2 - tgt[i2].to(dev)) ** 2).mean()
+    loss.backward()
+    worst = max(relmax(p.grad.cpu(), q) for p, q in zip(plist, go))
+    assert worst <= 5e-3, worst
+    with pytest.raises(RuntimeError):
+        loss.backward()                                                   # the stash is released after backward
+
+
+def test_rebinding_an_interior_parameter_is_noticed(mods, dev):
+    """hip_state() compared only the first and last parameter's pointer.  Rebind one in the middle: the next
+    forward, the packed weights, FlatAdam and state_dict() must all see the new values."""
+    cfg, params = golden_params("4x128")
+    g = load_golden("mlp_4x128")
+    model = make_model(mods, cfg, params, dev)
+    x = g["x"][:256].to(dev)
+    with torch.no_grad():
+        model(x)
+    new_w = params[2] * 0.5                                              # layers.1.weight
+    model.layers[1].weight = torch.nn.Parameter(new_w.clone().to(dev))
+    p2 = [p.clone() for p in params]; p2[2] = new_w
+    with torch.no_grad():
+        rgb, sig = model(x)
+    ro, so = O.mlp_forward(p2, g["x"][:256], cfg["skip_at"])
+    assert float((rgb.cpu() - ro).abs().max()) <= 2e-6
+    st = model.hip_state()
+    assert st.owns(model._param_list()) and model.layers[1].weight.data_ptr() == st.flat.data_ptr() + 4 * st.offsets[2]
+    assert torch.equal(model.state_dict()["layers.1.weight"].cpu(), new_w)
+    # p.data = ... on another interior parameter
+    model.layers[2].bias.data = (params[5] + 1.0).to(dev)
+    p2[5] = params[5] + 1.0
+    with torch.no_grad():
+        rgb, _ = model(x)
+    assert float((rgb.cpu() - O.mlp_forward(p2, g["x"][:256], cfg["skip_at"])[0]).abs().max()) <= 2e-6
+
+
+# ----------------------------------------------------------------------------------- novel views
+def test_spiral_poses_and_novel_view_frames(mods, dev, tmp_path):
+    """camera.spiral_poses vs the reference's poses (<= 1e-6), spiral frames through render_one vs the frames the
+    reference functions rendered (<= 1e-4), and make_gif.main end to end (checkpoint + npz in, 60 uint8 frames out)."""
+    g = load_golden("spiral")
+    p60 = mods["camera"].spiral_poses(g["ref"].to(dev))
+    assert p60.shape == (60, 4, 4) and p60.device.type == "cuda"
+    assert float((p60.cpu() - g["poses60"]).abs().max()) <= 1e-6
+    assert float((mods["camera"].spiral_poses(g["ref"].to(dev), n_frames=7, radius=0.5).cpu() - g["poses7"]).abs().max()) <= 1e-6
+    assert float((mods["camera"].spiral_poses(g["ref"]).cpu() - O.spiral_poses(g["ref"])).abs().max()) <= 1e-6    # CPU tensors work too
+    nv = load_golden("novel_views")
+    cfg, params = golden_params("4x128")
+    model = make_model(mods, cfg, params, dev)
+    enc = mods["encoding"].PositionalEncoding(cfg["L"], True).to(dev)
+    H, W = int(nv["H"]), int(nv["W"])
+    path = mods["camera"].spiral_poses(nv["ref"].to(dev))
+    for j, k in enumerate(nv["frame_index"].tolist()):
+        img = mods["train"].render_one(model, enc, H, W, nv["focal"], path[k], dev, n_samples=64, near=2.0, far=6.0)
+        assert float((img.cpu() - nv["frames"][j]).abs().max()) <= RGB_TOL
+        want = O.render_image(params, cfg["skip_at"], cfg["L"], H, W, nv["focal"], O.spiral_poses(nv["ref"])[k], 64, 2.0, 6.0)
+        assert float((img.cpu() - want).abs().max()) <= RGB_TOL
+    # make_gif.main: npz + checkpoint in a tmp dir
+    scene = mods["data"].make_synthetic_scene(n_images=3, H=24, W=24, focal=138.88887889922103 * 0.24, seed=2)
+    npz = str(tmp_path / "scene.npz")
+    np.savez(npz, images=scene["images"], poses=scene["poses"], focal=np.float64(scene["focal"]))
+    ck = str(tmp_path / "ck.pth")
+    torch.save({"model": model.state_dict(), "step": 1, "in_dim": cfg["in_dim"],
+                "cfg": dict(hidden=cfg["hidden"], depth=cfg["depth"], skip_at=cfg["skip_at"])}, ck)
+    frames = mods["make_gif"].main(ck, str(tmp_path / "out"), "fp32", npz, 6, 0.3)
+    assert len(frames) == 6 and frames[0].shape == (24, 24, 3) and frames[0].dtype == np.uint8
+    sp = O.spiral_poses(torch.from_numpy(scene["poses"][0]), 6, 0.3)
+    for k in (0, 3, 5):
+        want = O.render_image(params, cfg["skip_at"], cfg["L"], 24, 24, float(scene["focal"]), sp[k], 64, 2.0, 6.0)
+        assert int(np.abs(frames[k].astype(np.int32) - (want.numpy() * 255).astype(np.uint8).astype(np.int32)).max()) <= 1
+    assert np.array_equal(frames[0], frames[5])                          # linspace(0, 2 pi) closes the loop
+    assert len(os.listdir(tmp_path / "out")) >= 1
+    with pytest.raises(FileNotFoundError):                                # a missing dataset raises like the reference
+        mods["make_gif"].main(ck, str(tmp_path / "out2"), "fp32", str(tmp_path / "nope.npz"))
+
+
+# ------------------------------------------------------------------------- the loop, end to end
+def _read_png(path):
+    raw = open(path, "rb").read()
+    assert raw[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, w = 8, b"", None
+    while pos < len(raw):
+        n, tag = struct.unpack(">I4s", raw[pos:pos + 8])
+        body = raw[pos + 8:pos + 8 + n]
+        assert zlib.crc32(tag + body) & 0xFFFFFFFF == struct.unpack(">I", raw[pos + 8 + n:pos + 12 + n])[0]
+        if tag == b"IHDR":
+            w, h, bits, ctype = struct.unpack(">IIBB", body[:10]); assert (bits, ctype) == (8, 2)
+        elif tag == b"IDAT":
+            idat += body
+        pos += 12 + n
+    rows = zlib.decompress(idat)
+    img = np.frombuffer(rows, np.uint8).reshape(h, 1 + 3 * w)
+    assert not img[:, 0].any()                                           # filter type 0 on every row
+    return img[:, 1:].reshape(h, w, 3)
+
+
+def _oracle_loop(params, cfg, images, poses, focal, n_rand, S, draws, first_step, lr, adam=None):
+    """The reference loop body (src/train.py:106-128) on the CPU oracle with recorded draws."""
+    N, H, W, _ = images.shape
+    ps = [p.clone() for p in params]
+    adam = adam or O.AdamState(ps, lr=lr)
+    pix = images.reshape(N, H * W, 3)
+    losses = []
+    for k, (inds, u) in enumerate(draws):
+        i = (first_step + k) % N
+        ro, rd = O.pinhole_rays(H, W, focal, poses[i])
+        loss, _, grads = O.loss_and_grads(ps, cfg["skip_at"], cfg["L"], ro[inds], rd[inds], pix[i, inds], 2.0, 6.0, S, u)
+        adam.step(ps, grads)
+        losses.append(float(loss))
+    return ps, adam, losses
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_train_main_checkpoint_resume_preview(mods, dev, tmp_path, fused):
+    """train.main(cfg) (reference src/train.py:61-160): data loading from an npz, 6 steps with logging / preview /
+    checkpoint cadence, then the same run split 3 + 3 with resume=True.  The weights are checked against the CPU oracle
+    driven with the very draws main() makes (manual_seed(0), then randint + rand per step on the GPU generator)."""
+    train, data = mods["train"], mods["data"]
+    scene = data.make_synthetic_scene(n_images=5, H=20, W=20, focal=138.88887889922103 * 0.2, seed=4)
+    npz = str(tmp_path / "tiny.npz")
+    np.savez(npz, images=scene["images"].astype(np.float64), poses=scene["poses"], focal=np.float64(scene["focal"]))
+    d = data.load_tiny_nerf_npz(npz)
+    assert d["images"].dtype == np.float32 and d["focal"].dtype == np.float32 and d["poses"].dtype == np.float32   # float64 -> float32
+    images, poses, focal = torch.from_numpy(d["images"]), torch.from_numpy(d["poses"]), float(d["focal"])
+    n_rand, S, L, hid, dep, skip = 96, 24, 4, 128, 3, 2
+
+    def cfg(iters, tag, resume):
+        return train.Config(iters=iters, n_rand=n_rand, n_samples=S, lr=5e-4, log_every=2, preview_every=3, ckpt_every=3,
+                            ckpt_path=str(tmp_path / tag / "ck" / "latest.pth"), out_dir=str(tmp_path / tag / "out"), resume=resume,
+                            preview_pose=None, fused=fused, num_freqs=L, hidden=hid, depth=dep, skip_at=skip, data_path=npz)
+
+    def draws(n):
+        torch.manual_seed(0)
+        out = []
+        for _ in range(n):
+            inds = torch.randint(0, 400, (n_rand,), device=dev)
+            out.append((inds.cpu(), torch.rand(n_rand, S, device=dev).cpu()))
+        return out
+
+    # the initial weights main() builds: manual_seed(0) then the constructors in the reference's order
+    torch.manual_seed(0)
+    ref_model = mods["nerf"].TinyNeRF(6 * L + 3, hid, dep, skip)
+    p0 = [p.detach().clone() for p in ref_model.parameters()]
+    mcfg = dict(L=L, skip_at=skip)
+
+    # ---- A: 6 uninterrupted steps
+    mA = train.main(cfg(6, "A", True))
+    wantA, _, _ = _oracle_loop(p0, mcfg, images, poses, focal, n_rand, S, draws(6), 0, 5e-4)
+    errA = max(float((p.detach().cpu() - q).abs().max()) for p, q in zip(mA.parameters(), wantA))
+    assert errA <= 2e-5, errA
+    outA = sorted(os.listdir(tmp_path / "A" / "out"))
+    assert outA == ["final.png", "preview_000003.png", "preview_000006.png"], outA
+    ck = torch.load(str(tmp_path / "A" / "ck" / "latest.pth"), map_location="cpu")
+    assert set(ck.keys()) == {"model", "opt", "step", "in_dim", "cfg"} and ck["step"] == 6 and ck["in_dim"] == 6 * L + 3
+    assert list(ck["model"].keys())[0] == "layers.0.weight" and ck["cfg"] == dict(hidden=hid, depth=dep, skip_at=skip)
+    # final.png is the render of poses[-1], quantised like the reference (img * 255 -> uint8)
+    png = _read_png(str(tmp_path / "A" / "out" / "final.png"))
+    want_img = O.render_image(wantA, skip, L, 20, 20, focal, poses[-1], S, 2.0, 6.0)
+    assert png.shape == (20, 20, 3) and int(np.abs(png.astype(np.int32) - (want_img.numpy() * 255).astype(np.uint8).astype(np.int32)).max()) <= 1
+    # preview at step 3 shows pose (img_i + 1) % N = 3 (train.py:135-136)
+    w3, _, _ = _oracle_loop(p0, mcfg, images, poses, focal, n_rand, S, draws(3), 0, 5e-4)
+    pv = _read_png(str(tmp_path / "A" / "out" / "preview_000003.png"))
+    want_pv = O.render_image(w3, skip, L, 20, 20, focal, poses[3], S, 2.0, 6.0)
+    assert int(np.abs(pv.astype(np.int32) - (want_pv.numpy() * 255).astype(np.uint8).astype(np.int32)).max()) <= 1
+
+    # ---- B: 3 steps, then resume to 6.  The resumed process re-seeds (train.py:63), so steps 3..5 see draws 0..2 again;
+    # image index, Adam moments and step count continue from the checkpoint.
+    train.main(cfg(3, "B", True))
+    ck3 = torch.load(str(tmp_path / "B" / "ck" / "latest.pth"), map_location="cpu")
+    assert ck3["step"] == 3
+    mB = train.main(cfg(6, "B", True))
+    w3, adam3, _ = _oracle_loop(p0, mcfg, images, poses, focal, n_rand, S, draws(3), 0, 5e-4)
+    wantB, _, _ = _oracle_loop(w3, mcfg, images, poses, focal, n_rand, S, draws(3), 3, 5e-4, adam=adam3)
+    errB = max(float((p.detach().cpu() - q).abs().max()) for p, q in zip(mB.parameters(), wantB))
+    assert errB <= 2e-5, errB
+    assert torch.load(str(tmp_path / "B" / "ck" / "latest.pth"), map_location="cpu")["step"] == 6
+    # resume=False ignores the checkpoint: same result as run A
+    mC = train.main(cfg(6, "B", False))
+    assert max(float((p - q).abs().max()) for p, q in zip(mC.parameters(), mA.parameters())) == 0.0
+    # a missing dataset raises like the reference (no silent synthetic fallback)
+    bad = cfg(1, "D", False); bad.data_path = str(tmp_path / "missing.npz")
+    with pytest.raises(FileNotFoundError):
+        train.main(bad)
+
+
+# --------------------------------------------------------------------------- RCCL through the C ABI
+def test_rccl_entry_points_with_one_rank(mods, dev):
+    """tnerf_comm_unique_id / tnerf_comm_init_rank / tnerf_allreduce_grads / tnerf_comm_destroy (include/tnerf.h) with
+    n_ranks = 1: SUM over one rank leaves the gradient unchanged, on the caller's stream."""
+    lib = mods["lib"]
+    L = lib.load()
+    uid = (C.c_char * 128)()
+    lib.check(L.tnerf_comm_unique_id(C.cast(uid, C.c_void_p)), "tnerf_comm_unique_id")
+    assert any(bytes(uid))
+    comm = C.c_void_p()
+    lib.check(L.tnerf_comm_init_rank(C.cast(uid, C.c_void_p), 1, 0, C.byref(comm)), "tnerf_comm_init_rank")
+    assert comm.value
+    g = torch.randn(481796, device=dev)
+    keep = g.clone()
+    s = torch.cuda.Stream(dev)
+    s.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(s):
+        lib.check(L.tnerf_allreduce_grads(comm, g.data_ptr(), g.numel(), s.cuda_stream), "tnerf_allreduce_grads")
+    s.synchronize()
+    assert torch.equal(g, keep)
+    assert L.tnerf_allreduce_grads(None, g.data_ptr(), g.numel(), None) == lib.EINVAL
+    assert L.tnerf_comm_init_rank(C.cast(uid, C.c_void_p), 1, 1, C.byref(comm)) == lib.EINVAL     # rank out of range
+    lib.check(L.tnerf_comm_destroy(comm), "tnerf_comm_destroy")
+
+
+# ----------------------------------------------------------- BASELINE cfg 3 / cfg 5 at full size
+@pytest.mark.parametrize("name,HW,S,prec", [("cfg3", 400, 128, "fp32"), ("cfg3", 400, 128, "bf16"),
+                                            ("cfg5", 800, 256, "fp32"), ("cfg5", 800, 256, "bf16")])
+def test_full_size_render_properties(mods, dev, name, HW, S, prec):
+    """160,000 rays x 128 samples (cfg 3) and 640,000 rays x 256 samples = 163.8 M samples (cfg 5) through the fused
+    render kernels in ONE launch per image: bitwise determinism, chunk invariance (bitwise), finite / in range, the
+    white-background identity, and a strided sample of pixels against the CPU oracle."""
+    ops, train = mods["ops"], mods["train"]
+    cfg, params = golden_params("8x256")
+    model = make_model(mods, cfg, params, dev)
+    enc = mods["encoding"].PositionalEncoding(cfg["L"], True).to(dev)
+    g = torch.Generator().manual_seed(HW)
+    q, r_ = torch.linalg.qr(torch.randn(3, 3, generator=g))
+    q = q * torch.sign(torch.diagonal(r_))
+    if torch.det(q) < 0:
+        q[:, 2] = -q[:, 2]
+    pose = torch.eye(4); pose[:3, :3] = q
+    pose[:3, 3] = q[:, 2] * 4.0                                        # camera on the radius-4 sphere looking at the origin (-z forward)
+    focal = 138.88887889922103 * HW / 100.0
+    pose_d = pose.to(dev)
+    st = model._ensure_packed()
+    n = HW * HW
+    render = ops.render_camera_fused_bf16 if prec == "bf16" else ops.render_camera_fused
+    c1, d1, a1 = render(st, pose_d, HW, HW, focal, 0, n, 2.0, 6.0, S)              # one sharded launch for the whole image
+    c2, _, _ = render(st, pose_d, HW, HW, focal, 0, n, 2.0, 6.0, S)
+    assert torch.equal(c1, c2)                                                       # deterministic, bit for bit
+    img = train.render_one(model, enc, HW, HW, focal, pose, dev, n_samples=S, near=2.0, far=6.0, chunk=50000, precision=prec)
+    assert torch.equal(img.reshape(-1, 3), c1.clamp(0, 1))                          # chunk invariance (render_one chunks at 50,000)
+    assert bool(torch.isfinite(c1).all()) and bool(torch.isfinite(d1).all()) and bool(torch.isfinite(a1).all())
+    assert float(a1.min()) >= 0.0 and float(a1.max()) <= 1.0 + 1e-4 and float(d1.min()) >= 0.0 and float(d1.max()) <= 6.0 * 1.0001
+    cq, _, aq = render(st, pose_d, HW, HW, focal, 0, n, 2.0, 6.0, S, white_bkgd=False)
+    assert float((c1 - (cq + (1.0 - aq))).abs().max()) <= 2e-6                     # white background identity
+    assert float(c1.std()) > 1e-3                                                    # not a constant image
+    # strided pixel sample against the oracle (fp32 path: 1e-4; bf16 mode: SURVEY 8d cfg 4's 2e-2 against fp32)
+    idx = torch.arange(0, n, n // 193)[:192]
+    ro, rd = O.pinhole_rays(HW, HW, focal, pose)
+    want, _, _, _ = O.render_rays(params, cfg["skip_at"], cfg["L"], ro[idx].contiguous(), rd[idx], 2.0, 6.0, S, None)
+    err = float((c1[idx.to(dev)].cpu() - want).abs().max())
+    assert err <= (RGB_TOL if prec == "fp32" else 2e-2), err
+
+
+def test_full_size_train_step_cfg3(mods, dev):
+    """cfg 3 train step shape (4096 rays x 128 samples, 8x256): bitwise determinism of the whole fused step and shard
+    additivity of its gradient (what the RCCL all-reduce relies on)."""
+    from data import make_synthetic_scene
+    trainer = mods["trainer"]
+    sc = make_synthetic_scene(n_images=2, H=400, W=400, focal=4 * 138.88887889922103, seed=0)
+    images = torch.from_numpy(sc["images"]).to(dev); poses = torch.from_numpy(sc["poses"]).to(dev); focal = float(sc["focal"])
+    pixels = images.view(2, 160000, 3)
+    gen = torch.Generator(device=dev); gen.manual_seed(3)
+    inds = torch.randint(0, 160000, (4096,), device=dev, generator=gen)
+    u = torch.rand(4096, 128, device=dev, generator=gen)
+
+    def grad_of(lo, hi):
+        torch.manual_seed(0)
+        m = mods["nerf"].TinyNeRF(39, 256, 8, 4).to(dev)
+        with torch.no_grad():
+            m.sigma[0].bias += 0.5
+        tr = trainer.FusedTrainer(m, trainer.FlatAdam(m, lr=0.0), 2.0, 6.0, 128)
+        loss, _ = tr.step_camera(poses[1], 400, 400, focal, inds[lo:hi], pixels[1], t_rand=u[lo:hi], global_rays=4096)
+        return float(loss), m.hip_state().grad.clone()
+
+    l1, g1 = grad_of(0, 4096); l2, g2 = grad_of(0, 4096)
+    assert l1 == l2 and torch.equal(g1, g2) and bool(torch.isfinite(g1).all()) and float(g1.abs().max()) > 0
+    la, ga = grad_of(0, 1500); lb, gb = grad_of(1500, 4096)
+    assert abs(la + lb - l1) <= 1e-5 * l1
+    assert float((ga + gb - g1).abs().max()) <= 2e-5 * float(g1.abs().max())

@@ -1,0 +1,36 @@
+"""SURVEY.md §5 (race / memory checking): the host planner (csrc/host_plan.cpp — depth tables, parameter layout, MFMA
+pack tables, wgrad job / reduce tables, bf16 stream tables: all the index arithmetic the kernels trust) compiled for the
+CPU with AddressSanitizer + UndefinedBehaviorSanitizer and driven by the host-logic tests.  (GPU sanitizers are not
+available on this pool; the kernels' indexing is covered by emulating their data flow on these tables.)"""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "tiny-nerf-pytorch_amd", "csrc")
+
+
+def _gcc_file(name):
+    return subprocess.run(["g++", f"-print-file-name={name}"], capture_output=True, text=True).stdout.strip()
+
+
+@pytest.mark.timeout(900)
+def test_host_planner_under_asan_ubsan(tmp_path):
+    asan, ubsan = _gcc_file("libasan.so"), _gcc_file("libubsan.so")
+    if not (os.path.isabs(asan) and os.path.exists(asan)):
+        pytest.skip("no libasan for this g++")
+    so = str(tmp_path / "libtnerf_host_asan.so")
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-omit-frame-pointer",
+                    "-fsanitize=address,undefined", "-fno-sanitize-recover=all", os.path.join(CSRC, "host_plan.cpp"), "-o", so],
+                   check=True)
+    env = dict(os.environ, TNERF_LIB=so, TNERF_HOST_ONLY="1", LD_PRELOAD=" ".join(p for p in (asan, ubsan) if os.path.exists(p)),
+               ASAN_OPTIONS="detect_leaks=0:abort_on_error=1:verify_asan_link_order=0", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1",
+               OMP_NUM_THREADS="2")
+    # every host-logic test except the one that needs the GPU symbols of the full library
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_host_logic.py"), "-x", "-q", "-p", "no:cacheprovider",
+                        "-k", "not exports_every_declared_symbol and not oracle_bf16"], env=env, capture_output=True, text=True, cwd=ROOT)
+    tail = (r.stdout + r.stderr)[-3000:]
+    assert r.returncode == 0, tail
+    assert "passed" in r.stdout and "AddressSanitizer" not in tail and "runtime error" not in tail, tail

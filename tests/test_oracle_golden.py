@@ -129,3 +129,43 @@ def test_train_steps_follow_reference(tag):
     torch.testing.assert_close(head, g["final_head"], rtol=0, atol=2e-5)
     sums = torch.stack([p.double().sum() for p in params])
     torch.testing.assert_close(sums, g["final_sum"], rtol=0, atol=5e-3)
+
+
+# ---- round 2: per-ray near/far and the novel-view path (fixtures: tests/golden/make_golden_r2.py)
+def test_sample_bins_per_ray_near_far_bitwise():
+    g = load_golden("sampling_per_ray")
+    for S in (64, 33):
+        z, pts = O.stratified(g["near"], g["far"], S, g["rays_o"], g["rays_d"], None)
+        assert torch.equal(z, g[f"z_det_{S}"]) and torch.equal(pts[:16], g[f"pts_det_{S}"])
+        z, pts = O.stratified(g["near"], g["far"], S, g["rays_o"], g["rays_d"], g[f"u_{S}"])
+        assert torch.equal(z, g[f"z_rand_{S}"]) and torch.equal(pts[:16], g[f"pts_rand_{S}"])
+    z, pts = O.stratified(torch.tensor(g["near0"]), g["far0"], 64, g["rays_o"], g["rays_d"], g["u_mixed"])
+    assert torch.equal(z, g["z_mixed"]) and torch.equal(pts[:16], g["pts_mixed"])
+
+
+def test_spiral_poses_match_reference():
+    g = load_golden("spiral")
+    p60 = O.spiral_poses(g["ref"])
+    assert p60.shape == (60, 4, 4) and torch.equal(p60, g["poses60"])
+    assert torch.equal(O.spiral_poses(g["ref"], n_frames=7, radius=0.5), g["poses7"])
+    # properties of the path: rotation untouched, translation offsets of length `radius` in the camera's xy plane,
+    # closed loop (linspace includes 2 pi)
+    ref = g["ref"]
+    assert torch.equal(p60[:, :3, :3], ref[:3, :3].expand(60, 3, 3)) and torch.equal(p60[:, 3], ref[3].expand(60, 4))
+    off = (p60[:, :3, 3] - ref[:3, 3]) @ ref[:3, :3]               # back into the camera frame
+    assert float((off.norm(dim=-1) - 0.3).abs().max()) < 1e-6 and float(off[:, 2].abs().max()) < 1e-6
+    assert float((p60[0] - p60[-1]).abs().max()) < 1e-6
+    assert O.deal_frames(7, 1, 3) == [1, 4] and sorted(sum((O.deal_frames(60, r, 8) for r in range(8)), [])) == list(range(60))
+
+
+def test_novel_view_frames_match_reference():
+    g = load_golden("novel_views")
+    cfg, params = golden_params("4x128")
+    path = O.spiral_poses(g["ref"])
+    assert torch.equal(path, g["path"])
+    H, W = int(g["H"]), int(g["W"])
+    for j, k in enumerate(g["frame_index"].tolist()):
+        img = O.render_image(params, cfg["skip_at"], cfg["L"], H, W, g["focal"], path[k], 64, 2.0, 6.0)
+        assert float((img - g["frames"][j]).abs().max()) <= 1e-6
+        u8 = (img.numpy() * 255).astype("uint8")                       # make_gif.py:26
+        assert int((torch.from_numpy(u8).int() - g["frames_u8"][j].int()).abs().max()) <= 1

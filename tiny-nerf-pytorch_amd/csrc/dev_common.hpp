@@ -18,6 +18,40 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
         }                                                                      \
     } while (0)
 
+// ------------------------------------------------------------------------------- host-side launch helpers
+// Per-device facts are cached in atomics indexed by the device ordinal (idempotent values: a race only repeats a query).
+#include <atomic>
+#define TN_MAX_DEVICES 64
+// The device a launch on `stream` runs on (the NULL stream belongs to the current device).
+inline int tn_stream_device(hipStream_t stream) {
+    hipDevice_t d = 0; int cur = 0;
+    if (stream && hipStreamGetDevice(stream, &d) == hipSuccess) return (int)d;
+    (void)hipGetDevice(&cur);
+    return cur;
+}
+inline int tn_device_cus(int dev) {
+    static std::atomic<int> cus[TN_MAX_DEVICES];
+    if (dev < 0 || dev >= TN_MAX_DEVICES) return 256;
+    int n = cus[dev].load(std::memory_order_relaxed);
+    if (n <= 0) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus[dev].store(n, std::memory_order_relaxed);
+    }
+    return n;
+}
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a kernel: `seen` (one array per kernel, indexed by
+// device) remembers the largest size already granted there.  Returns TNERF_OK or the hipError_t.
+inline int tn_grant_dyn_lds(const void* kernel, size_t bytes, int dev, std::atomic<uint32_t>* seen, const char* who) {
+    if (dev >= 0 && dev < TN_MAX_DEVICES && seen[dev].load(std::memory_order_acquire) >= bytes) return TNERF_OK;
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    if (cur != dev) { tn_set_error("%s: the stream belongs to device %d but the current device is %d", who, dev, cur); return TNERF_EINVAL; }
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) { tn_set_error("%s: cannot grant %zu B of dynamic LDS: %s", who, bytes, hipGetErrorString(e)); return (int)e; }
+    if (dev >= 0 && dev < TN_MAX_DEVICES) seen[dev].store((uint32_t)bytes, std::memory_order_release);
+    return TNERF_OK;
+}
+
 __device__ __forceinline__ int tn_lane() { return (int)(threadIdx.x & 63); }
 
 // ----------------------------------------------------------------------------- Philox4x32-10

@@ -188,16 +188,17 @@ __global__ __launch_bounds__(512, 2) void k_dgrad16(Fwd16Args a) {
 }
 
 int tn16_launch_dgrad(const Fwd16Args& a, hipStream_t stream, const char* who) {
-    int dev = 0, n_cu = 256;
-    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    const int dev = tn_stream_device(stream), n_cu = tn_device_cus(dev);
     const int64_t groups = (a.R + 7) / 8;
     const dim3 grid((unsigned)(groups < n_cu ? groups : n_cu)), block(512);
     const size_t lds_bytes = TN16_SEL_OFF(a.n.n_bias) + 2048;
     if (a.n.hidden == 256) {
-        { static size_t set_ = 0; if (set_ < lds_bytes) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dgrad16<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); set_ = lds_bytes; } }
+        static std::atomic<uint32_t> seen_[TN_MAX_DEVICES];
+        if (int rc = tn_grant_dyn_lds(reinterpret_cast<const void*>(&k_dgrad16<256>), lds_bytes, dev, seen_, who)) return rc;
         hipLaunchKernelGGL((k_dgrad16<256>), grid, block, lds_bytes, stream, a);
     } else {
-        { static size_t set_ = 0; if (set_ < lds_bytes) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dgrad16<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); set_ = lds_bytes; } }
+        static std::atomic<uint32_t> seen_[TN_MAX_DEVICES];
+        if (int rc = tn_grant_dyn_lds(reinterpret_cast<const void*>(&k_dgrad16<128>), lds_bytes, dev, seen_, who)) return rc;
         hipLaunchKernelGGL((k_dgrad16<128>), grid, block, lds_bytes, stream, a);
     }
     TN_HIP_CHECK_LAUNCH(who);
@@ -317,7 +318,8 @@ __global__ __launch_bounds__(512, 2) void k_wgrad16(Wgrad16Args a) {
 int tn16_launch_wgrad(const Net16& n, const unsigned char* stash, const int32_t* jobs, int64_t n_jobs, float* slabs, hipStream_t stream) {
     Wgrad16Args a{stash, jobs, slabs, n.n_ft};
     const size_t lds_bytes = TN16W_NS * TN16W_SLOT;
-    { static size_t set_ = 0; if (set_ < lds_bytes) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad16), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); set_ = lds_bytes; } }
+    static std::atomic<uint32_t> seen_[TN_MAX_DEVICES];
+    if (int rc = tn_grant_dyn_lds(reinterpret_cast<const void*>(&k_wgrad16), lds_bytes, tn_stream_device(stream), seen_, "tnerf_wgrad_bf16")) return rc;
     hipLaunchKernelGGL(k_wgrad16, dim3((unsigned)n_jobs), dim3(512), lds_bytes, stream, a);
     TN_HIP_CHECK_LAUNCH("tnerf_wgrad_bf16");
     return TNERF_OK;

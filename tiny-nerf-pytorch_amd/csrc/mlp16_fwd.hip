@@ -123,14 +123,14 @@ __global__ __launch_bounds__(512, 2) void k_render16(Fwd16Args a) {
 }
 
 int tn16_launch_fwd(const Fwd16Args& a, bool train, hipStream_t stream, const char* who) {
-    int dev = 0, n_cu = 256;
-    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    const int dev = tn_stream_device(stream), n_cu = tn_device_cus(dev);
     const int64_t groups = (a.R + 7) / 8;
     const dim3 grid((unsigned)(groups < n_cu ? groups : n_cu)), block(512);
     const size_t lds_bytes = TN16_SEL_OFF(a.n.n_bias) + 2048;
 #define TN16_CASE(H_, T_)                                                                                                        \
     if (a.n.hidden == H_ && train == T_) {                                                                                        \
-        { static size_t set_ = 0; if (set_ < lds_bytes) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_render16<H_, T_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); set_ = lds_bytes; } } \
+        static std::atomic<uint32_t> seen_[TN_MAX_DEVICES];                                                                       \
+        if (int rc_ = tn_grant_dyn_lds(reinterpret_cast<const void*>(&k_render16<H_, T_>), lds_bytes, dev, seen_, who)) return rc_; \
         hipLaunchKernelGGL((k_render16<H_, T_>), grid, block, lds_bytes, stream, a);                                              \
         TN_HIP_CHECK_LAUNCH(who);                                                                                                 \
         return TNERF_OK;                                                                                                          \

@@ -34,10 +34,6 @@ int tn_fused_args(const char* who, FwdArgs& a, const tnerf_mlp_desc* d, const fl
                   uint64_t seed, uint64_t offset, int32_t white);
 int tn_camera_source(const char* who, const tnerf_camera* cam, int64_t R, RaySource* rs);
 inline RaySource tn_table_source(const float* rays_o, const float* rays_d) { return RaySource{rays_o, rays_d, nullptr, nullptr, 0, 0, 0, 0.0f}; }
-// mlp_pair.hip: two wavefronts per tile, two waves per SIMD (fused paths only)
-int tn_launch_fwd_pair(const FwdArgs& a, bool train, hipStream_t stream, const char* who);
-int tn_launch_train_bwd_pair(const BwdArgs& a, hipStream_t stream);
-bool tn_use_pair();   // TNERF_PAIR=0 selects the one-wave-per-tile kernels
 // mlp_bwd.hip
 int tn_launch_mlp_bwd(const BwdArgs& a, hipStream_t stream);
 int tn_launch_train_bwd(const BwdArgs& a, hipStream_t stream);

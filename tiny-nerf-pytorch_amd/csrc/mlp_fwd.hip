@@ -316,7 +316,6 @@ static int render_impl(const char* who, const tnerf_mlp_desc* d, const float* pa
     if (R == 0) return TNERF_OK;
     if (!comp) { tn_set_error("tnerf_render_fused: comp_rgb is NULL"); return TNERF_EINVAL; }
     a.comp = comp; a.depth = depth; a.acc = acc;
-    if (tn_use_pair()) return tn_launch_fwd_pair(a, false, (hipStream_t)stream, who);
     return launch_fwd<true, false>(a, R, (hipStream_t)stream, who);
 }
 
@@ -334,7 +333,6 @@ extern "C" int tnerf_train_fwd_fused(const tnerf_mlp_desc* d, const float* packe
     }
     if (R == 0) return TNERF_OK;
     a.comp = comp; a.stash = stash; a.Mp = Mp;
-    if (tn_use_pair()) return tn_launch_fwd_pair(a, true, (hipStream_t)stream, "tnerf_train_fwd_fused");
     return launch_fwd<true, true>(a, R, (hipStream_t)stream, "tnerf_train_fwd_fused");
 }
 

@@ -111,6 +111,48 @@ extern "C" int tnerf_sample_encode_fwd(const float* rays_o, const float* rays_d,
     return TNERF_OK;
 }
 
+// near / far given per ray ("tensors broadcastable to (N_rays, 1)", reference src/sampling.py:8): the bins of ray r are
+// z_i = near_r (1 - t_i) + far_r t_i with the same op-by-op rounding as tnerf_sample_tables (every product and sum
+// rounded separately, mids = 0.5 (z_i + z_i+1)), computed per thread from the linspace table t.
+__global__ __launch_bounds__(256) void k_sample_per_ray(const float* __restrict__ rays_o, const float* __restrict__ rays_d, int64_t R, int S,
+                                                        const float* __restrict__ ttab, const float* __restrict__ near_, const float* __restrict__ far_,
+                                                        int randomized, const float* __restrict__ t_rand, uint64_t seed, uint64_t offset,
+                                                        float* __restrict__ z_vals, float* __restrict__ pts) {
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= R * S) return;
+    const int64_t r = m / S; const int s = (int)(m % S);
+    const float nr = near_[r], fr = far_[r];
+    auto bin = [&](int i) { const float t = ttab[i]; return __fadd_rn(__fmul_rn(nr, __fsub_rn(1.0f, t)), __fmul_rn(fr, t)); };
+    float z = bin(s);
+    if (randomized) {
+        const float lo = s == 0 ? z : __fmul_rn(0.5f, __fadd_rn(bin(s - 1), z));
+        const float hi = s == S - 1 ? z : __fmul_rn(0.5f, __fadd_rn(z, bin(s + 1)));
+        const float u = t_rand ? t_rand[m] : tn_philox_uniform(seed, offset + (uint64_t)m);
+        z = __fadd_rn(lo, __fmul_rn(__fsub_rn(hi, lo), u));
+    }
+    if (z_vals) z_vals[m] = z;
+    if (pts) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) pts[3 * m + c] = tn_point(rays_o[3 * r + c], rays_d[3 * r + c], z);
+    }
+}
+
+extern "C" int tnerf_sample_per_ray_fwd(const float* rays_o, const float* rays_d, int64_t R, int32_t S, const float* ttab,
+                                        const float* near_, const float* far_, int32_t randomized, const float* t_rand,
+                                        uint64_t seed, uint64_t offset, float* z_vals, float* pts, tnerf_stream_t stream) {
+    if (R == 0 && S >= 1) return TNERF_OK;
+    if (R < 0 || S < 1 || !rays_o || !rays_d || !ttab || !near_ || !far_ || (!z_vals && !pts)) {
+        tn_set_error("tnerf_sample_per_ray_fwd: R=%lld S=%d rays_o=%p rays_d=%p t=%p near=%p far=%p z=%p pts=%p", (long long)R, S, (const void*)rays_o,
+                     (const void*)rays_d, (const void*)ttab, (const void*)near_, (const void*)far_, (void*)z_vals, (void*)pts);
+        return TNERF_EINVAL;
+    }
+    const int64_t M = R * S;
+    hipLaunchKernelGGL(k_sample_per_ray, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rays_o, rays_d, R, S, ttab,
+                       near_, far_, randomized ? 1 : 0, t_rand, seed, offset, z_vals, pts);
+    TN_HIP_CHECK_LAUNCH("tnerf_sample_per_ray_fwd");
+    return TNERF_OK;
+}
+
 extern "C" int tnerf_posenc_fwd(const float* x, int64_t n, int32_t L, int32_t include_input, float* out, tnerf_stream_t stream) {
     if (n == 0) return TNERF_OK;
     if (n < 0 || !x || !out || L < 0 || L > 16 || 6 * L + (include_input ? 3 : 0) < 1) {

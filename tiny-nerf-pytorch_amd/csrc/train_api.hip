@@ -2,13 +2,8 @@
 #include <dlfcn.h>
 #include <cstring>
 #include <cstdlib>
+#include <mutex>
 #include "mlp_args.hpp"
-
-// Kernel family of the fused paths: wave pairs (default) or one wave per tile (TNERF_PAIR=0).  Read once.
-bool tn_use_pair() {
-    static const bool v = [] { const char* e = getenv("TNERF_PAIR"); return e ? (e[0] != '0') : false; }();
-    return v;
-}
 
 static int bwd_common_check(const char* who, const float* packed, float* stash, int64_t Mp, int64_t M, const int32_t* job_table,
                             int64_t n_jobs, float* slabs, const int32_t* reduce_table, float* grads) {
@@ -46,7 +41,7 @@ static int train_bwd_impl(const char* who, const tnerf_mlp_desc* d, const float*
     BwdArgs a{};
     a.L = f.L; a.packed = packed; a.stash = stash; a.Mp = Mp; a.rs = f.rs; a.R = R; a.sa = f.sa;
     a.white = white; a.g_comp = g_comp;
-    if ((rc = tn_use_pair() ? tn_launch_train_bwd_pair(a, s) : tn_launch_train_bwd(a, s))) return rc;
+    if ((rc = tn_launch_train_bwd(a, s))) return rc;
     if ((rc = tn_launch_wgrad(stash, a.L.stash_rows, R * S, job_table, n_jobs, slabs, s))) return rc;
     return tn_launch_reduce(slabs, reduce_table, a.L.n_params, grads, s);
 }
@@ -71,7 +66,7 @@ extern "C" int tnerf_train_dgrad_fused(const tnerf_mlp_desc* d, const float* pac
     BwdArgs a{};
     a.L = f.L; a.packed = packed; a.stash = stash; a.Mp = Mp; a.rs = f.rs; a.R = R; a.sa = f.sa;
     a.white = white; a.g_comp = g_comp;
-    return tn_use_pair() ? tn_launch_train_bwd_pair(a, (hipStream_t)stream) : tn_launch_train_bwd(a, (hipStream_t)stream);
+    return tn_launch_train_bwd(a, (hipStream_t)stream);
 }
 
 extern "C" int tnerf_wgrad(const tnerf_mlp_desc* d, const float* stash, int64_t Mp, int64_t M, const int32_t* job_table, int64_t n_jobs,
@@ -94,7 +89,6 @@ int tn_train_fwd_impl(const char* who, const tnerf_mlp_desc* d, const float* pac
     if (rc) return rc;
     if (!comp || !stash || Mp < R * S) { tn_set_error("%s: comp=%p stash=%p Mp=%lld < R*S=%lld", who, (void*)comp, (void*)stash, (long long)Mp, (long long)(R * S)); return TNERF_EINVAL; }
     a.comp = comp; a.stash = stash; a.Mp = Mp;
-    if (tn_use_pair()) return tn_launch_fwd_pair(a, true, stream, who);
     return tn_launch_fwd(a, true, true, R, stream, who);
 }
 
@@ -152,11 +146,11 @@ typedef int (*fn_allreduce)(const void*, void*, size_t, int, int, void*, hipStre
 typedef const char* (*fn_errstr)(int);
 struct Rccl { void* h; fn_get_uid get_uid; fn_init_rank init_rank; fn_destroy destroy; fn_allreduce allreduce; fn_errstr errstr; };
 
+// The dlopen'ed function table is filled exactly once (std::call_once) and never changes afterwards.
 static Rccl* rccl() {
     static Rccl r{};
-    static bool tried = false;
-    if (!tried) {
-        tried = true;
+    static std::once_flag once;
+    std::call_once(once, [] {
         const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
         for (const char* n : names) { r.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (r.h) break; }
         if (r.h) {
@@ -166,7 +160,7 @@ static Rccl* rccl() {
             r.allreduce = (fn_allreduce)dlsym(r.h, "ncclAllReduce");
             r.errstr = (fn_errstr)dlsym(r.h, "ncclGetErrorString");
         }
-    }
+    });
     if (!r.h || !r.get_uid || !r.init_rank || !r.destroy || !r.allreduce) { tn_set_error("RCCL (librccl.so) could not be loaded: %s", dlerror()); return nullptr; }
     return &r;
 }

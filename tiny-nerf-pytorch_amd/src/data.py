@@ -10,7 +10,7 @@ def load_tiny_nerf_npz(path: str = "data/tiny_nerf_data.npz") -> Dict[str, Any]:
     """npz -> dict with 'images' (N,H,W,3), 'poses' (N,4,4), 'focal'; float64 arrays become float32.
     [reference src/data.py:4-13]"""
     with np.load(path) as z:
-        return {k: (z[k].astype(np.float32) if z[k].dtype == np.float64 else z[k]) for k in z.files}
+        return {k: (v.astype(np.float32) if v.dtype == np.float64 else v) for k, v in ((k, z[k]) for k in z.files)}
 
 
 # ---------------------------------------------------------------------------- synthetic scene
@@ -75,10 +75,15 @@ def make_synthetic_scene(n_images: int = 106, H: int = 100, W: int = 100, focal:
             "focal": np.float32(focal)}
 
 
+SYNTHETIC = "synthetic"
+
+
 def load_scene(path: str = "data/tiny_nerf_data.npz", **synthetic_kwargs) -> Dict[str, Any]:
-    """The real npz if it exists, otherwise the seeded synthetic scene (tagged with 'synthetic': True)."""
-    if os.path.exists(path):
-        d = load_tiny_nerf_npz(path); d["synthetic"] = False
+    """load_tiny_nerf_npz(path) — a missing file raises FileNotFoundError exactly like the reference (src/data.py:9,
+    src/train.py:71) — unless `path` is the explicit sentinel "synthetic": then the seeded stand-in scene is built
+    (tagged 'synthetic': True).  There is no silent fallback: a typo in --data-path must not train on fake data."""
+    if path == SYNTHETIC:
+        d = make_synthetic_scene(**synthetic_kwargs); d["synthetic"] = True
         return d
-    d = make_synthetic_scene(**synthetic_kwargs); d["synthetic"] = True
+    d = load_tiny_nerf_npz(path); d["synthetic"] = False
     return d

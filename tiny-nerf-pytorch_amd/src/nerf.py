@@ -45,7 +45,7 @@ class TinyNeRF(nn.Module):
             if self.skip_at == self.depth:
                 raise RuntimeError("TinyNeRF: skip_at == depth feeds hidden+in_dim features to the heads")
             st = self._hip = ops.ModelState(self.in_dim, self.hidden, self.depth, skip, dev)
-        if params[0].data_ptr() != st.flat.data_ptr() or params[-1].data_ptr() != st.flat.data_ptr() + 4 * st.offsets[-1]:
+        if not st.owns(params):          # first use, or some parameter was rebound since: re-adopt all of them
             st.adopt(params)
         return st
 

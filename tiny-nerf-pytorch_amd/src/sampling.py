@@ -12,10 +12,10 @@ def stratified_samples(near, far, n_samples, rays_o, rays_d, randomized=True):
     lerp in the kernel).  The jitter is drawn with torch.rand on the rays' device — the same generator
     call the reference makes with rand_like (sampling.py:24).
     """
-    if isinstance(near, torch.Tensor) or isinstance(far, torch.Tensor):
-        raise NotImplementedError("stratified_samples (HIP): per-ray near/far tensors are not built; pass floats")
     t_rand = None
     if randomized:
         t_rand = torch.rand(rays_o.shape[0], int(n_samples), dtype=torch.float32, device=rays_o.device)
+    if isinstance(near, torch.Tensor) or isinstance(far, torch.Tensor):      # "tensors broadcastable to (N_rays, 1)", sampling.py:8
+        return ops.sample_along_rays_per_ray(near, far, int(n_samples), rays_o, rays_d, bool(randomized), t_rand)
     z_vals, pts, _ = ops.sample_along_rays(float(near), float(far), int(n_samples), rays_o, rays_d, bool(randomized), t_rand)
     return z_vals, pts

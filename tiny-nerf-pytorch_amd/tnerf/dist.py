@@ -50,3 +50,14 @@ def all_gather_rows(local: torch.Tensor, n_total: int) -> torch.Tensor:
     parts = [torch.empty_like(pad) for _ in range(ws)]
     dist.all_gather(parts, pad)
     return torch.cat([p[: hi - lo] for p, (lo, hi) in zip(parts, sizes)], dim=0)
+
+
+def deal_round_robin(n: int, rank: int, world_size: int):
+    """Whole work items (novel-view frames) dealt round-robin: rank r takes items r, r+world, ..."""
+    return list(range(int(rank), int(n), int(world_size)))
+
+
+def merge_round_robin(parts, n: int):
+    """Inverse of deal_round_robin: parts[r] is rank r's list in its own order; returns the n items in global order."""
+    world_size = len(parts)
+    return [parts[k % world_size][k // world_size] for k in range(int(n))]

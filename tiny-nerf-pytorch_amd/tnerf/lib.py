@@ -49,6 +49,7 @@ SIGNATURES = {
     "tnerf_plan_fill": (C.c_int, [_DESC, _I64, _I32, _P, _P, _P]),
     "tnerf_get_rays": (C.c_int, [_I32, _I32, _F, _P, _P, _P, _P]),
     "tnerf_sample_encode_fwd": (C.c_int, [_P, _P, _I64, _I32, _P, _I32, _P, _U64, _U64, _P, _P, _P, _I32, _I32, _P]),
+    "tnerf_sample_per_ray_fwd": (C.c_int, [_P, _P, _I64, _I32, _P, _P, _P, _I32, _P, _U64, _U64, _P, _P, _P]),
     "tnerf_posenc_fwd": (C.c_int, [_P, _I64, _I32, _I32, _P, _P]),
     "tnerf_composite_fwd": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _I32, _P, _P, _P, _P, _P]),
     "tnerf_composite_bwd": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _I32, _P, _P, _P, _P, _P, _P, _P]),
@@ -100,8 +101,14 @@ def load():
                 f"{LIB_PATH} is missing: build it with `python __graft_entry__.py build` "
                 "(tiny-nerf-pytorch_amd/csrc/build.sh).  The HIP path has no CPU fallback.")
         lib = C.CDLL(LIB_PATH)
+        host_only = bool(os.environ.get("TNERF_HOST_ONLY"))      # sanitizer build of csrc/host_plan.cpp alone (tests/test_host_sanitizers.py)
         for name, (res, args) in SIGNATURES.items():
-            fn = getattr(lib, name)          # AttributeError if the .so does not export it
+            try:
+                fn = getattr(lib, name)      # AttributeError if the .so does not export it
+            except AttributeError:
+                if host_only:
+                    continue
+                raise
             fn.restype, fn.argtypes = res, args
         if lib.tnerf_version() != 1:
             raise RuntimeError(f"libtnerf_hip.so ABI version {lib.tnerf_version()} != 1")

@@ -114,6 +114,39 @@ def sample_along_rays(near: float, far: float, n_samples: int, rays_o: torch.Ten
     return z, pts, enc
 
 
+_TTAB: Dict[Tuple, torch.Tensor] = {}
+
+
+def sample_along_rays_per_ray(near, far, n_samples: int, rays_o: torch.Tensor, rays_d: torch.Tensor, randomized: bool,
+                              t_rand: Optional[torch.Tensor] = None, philox=None):
+    """stratified_samples with near / far given as tensors broadcastable to (R, 1) (reference src/sampling.py:8):
+    every ray has its own bins.  Python floats mixed with tensors are rounded to fp32 as torch's scalar ops do."""
+    dev = _need_cuda(rays_o, rays_d, t_rand)
+    rays_o, rays_d = _f32c(rays_o), _f32c(rays_d)
+    R, S = rays_o.shape[0], int(n_samples)
+
+    def per_ray(v):
+        t = torch.as_tensor(v, dtype=torch.float32).to(dev)
+        return torch.broadcast_to(t, (R, 1)).reshape(R).contiguous()        # raises like the reference's broadcast would
+    nr, fr = per_ray(near), per_ray(far)
+    key = (S, str(dev))
+    ttab = _TTAB.get(key)
+    if ttab is None:
+        z3, th = np.empty(3 * S, np.float32), np.empty(S, np.float32)
+        _l.call("tnerf_sample_tables", 0.0, 1.0, S, z3.ctypes.data_as(C.c_void_p), th.ctypes.data_as(C.c_void_p))
+        ttab = _TTAB[key] = torch.from_numpy(th).to(dev)
+    rnd, tr, seed, off = _rng_args(randomized, t_rand, philox)
+    if tr is not None:
+        tr = _f32c(tr)
+        if tr.shape != (R, S):
+            raise ValueError(f"t_rand must be ({R},{S})")
+    z = torch.empty(R, S, dtype=torch.float32, device=dev)
+    pts = torch.empty(R, S, 3, dtype=torch.float32, device=dev)
+    _l.call("tnerf_sample_per_ray_fwd", rays_o.data_ptr(), rays_d.data_ptr(), R, S, ttab.data_ptr(), nr.data_ptr(), fr.data_ptr(),
+            rnd, _ptr(tr), seed, off, z.data_ptr(), pts.data_ptr(), _stream(dev))
+    return z, pts
+
+
 def posenc(x: torch.Tensor, num_freqs: int, include_input: bool) -> torch.Tensor:
     dev = _need_cuda(x)
     lead = x.shape[:-1]
@@ -178,6 +211,34 @@ class _Plan:
         self.reduce = torch.from_numpy(red).to(dev)
         self.stash = torch.empty(sz.stash_floats, dtype=torch.float32, device=dev)
         self.slabs = torch.empty(sz.slab_floats, dtype=torch.float32, device=dev)
+        self._free = [self.stash]          # stash buffers nobody holds (see lease())
+
+    def lease(self) -> "_StashLease":
+        """Exclusive use of ONE stash buffer until the lease object dies.  A training forward writes the activations
+        its backward needs into the stash; an autograd node keeps its lease alive in `ctx`, so a second forward of the
+        same size before the first backward (two batches summed into one loss, a grad-enabled validation pass) gets a
+        buffer of its own instead of overwriting the first one's activations."""
+        return _StashLease(self)
+
+
+class _StashLease:
+    def __init__(self, plan: _Plan):
+        self.plan = plan
+        self.buf = plan._free.pop() if plan._free else torch.empty_like(plan.stash)
+
+    def release(self):
+        if self.buf is not None:
+            if len(self.plan._free) < 2:                  # the primary buffer + one spare; larger pools go back to the allocator
+                self.plan._free.append(self.buf)
+            self.buf = None
+
+    __del__ = release
+
+    def __enter__(self):
+        return self.buf
+
+    def __exit__(self, *exc):
+        self.release()
 
 
 class ModelState:
@@ -208,6 +269,7 @@ class ModelState:
         self.packed = torch.empty(self.packed_floats, dtype=torch.float32, device=device)
         self.packed_key = None
         self.plans: Dict[int, _Plan] = {}
+        self.adopted_ptrs: Tuple[int, ...] = ()
         self.bf16: Optional[_Bf16State] = None          # built on first use of the bf16 mode
 
     def plan(self, M: int) -> _Plan:
@@ -227,9 +289,15 @@ class ModelState:
                 if p.data_ptr() != view.data_ptr():
                     view.copy_(p.data)
                     p.data = view
+        self.adopted_ptrs = tuple(p.data_ptr() for p in params)
         self.packed_key = None
         if self.bf16 is not None:
             self.bf16.key = None
+
+    def owns(self, params) -> bool:
+        """True while EVERY parameter is still the view into the flat buffer that adopt() made (2*depth+4 pointer
+        compares): rebinding any one of them (`layer.weight = nn.Parameter(..)`, `p.data = ..`) is noticed."""
+        return tuple(p.data_ptr() for p in params) == self.adopted_ptrs
 
     def repack(self, key=None) -> None:
         if key is not None and key == self.packed_key:
@@ -306,24 +374,29 @@ class _MlpFn(torch.autograd.Function):
         rgb = torch.empty(M, 3, dtype=torch.float32, device=dev)
         sigma = torch.empty(M, 1, dtype=torch.float32, device=dev)
         plan = st.plan(M) if train else None
+        lease = plan.lease() if train else None
         _l.call("tnerf_mlp_fwd", C.byref(st.desc), st.packed.data_ptr(), x.data_ptr(), M, rgb.data_ptr(), sigma.data_ptr(),
-                plan.stash.data_ptr() if train else None, plan.Mp if train else 0, _stream(dev))
-        ctx.st, ctx.plan, ctx.M = st, plan, M
+                lease.buf.data_ptr() if train else None, plan.Mp if train else 0, _stream(dev))
+        ctx.st, ctx.plan, ctx.M, ctx.lease = st, plan, M, lease
         ctx.shapes = [p.shape for p in params]
         return rgb, sigma
 
     @staticmethod
     def backward(ctx, g_rgb, g_sigma):
-        st, plan, M = ctx.st, ctx.plan, ctx.M
+        st, plan, M, lease = ctx.st, ctx.plan, ctx.M, ctx.lease
         if plan is None:
             raise RuntimeError("TinyNeRF (HIP): backward through a forward that ran without grad enabled")
+        if lease.buf is None:
+            raise RuntimeError("TinyNeRF (HIP): backward called twice on the same forward (its activation stash was released; "
+                               "retain_graph is not supported)")
         dev = st.device
         g_rgb = torch.zeros(M, 3, dtype=torch.float32, device=dev) if g_rgb is None else _f32c(g_rgb)
         g_sigma = torch.zeros(M, 1, dtype=torch.float32, device=dev) if g_sigma is None else _f32c(g_sigma)
         _l.call("tnerf_mlp_bwd", C.byref(st.desc), st.packed.data_ptr(), M, g_rgb.data_ptr(), g_sigma.data_ptr(),
-                plan.stash.data_ptr(), plan.Mp, plan.jobs.data_ptr(), plan.n_jobs, plan.slabs.data_ptr(), plan.reduce.data_ptr(),
+                lease.buf.data_ptr(), plan.Mp, plan.jobs.data_ptr(), plan.n_jobs, plan.slabs.data_ptr(), plan.reduce.data_ptr(),
                 st.grad.data_ptr(), _stream(dev))
         grads = [st.grad[o:o + int(np.prod(s))].view(s).clone() for s, o in zip(ctx.shapes, st.offsets)]
+        lease.release()
         return (None, None, None, *grads)
 
 
@@ -349,11 +422,13 @@ class _FusedRaysFn(torch.autograd.Function):
         comp = torch.empty(R, 3, dtype=torch.float32, device=dev)
         if train:
             plan = st.plan(R * S)
+            lease = plan.lease()
             _l.call("tnerf_train_fwd_fused", C.byref(st.desc), st.packed.data_ptr(), rays_o.data_ptr(), rays_d.data_ptr(), R, S,
-                    ztab.data_ptr(), rnd, _ptr(t_rand), seed, off, white, comp.data_ptr(), plan.stash.data_ptr(), plan.Mp,
+                    ztab.data_ptr(), rnd, _ptr(t_rand), seed, off, white, comp.data_ptr(), lease.buf.data_ptr(), plan.Mp,
                     _stream(dev))
             ctx.save_for_backward(rays_o, rays_d, ztab, t_rand if t_rand is not None else ztab)
             ctx.args = (st, plan, R, S, rnd, t_rand is not None, seed, off, white)
+            ctx.lease = lease
             ctx.shapes = [p.shape for p in params]
             return comp, None, None
         depth = torch.empty(R, 1, dtype=torch.float32, device=dev)
@@ -371,11 +446,15 @@ class _FusedRaysFn(torch.autograd.Function):
         rays_o, rays_d, ztab, t_rand = ctx.saved_tensors
         dev = st.device
         g_comp = _f32c(g_comp)
+        lease = ctx.lease
+        if lease.buf is None:
+            raise RuntimeError("fused render (HIP): backward called twice on the same forward (retain_graph is not supported)")
         _l.call("tnerf_train_bwd_fused", C.byref(st.desc), st.packed.data_ptr(), rays_o.data_ptr(), rays_d.data_ptr(), R, S,
                 ztab.data_ptr(), rnd, t_rand.data_ptr() if has_tr else None, seed, off, white, g_comp.data_ptr(),
-                plan.stash.data_ptr(), plan.Mp, plan.jobs.data_ptr(), plan.n_jobs, plan.slabs.data_ptr(), plan.reduce.data_ptr(),
+                lease.buf.data_ptr(), plan.Mp, plan.jobs.data_ptr(), plan.n_jobs, plan.slabs.data_ptr(), plan.reduce.data_ptr(),
                 st.grad.data_ptr(), _stream(dev))
         grads = [st.grad[o:o + int(np.prod(s))].view(s).clone() for s, o in zip(ctx.shapes, st.offsets)]
+        lease.release()
         return (None,) * 11 + tuple(grads)
 
 

@@ -20,6 +20,7 @@ class FlatAdam(torch.optim.Optimizer):
     """Adam(lr, betas=(0.9,0.999), eps=1e-8, weight_decay=0) as ONE kernel over the model's flat buffer."""
 
     def __init__(self, model, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8):
+        self._model = model
         self._st: _ops.ModelState = model.hip_state()
         params = list(model.parameters())
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False, maximize=False,
@@ -57,7 +58,9 @@ class FlatAdam(torch.optim.Optimizer):
     def step(self, closure=None, grads_in_flat: bool = False, grad_scale: float = 1.0):
         """grads_in_flat=True: the gradient already sits in the model's flat grad buffer (fused step);
         otherwise p.grad of every parameter is gathered into it first."""
-        st = self._st
+        st = self._model.hip_state()             # re-adopts the parameters if one of them was rebound since the last step
+        if st is not self._st:
+            raise RuntimeError("FlatAdam: the model moved to another device after the optimizer was built")
         if not grads_in_flat:
             for p, gv in zip(self._params, st.grad_views(self._params)):
                 if p.grad is None:
@@ -131,11 +134,12 @@ class FusedTrainer:
             return self.loss, self._comp
         self.model._ensure_packed()
         plan = st.plan(R * self.S)
-        _l.call("tnerf_train_step_fused", C.byref(st.desc), st.packed.data_ptr(), rays_o.data_ptr(), rays_d.data_ptr(),
-                target.data_ptr(), R, self.S, ztab.data_ptr(), rnd, _ops._ptr(tr), seed, off, self.white, denom,
-                self._comp.data_ptr(), self._gws.data_ptr(), self.loss.data_ptr(), plan.stash.data_ptr(), plan.Mp,
-                plan.jobs.data_ptr(), plan.n_jobs, plan.slabs.data_ptr(), plan.reduce.data_ptr(), st.grad.data_ptr(),
-                torch.cuda.current_stream(dev).cuda_stream)
+        with plan.lease() as stash:               # not the buffer a pending autograd node of the same size may still hold
+            _l.call("tnerf_train_step_fused", C.byref(st.desc), st.packed.data_ptr(), rays_o.data_ptr(), rays_d.data_ptr(),
+                    target.data_ptr(), R, self.S, ztab.data_ptr(), rnd, _ops._ptr(tr), seed, off, self.white, denom,
+                    self._comp.data_ptr(), self._gws.data_ptr(), self.loss.data_ptr(), stash.data_ptr(), plan.Mp,
+                    plan.jobs.data_ptr(), plan.n_jobs, plan.slabs.data_ptr(), plan.reduce.data_ptr(), st.grad.data_ptr(),
+                    torch.cuda.current_stream(dev).cuda_stream)
         _dist.all_reduce_sum_(st.grad)
         self.opt.step(grads_in_flat=True)
         return self.loss, self._comp
@@ -170,10 +174,11 @@ class FusedTrainer:
             return self.loss, self._comp
         self.model._ensure_packed()
         plan = st.plan(R * self.S)
-        _l.call("tnerf_train_step_fused_cam", C.byref(st.desc), st.packed.data_ptr(), C.byref(cam), pixels.data_ptr(), R, self.S,
-                ztab.data_ptr(), rnd, _ops._ptr(tr), seed, off, self.white, denom, self._comp.data_ptr(), self._gws.data_ptr(),
-                self.loss.data_ptr(), plan.stash.data_ptr(), plan.Mp, plan.jobs.data_ptr(), plan.n_jobs, plan.slabs.data_ptr(),
-                plan.reduce.data_ptr(), st.grad.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+        with plan.lease() as stash:
+            _l.call("tnerf_train_step_fused_cam", C.byref(st.desc), st.packed.data_ptr(), C.byref(cam), pixels.data_ptr(), R, self.S,
+                    ztab.data_ptr(), rnd, _ops._ptr(tr), seed, off, self.white, denom, self._comp.data_ptr(), self._gws.data_ptr(),
+                    self.loss.data_ptr(), stash.data_ptr(), plan.Mp, plan.jobs.data_ptr(), plan.n_jobs, plan.slabs.data_ptr(),
+                    plan.reduce.data_ptr(), st.grad.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
         _dist.all_reduce_sum_(st.grad)
         self.opt.step(grads_in_flat=True)
         return self.loss, self._comp
