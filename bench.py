@@ -149,7 +149,11 @@ def parse_args(argv=None):
                     help="weak: 4096 rays per GPU per step; strong: 4096 rays per step in total (SURVEY §8e)")
     ap.add_argument("--psnr-steps", type=int, default=1000, help="extra untimed steps before reporting PSNR (rank 0 context)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--philox", action="store_true", help="draw the jitter in-kernel (Philox) instead of torch.rand")
+    ap.add_argument("--parity-rng", action="store_true",
+                    help="draw pixel indices / jitter with torch.randint / torch.rand on the host side of every step, like the reference "
+                         "loop (parity path, one C-ABI call + optimizer call per step) instead of in the kernels from a device-side step "
+                         "counter (speed path: the whole step is one hipGraph replay)")
+    ap.add_argument("--no-graph", action="store_true", help="speed path without hipGraph capture (4 launches per step)")
     ap.add_argument("--no-bf16", action="store_true", help="skip the bf16-mode section (BASELINE.json configs[3])")
     ap.add_argument("--no-extra", action="store_true", help="skip the ref_default / cfg3 / cfg5 sections")
     ap.add_argument("--ray-tables", action="store_true",
@@ -187,6 +191,7 @@ def run(args):
     local_dev = local % n_dev                                             # TNERF_SHARE_GPU=1: rehearse N ranks on fewer cards (gloo)
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
+    torch.cuda.set_stream(torch.cuda.Stream(dev))       # a capturable stream of our own for everything below (hipGraph needs a non-NULL stream)
     use_dist = world > 1 or bool(os.environ.get("TNERF_FORCE_DIST"))      # the env var exercises RCCL init with one rank
     backend = os.environ.get("TNERF_DIST_BACKEND", "nccl")                # "nccl" IS RCCL on ROCm
     if use_dist:
@@ -220,7 +225,7 @@ def run(args):
 
     encoder = PositionalEncoding(L_FREQS, True).to(dev)
 
-    def make_trainer(precision, L=L_FREQS, hidden=HIDDEN, depth=DEPTH, skip=SKIP, samples=SAMPLES):
+    def make_trainer(precision, L=L_FREQS, hidden=HIDDEN, depth=DEPTH, skip=SKIP, samples=SAMPLES, scene_t=None, rays_global=None):
         torch.manual_seed(0)                               # identical initial weights on every rank (and in both modes)
         mdl = nerf_mod.TinyNeRF(6 * L + 3, hidden, depth, skip).to(dev)
         with torch.no_grad():
@@ -229,7 +234,11 @@ def run(args):
             # timed on zeros (which clock higher).  Nudge the bias so the network is alive, as the fixtures do.
             mdl.sigma[0].bias += 0.5
         op = trainer.FlatAdam(mdl, lr=LR)
-        return mdl, op, trainer.FusedTrainer(mdl, op, NEAR, FAR, samples, precision=precision)
+        if args.parity_rng:
+            return mdl, op, trainer.FusedTrainer(mdl, op, NEAR, FAR, samples, precision=precision)
+        imgs, pss, fc = scene_t if scene_t is not None else (images, poses, focal)
+        return mdl, op, trainer.DatasetTrainer(mdl, op, imgs, pss, fc, rays_global if rays_global is not None else R_global, samples, NEAR, FAR,
+                                               seed=1234, precision=precision, graph=not args.no_graph)
 
     model, opt, tr = make_trainer("fp32")
 
@@ -251,14 +260,12 @@ def run(args):
         c = run_
         tr = c["tr"]
         s = state["step"]; state["step"] += 1
+        if not args.parity_rng:
+            return tr.step()                               # image index, pixel and jitter draws: in the kernels (device step counter)
         img_i = s % c["N"]
         Rg, lo, hi, S = c["R_global"], c["lo"], c["hi"], c["S"]
         inds = torch.randint(0, c["H"] * c["W"], (Rg,), device=dev, generator=gen)[lo:hi]
-        kw = dict(global_rays=Rg)
-        if args.philox:
-            kw["philox"] = (1234, s * Rg * S + lo * S)
-        else:
-            kw["t_rand"] = torch.rand(Rg, S, device=dev, generator=gen)[lo:hi]
+        kw = dict(global_rays=Rg, t_rand=torch.rand(Rg, S, device=dev, generator=gen)[lo:hi])
         if args.ray_tables:
             return tr.step(all_o[img_i, inds], all_d[img_i, inds], c["pixels"][img_i, inds], **kw)
         return tr.step_camera(c["poses"][img_i], c["H"], c["W"], c["focal"], inds, c["pixels"][img_i], **kw)
@@ -303,7 +310,8 @@ def run(args):
                                   f"64 samples/ray, {'4096 rays per GPU' if args.scaling == 'weak' else '4096 rays in total'} per step, "
                                   "Adam, fp32 (BASELINE.json configs[1])",
                       "rays_per_step_global": R_global, "rays_per_gpu": R_local, "samples_per_ray": SAMPLES,
-                      "jitter": "philox-in-kernel" if args.philox else "torch.rand",
+                      "rng": "torch.randint + torch.rand per step (parity path)" if args.parity_rng else
+                             "Philox in the kernels from a device-side step counter; step = one hipGraph replay" + (" (graph off)" if args.no_graph or world > 1 else ""),
                       "rays": "precomputed tables + gather" if args.ray_tables else "generated in-kernel from pose + pixel index",
                       "parallelism": f"rays sharded x{world} ({args.scaling}), 1 all-reduce of {opt._st.n_params * 4} B per step" if world > 1 else "single GPU"}}
 
@@ -346,6 +354,8 @@ def run(args):
                 "wgrad": lambda: lib.call("tnerf_wgrad", C.byref(st.desc), plan.stash.data_ptr(), plan.Mp, R * S, plan.jobs.data_ptr(), plan.n_jobs, plan.slabs.data_ptr(), sp),
                 "reduce": lambda: lib.call("tnerf_wgrad_reduce", plan.slabs.data_ptr(), plan.reduce.data_ptr(), st.n_params, st.grad.data_ptr(), sp),
             }
+            d32 = lib.MlpDesc(st.desc.in_dim, st.desc.hidden, st.desc.depth, st.desc.skip_at, lib.FLAG_FP32_MFMA)
+            calls["wgrad_fp32_mfma"] = lambda: lib.call("tnerf_wgrad", C.byref(d32), plan.stash.data_ptr(), plan.Mp, R * S, plan.jobs.data_ptr(), plan.n_jobs, plan.slabs.data_ptr(), sp)
         else:
             b = st.repack_bf16(); bp = b.train_plan(R, S)
             common = (C.byref(st.desc), b.packed.data_ptr(), ro.data_ptr(), rd.data_ptr(), R, S, ztab.data_ptr(), 1, u.data_ptr(), 0, 0, 1)
@@ -371,6 +381,7 @@ def run(args):
                            "traffic": cap[dom]["hbm_bytes"] if cap and dom in cap else None,
                            "traffic_source": f"profiles/r02_traffic.json (PMC passes on kernel sources {cap['kernel_source_sha']})" if cap and dom in cap else None,
                            "flops_per_launch": fl[dom], "ms_per_launch": kern[dom]}
+        fl["wgrad_fp32_mfma"] = fl["wgrad"]
         out["kernels"] = {k: {"ms": kern[k], "tflops": (fl[k] / (kern[k] * 1e-3) / 1e12) if k in fl else None,
                               "mfma_frac": (fl[k] / (kern[k] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS) if k in fl else None} for k in kern}
         if args.scaling == "weak" or world == 1:
@@ -464,7 +475,7 @@ def run(args):
             Rg = world * rays if args.scaling == "weak" else rays
             l0, h0 = tdist.shard_bounds(Rg, rank, world)
             for prec in ("fp32", "bf16"):
-                mdl, op, t_ = make_trainer(prec, L, hidden, depth, skip, samples)
+                mdl, op, t_ = make_trainer(prec, L, hidden, depth, skip, samples, scene_t=scene_t, rays_global=Rg)
                 run_.update(tr=t_, R_global=Rg, lo=l0, hi=h0, S=samples, pixels=imgs.view(n, h * w, 3), poses=pss, H=h, W=w, focal=fc, N=n)
                 d_ = timed(warm, steps)
                 f, dg, wg = mlp_macs(6 * L + 3, hidden, depth, skip)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define TNERF_ABI_VERSION 1
+#define TNERF_ABI_VERSION 2
 
 #define TNERF_OK            0
 #define TNERF_EINVAL       (-1)  /* bad size / NULL pointer / inconsistent arguments        */
@@ -44,7 +44,14 @@ typedef struct tnerf_mlp_desc {
     int32_t hidden;
     int32_t depth;
     int32_t skip_at;
+    int32_t flags;           /* TNERF_FLAG_* (ABI 2); 0 = defaults                                */
 } tnerf_mlp_desc;
+/* How the fp32 kernels form their fp32 products.  Default (0): on the bf16 matrix pipe by EXACT three-way splitting —
+ * an fp32 value is the sum of three bf16 numbers (8+8+8 mantissa bits), products of bf16 numbers are exact in fp32, six
+ * v_mfma_f32_32x32x16_bf16 with fp32 accumulation carry a*b up to terms below 2^-24 |ab| — fp32-grade results (measured
+ * against fp64: at least as accurate as an fp32 fma chain) at 6/16 of the fp32-MFMA time (CDNA4's bf16 matrix rate is 16x
+ * its fp32 rate).  TNERF_FLAG_FP32_MFMA selects v_mfma_f32_32x32x2_f32 (plain fp32 fma chains) instead. */
+#define TNERF_FLAG_FP32_MFMA 1
 
 /* Sizes (in elements) of everything the caller must allocate for a model + sample count. */
 typedef struct tnerf_plan_sizes {
@@ -208,6 +215,7 @@ int tnerf_wgrad_reduce(const float* slabs, const int32_t* reduce_table, int64_t 
 /* One whole minibatch step up to (not including) the optimizer (train.py:114-126):
  * forward, loss = sum((comp-target)^2)/loss_denominator, backward -> grads (overwritten),
  * loss_out[0] = this batch's loss contribution (device scalar), comp_rgb [R,3].
+ * g_comp_ws: workspace of 4*R floats (ABI 2: per ray dL/dcomp_rgb and the squared error, written by the forward kernel).
  * loss_denominator = 3*R reproduces torch.mean (train.py:122); a ray shard passes the GLOBAL 3*R. */
 int tnerf_train_step_fused(const tnerf_mlp_desc* d, const float* packed,
                            const float* rays_o, const float* rays_d, const float* target,
@@ -247,6 +255,65 @@ int tnerf_train_step_fused_cam(const tnerf_mlp_desc* d, const float* packed, con
                                float* stash, int64_t stash_row_stride,
                                const int32_t* job_table, int64_t n_jobs, float* slabs,
                                const int32_t* reduce_table, float* grads, tnerf_stream_t stream);
+
+/* -------------------------------------------------------------- the whole step on device-resident state */
+/* The body of the reference training loop (src/train.py:106-128) with NO per-step host input: which image (step % N,
+ * train.py:108), which pixels (torch.randint there, :109) and which jitter (rand_like, sampling.py:24) come from a
+ * device-side step counter and Philox4x32-10 inside the kernels; the loss gradient 2 (C - target) / denom (train.py:122)
+ * is formed by the forward kernel; the counter advances inside the weight-gradient kernel; slab reduction, Adam
+ * (train.py:80,125-128) and the re-packing of the updated weights are ONE finishing kernel.  One GPU: 4 launches per
+ * step whose arguments never change, so the step can be captured into a hipGraph (below) and replayed.
+ * Draws of step s (0-based) for global ray row g = ray_first + r, sample k:
+ *     pixel  = Philox(seed ^ 0x9E3779B97F4A7C15, s * n_rays_global + g)  mod  H*W           (32 random bits)
+ *     jitter = Philox(seed, (s * n_rays_global + g) * n_samples + k)  ->  24-bit uniform in [0,1)
+ * so ranks that shard the rows of one global batch draw exactly what one GPU would. */
+#define TNERF_PHASE_GRADIENT 1   /* forward + loss gradient + dgrad + wgrad -> slabs; *step += 1                       */
+#define TNERF_PHASE_REDUCE   2   /* slabs -> grads (fixed order), loss_out = sum of squared errors / denom             */
+#define TNERF_PHASE_UPDATE   4   /* Adam on (params, exp_avg, exp_avg_sq) with t = *step, scatter into `packed`        */
+typedef struct tnerf_step_args {
+    tnerf_mlp_desc desc;
+    int32_t precision;            /* 0: fp32 kernels, 1: bf16 mode                                                   */
+    int32_t phases;               /* TNERF_PHASE_* bits; REDUCE|UPDATE in one call = one kernel; multi-GPU: GRADIENT|REDUCE,
+                                     all-reduce of grads, then UPDATE                                                 */
+    /* dataset, resident in HBM */
+    const float* poses;           /* [n_images,16]                                                                   */
+    const float* pixels;          /* [n_images, H*W, 3]                                                              */
+    int32_t n_images, H, W;
+    float focal;
+    /* batch */
+    int64_t n_rays;               /* rays of THIS rank                                                               */
+    int64_t ray_first;            /* first global row of this rank (dist.shard_bounds)                               */
+    int64_t n_rays_global;        /* rows of the global batch                                                        */
+    int32_t n_samples, white_bkgd;
+    const float* ztab;            /* tnerf_sample_tables                                                             */
+    uint64_t seed;
+    double loss_denominator;      /* 3 * n_rays_global reproduces torch.mean                                         */
+    int64_t* step;                /* DEVICE: completed steps                                                         */
+    /* weights: fp32 fragment-packed floats (tnerf_mlp_pack) or the bf16 stream (tnerf_mlp_pack_bf16)                */
+    const void* packed;
+    /* workspaces */
+    float* comp_rgb;              /* [n_rays,3]                                                                      */
+    float* ray_ws;                /* [n_rays,4]: dL/dcomp_rgb and the squared error of every ray                     */
+    int32_t* pix_out;             /* [n_rays] or NULL: the pixel every ray trained on                                */
+    float* loss_out;              /* device scalar or NULL                                                           */
+    void* stash; int64_t stash_row_stride;      /* fp32: plan stash + its row stride; bf16: the tile stash            */
+    const int32_t* job_table; int64_t n_jobs; float* slabs;
+    const int32_t* reduce_table; float* grads;
+    /* optimizer */
+    float* params; float* exp_avg; float* exp_avg_sq;
+    float lr, beta1, beta2, eps;
+    const int32_t* scatter_table; /* [n_params, scatter_width]: positions of parameter i in `packed` (-1 terminated),
+                                     the inverse of the pack table; NULL = do not re-pack                            */
+    int32_t scatter_width;
+} tnerf_step_args;
+int tnerf_train_step_dataset(const tnerf_step_args* args, tnerf_stream_t stream);
+
+/* hipGraph capture of whatever the caller launches on `stream` (not the NULL stream) between begin and end — e.g. one
+ * tnerf_train_step_dataset call — and replay of the instantiated graph.  graph_exec is owned by the caller. */
+int tnerf_graph_begin(tnerf_stream_t stream);
+int tnerf_graph_end(tnerf_stream_t stream, void** graph_exec_out);
+int tnerf_graph_launch(void* graph_exec, tnerf_stream_t stream);
+int tnerf_graph_destroy(void* graph_exec);
 
 /* ------------------------------------------------------------------- bf16 mode (BASELINE cfg 4) */
 /* The same fused paths with bf16 weights and activations on v_mfma_f32_32x32x16_bf16: fp32 accumulation, fp32 biases,

@@ -401,3 +401,123 @@ def test_full_size_train_step_cfg3(mods, dev):
     la, ga = grad_of(0, 1500); lb, gb = grad_of(1500, 4096)
     assert abs(la + lb - l1) <= 1e-5 * l1
     assert float((ga + gb - g1).abs().max()) <= 2e-5 * float(g1.abs().max())
+
+
+# ------------------------------------------------------------ the whole step on device-resident state
+PIX_KEY = 0x9E3779B97F4A7C15
+
+
+def _emulated_draws(seed, step, Rg, S, HW):
+    """The draws tnerf_train_step_dataset documents (include/tnerf.h), from the numpy Philox of tests/test_host_logic.py."""
+    from test_host_logic import philox4x32_10
+    rows = np.uint64(step) * np.uint64(Rg) + np.arange(Rg, dtype=np.uint64)
+    pix = (philox4x32_10(seed ^ PIX_KEY, rows) % np.uint32(HW)).astype(np.int64)
+    idx = rows[:, None] * np.uint64(S) + np.arange(S, dtype=np.uint64)[None, :]
+    u = (philox4x32_10(seed, idx.reshape(-1)) & np.uint32(0xFFFFFF)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+    return torch.from_numpy(pix), torch.from_numpy(u.reshape(Rg, S))
+
+
+def _small_scene(mods, dev):
+    sc = mods["data"].make_synthetic_scene(n_images=5, H=20, W=20, focal=138.88887889922103 * 0.2, seed=4)
+    return torch.from_numpy(sc["images"]), torch.from_numpy(sc["poses"]), float(sc["focal"])
+
+
+@pytest.mark.parametrize("tag", ["4x128", "8x256"])
+def test_dataset_step_follows_the_oracle_on_emulated_draws(mods, dev, tag):
+    """tnerf_train_step_dataset (speed path): 5 steps of the whole loop body, hipGraph replay from step 2 on.  The pixel
+    and jitter draws the kernels make are re-derived on the host (numpy Philox), the pixel draw compared exactly, and
+    the CPU oracle driven with them must land on the same losses and weights."""
+    cfg, params = golden_params(tag)
+    images, poses, focal = _small_scene(mods, dev)
+    N, H, W, _ = images.shape
+    Rg, S, seed, lr = 96, 24, 77, 5e-4
+    model = make_model(mods, cfg, params, dev)
+    opt = mods["trainer"].FlatAdam(model, lr=lr)
+    tr = mods["trainer"].DatasetTrainer(model, opt, images.to(dev), poses.to(dev), focal, Rg, S, 2.0, 6.0, seed=seed, record_pixels=True)
+    ps = [p.clone() for p in params]
+    adam = O.AdamState(ps, lr=lr)
+    pixs = images.reshape(N, H * W, 3)
+    for s in range(5):
+        loss, comp = tr.step()
+        torch.cuda.synchronize()
+        pix, u = _emulated_draws(seed, s, Rg, S, H * W)
+        assert torch.equal(tr.pix.cpu().long(), pix), s                               # the in-kernel pixel draw, exactly
+        i = s % N
+        ro, rd = O.pinhole_rays(H, W, focal, poses[i])
+        lo_, _, grads = O.loss_and_grads(ps, cfg["skip_at"], cfg["L"], ro[pix], rd[pix], pixs[i, pix], 2.0, 6.0, S, u)
+        co, _, _, _ = O.render_rays(ps, cfg["skip_at"], cfg["L"], ro[pix], rd[pix], 2.0, 6.0, S, u)
+        assert float((comp.cpu() - co).abs().max()) <= RGB_TOL, s
+        assert math.isclose(float(loss), float(lo_), rel_tol=3e-4), (s, float(loss), float(lo_))
+        adam.step(ps, grads)
+    assert tr.steps_done == 5 and opt._t == 5 and tr._graph is not None
+    err = max(float((p.detach().cpu() - q).abs().max()) for p, q in zip(model.parameters(), ps))
+    assert err <= 5e-5, err
+    # the packed copy the finishing kernel maintains == a fresh pack of the same weights: identical pictures, bitwise
+    enc = mods["encoding"].PositionalEncoding(cfg["L"], True).to(dev)
+    img = mods["train"].render_one(model, enc, H, W, focal, poses[0], dev, n_samples=S)
+    fresh = make_model(mods, cfg, [p.detach().cpu() for p in model.parameters()], dev)
+    assert torch.equal(img, mods["train"].render_one(fresh, enc, H, W, focal, poses[0], dev, n_samples=S))
+    sd = opt.state_dict()
+    assert float(sd["state"][0]["step"]) == 5.0
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_dataset_step_equals_the_per_call_path_bitwise(mods, dev, prec):
+    """Same draws through three routes — (a) hipGraph replay, (b) the same entry point without a graph, (c) the per-call parity
+    API (tnerf_train_step_fused_cam with explicit pixel indices + Philox jitter offset, then tnerf_adam_step and a fresh
+    pack) — give bit-identical weights, losses and packed copies, in both precisions; and two ranks' shares of one step
+    add up to the full-batch gradient."""
+    cfg, params = golden_params("4x128")
+    images, poses, focal = _small_scene(mods, dev)
+    images_d, poses_d = images.to(dev), poses.to(dev)
+    N, H, W, _ = images.shape
+    Rg, S, seed = 80, 40, 5
+    T = mods["trainer"]
+
+    def run(graph):
+        m = make_model(mods, cfg, params, dev)
+        o = T.FlatAdam(m, lr=5e-4)
+        t = T.DatasetTrainer(m, o, images_d, poses_d, focal, Rg, S, 2.0, 6.0, seed=seed, precision=prec, graph=graph, record_pixels=True)
+        losses, pix = [], []
+        for _ in range(4):
+            l, _ = t.step()
+            losses.append(l.clone()); pix.append(t.pix.clone())
+        return m, torch.stack(losses), pix, t
+
+    ma, la, pixa, ta = run(True)
+    mb, lb, pixb, tb = run(False)
+    assert ta._graph is not None and tb._graph is None
+    assert torch.equal(la, lb) and all(torch.equal(a, b) for a, b in zip(ma.parameters(), mb.parameters()))
+    # (c) the per-call path with the same draws
+    mc = make_model(mods, cfg, params, dev)
+    oc = T.FlatAdam(mc, lr=5e-4)
+    tc = T.FusedTrainer(mc, oc, 2.0, 6.0, S, precision=prec)
+    pixels = images_d.view(N, H * W, 3)
+    lc = []
+    for s in range(4):
+        l, _ = tc.step_camera(poses_d[s % N], H, W, focal, pixa[s].long(), pixels[s % N], philox=(seed, s * Rg * S))
+        lc.append(l.clone())
+    assert torch.equal(torch.stack(lc), la)
+    for a, c in zip(ma.parameters(), mc.parameters()):
+        assert torch.equal(a, c)
+    sa, sc = ma.hip_state(), mc.hip_state()
+    if prec == "fp32":
+        mc._ensure_packed()
+        assert torch.equal(sa.packed, sc.packed)
+    else:
+        b = sc.repack_bf16(None)
+        assert torch.equal(ta._packed, b.packed)
+    # two shards of one global batch: gradients add up, pixel draws are the halves of the global draw
+    md = make_model(mods, cfg, params, dev)
+    full = T.DatasetTrainer(md, T.FlatAdam(md, lr=5e-4), images_d, poses_d, focal, Rg, S, 2.0, 6.0, seed=seed, precision=prec, graph=False, record_pixels=True, rank=0, world=1)
+    full.gradient_phase()
+    g_full, l_full = md.hip_state().grad.clone(), float(full.loss)
+    parts, pix_parts, l_parts = [], [], 0.0
+    for r in range(2):
+        mr = make_model(mods, cfg, params, dev)
+        tr_ = T.DatasetTrainer(mr, T.FlatAdam(mr, lr=5e-4), images_d, poses_d, focal, Rg, S, 2.0, 6.0, seed=seed, precision=prec, record_pixels=True, rank=r, world=2)
+        tr_.gradient_phase()
+        parts.append(mr.hip_state().grad.clone()); pix_parts.append(tr_.pix.clone()); l_parts += float(tr_.loss)
+    assert torch.equal(torch.cat(pix_parts), full.pix)
+    assert abs(l_parts - l_full) <= 1e-5 * l_full
+    assert float((parts[0] + parts[1] - g_full).abs().max()) <= (2e-5 if prec == "fp32" else 2e-3) * float(g_full.abs().max())

@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in tnerf.h but not exported"
         assert name in tl.SIGNATURES, f"{name} has no ctypes signature"
-    assert lib.tnerf_version() == 1
+    assert lib.tnerf_version() == 2
     assert tl.last_error() == "ok"
 
 
@@ -532,3 +532,66 @@ def test_oracle_bf16_forward_is_close_to_fp32():
     rgb16, sigma16 = O.mlp_forward_bf16(params, g["x"], cfg["skip_at"])
     assert float((rgb - rgb16).abs().max()) < 2e-2
     assert float((sigma - sigma16).abs().max()) <= 2e-2 * max(1.0, float(sigma.abs().max()))
+
+
+# ------------------------------------------------------------------------------- round 2: Philox draws of the dataset step
+def philox4x32_10(seed, index):
+    """numpy statement of the counter-based generator the kernels use (csrc/dev_common.hpp tn_philox_u32): Philox4x32-10,
+    counter = (index >> 2, 0, 0) as (c0 | c1 << 32), key = seed, output word index & 3.  Vectorised over `index` (uint64)."""
+    index = np.asarray(index, dtype=np.uint64)
+    blk = index >> np.uint64(2)
+    c0 = (blk & np.uint64(0xFFFFFFFF)).astype(np.uint64); c1 = (blk >> np.uint64(32)).astype(np.uint64)
+    c2 = np.zeros_like(c0); c3 = np.zeros_like(c0)
+    k0 = np.uint64(seed & 0xFFFFFFFF); k1 = np.uint64((seed >> 32) & 0xFFFFFFFF)
+    M0, M1, MASK = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0, p1 = M0 * c0, M1 * c2                       # 32x32 -> 64 bit products
+        h0, l0, h1, l1 = p0 >> np.uint64(32), p0 & MASK, p1 >> np.uint64(32), p1 & MASK
+        c0, c1, c2, c3 = (h1 ^ c1 ^ k0) & MASK, l1, (h0 ^ c3 ^ k1) & MASK, l0
+        k0 = (k0 + np.uint64(0x9E3779B9)) & MASK; k1 = (k1 + np.uint64(0xBB67AE85)) & MASK
+    w = (index & np.uint64(3)).astype(np.int64)
+    return np.choose(w, [c0, c1, c2, c3]).astype(np.uint32)
+
+
+def test_philox_emulation_known_answers():
+    """Random123's known-answer vectors for Philox4x32-10 (kat_vectors): counter 0 / key 0, and the all-ones vector."""
+    out = [int(philox4x32_10(0, i)) for i in range(4)]
+    assert out == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8], [hex(x) for x in out]
+    # counter = (ffffffff, ffffffff, 0, 0) is reachable through the index mapping only up to 2^62; check determinism / spread instead
+    a = philox4x32_10(1234, np.arange(4096, dtype=np.uint64))
+    b = philox4x32_10(1235, np.arange(4096, dtype=np.uint64))
+    assert len(set(a.tolist())) > 4090 and not np.array_equal(a, b)
+    u = (a & np.uint32(0xFFFFFF)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+    assert 0.0 <= float(u.min()) and float(u.max()) < 1.0 and abs(float(u.mean()) - 0.5) < 0.02
+
+
+def test_scatter_table_is_the_inverse_of_the_pack_table():
+    """The finishing kernel writes an updated weight straight to its packed positions: the scatter table must list, for
+    every parameter, exactly the positions the pack table reads it from (fp32 fragments and the bf16 stream)."""
+    from tnerf import trainer
+    for cfg in ((39, 256, 8, 4), (63, 128, 4, 2), (10, 128, 2, 1)):
+        d = _desc(*cfg)
+        lib = tl.load()
+        n_params = lib.tnerf_param_count(C.byref(d))
+        sz = tl.PlanSizes()
+        tl.call("tnerf_plan_sizes_query", C.byref(d), 64, 256, C.byref(sz))
+        tab = np.empty(sz.packed_floats, np.int32)
+        tl.call("tnerf_plan_fill", C.byref(d), 64, 256, _ptr(tab), None, None)
+        tabs = [tab]
+        if (cfg[0] - 3) % 6 == 0 and cfg[0] >= 9:
+            bs = tl.Bf16Sizes()
+            tl.call("tnerf_bf16_plan_sizes", C.byref(d), C.byref(bs))
+            t16 = np.empty(int(bs.pack_entries), np.int32)
+            tl.call("tnerf_bf16_pack_table", C.byref(d), _ptr(t16))
+            tabs.append(t16)
+        for t in tabs:
+            sc = trainer._scatter_table(t, n_params)
+            assert sc.shape[0] == n_params and 1 <= sc.shape[1] <= 4
+            rebuilt = np.full_like(t, -1)
+            for k in range(sc.shape[1]):
+                ok = sc[:, k] >= 0
+                rebuilt[sc[ok, k]] = np.nonzero(ok)[0]
+                if k + 1 < sc.shape[1]:
+                    assert not (sc[~ok, k + 1] >= 0).any()          # -1 terminated rows
+            assert np.array_equal(rebuilt, t)
+            assert (sc[:, 0] >= 0).all()                            # every parameter is packed somewhere

@@ -60,7 +60,12 @@ __device__ __forceinline__ int tn_lane() { return (int)(threadIdx.x & 63); }
 // torch's uniform_ for float.
 __device__ __forceinline__ uint32_t tn_mulhi(uint32_t a, uint32_t b) { return __umulhi(a, b); }
 
+__device__ __forceinline__ uint32_t tn_philox_u32(uint64_t seed, uint64_t index);
 __device__ __forceinline__ float tn_philox_uniform(uint64_t seed, uint64_t index) {
+    return (float)(tn_philox_u32(seed, index) & 0xFFFFFFu) * (1.0f / 16777216.0f);
+}
+// 32 random bits for counter `index` (the word (index & 3) of Philox block index >> 2)
+__device__ __forceinline__ uint32_t tn_philox_u32(uint64_t seed, uint64_t index) {
     uint32_t c0 = (uint32_t)(index >> 2), c1 = (uint32_t)(index >> 34), c2 = 0u, c3 = 0u;
     uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
 #pragma unroll
@@ -72,8 +77,7 @@ __device__ __forceinline__ float tn_philox_uniform(uint64_t seed, uint64_t index
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
     const uint32_t w = (uint32_t)(index & 3);
-    const uint32_t x = w == 0 ? c0 : (w == 1 ? c1 : (w == 2 ? c2 : c3));
-    return (float)(x & 0xFFFFFFu) * (1.0f / 16777216.0f);
+    return w == 0 ? c0 : (w == 1 ? c1 : (w == 2 ? c2 : c3));
 }
 
 // ------------------------------------------------------------------------------ sin / cos
@@ -110,6 +114,9 @@ struct SampleArgs {
     uint64_t seed, offset;
     int32_t S;
     int32_t randomized;
+    // dataset mode (tnerf_train_step_dataset): the Philox offset of this step is offset + *step * per_step, resolved once
+    // per kernel by tn_resolve_step
+    const int64_t* step; uint64_t per_step;
 };
 
 __device__ __forceinline__ float tn_depth(const SampleArgs& a, int64_t ray, int s) {
@@ -192,10 +199,33 @@ __device__ __forceinline__ void tn_glds16(const void* src, uint32_t voff, uint32
 //   tables : rays_o / rays_d [n,3] (what get_rays precomputed, reference src/train.py:94-101), row = index ? index[r] : r
 //   camera : c2w != NULL -> the ray of flat pixel p = index ? index[r] : first + r is generated in the kernel with
 //            exactly the arithmetic of k_get_rays (reference src/rays.py:15-32): no (N,HW,3) tables, no gathers.
+//   dataset: step != NULL (tnerf_train_step_dataset) -> c2w is the pose TABLE [n_images,16]; tn_resolve_step picks pose
+//            step % n_images and ray r trains on pixel Philox(seed, step * rays_global + ray_first + r) % (H*W) — the draw
+//            the reference makes with torch.randint (src/train.py:108-109), taken in the kernel.
 struct RaySource {
     const float* rays_o; const float* rays_d; const int64_t* index;
     const float* c2w; int64_t first; int32_t H, W; float focal;
+    const int64_t* step; int32_t n_images; int32_t image; uint64_t seed; int64_t ray_first, rays_global;
 };
+#define TN_PIX_KEY 0x9E3779B97F4A7C15ull      // the pixel draw and the jitter draw use different Philox keys
+
+// Dataset mode: read the device step counter ONCE and bind this launch's image / Philox counters (local copies).
+__device__ __forceinline__ int64_t tn_uniform64(int64_t v) {      // a wave-uniform value, moved to SGPRs
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)v >> 32));
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+// (Call it on LOCAL copies of the two small structs: writing into the kernel-argument block itself would turn the whole
+// block — with its runtime-indexed layout tables — into a scratch alloca.)
+__device__ __forceinline__ void tn_resolve_step(RaySource& rs, SampleArgs& sa) {
+    if (rs.step) {
+        const int64_t s = tn_uniform64(*rs.step);
+        rs.image = (int32_t)(s % rs.n_images);
+        rs.c2w += 16 * rs.image;
+        rs.first = s * rs.rays_global + rs.ray_first;           // Philox counter of ray 0 of this rank
+    }
+    if (sa.step) sa.offset += (uint64_t)tn_uniform64(*sa.step) * sa.per_step;
+}
 
 __device__ __forceinline__ void tn_pixel_ray(const float* __restrict__ c2w, int H, int W, float focal, int64_t p,
                                              float (&o)[3], float (&d)[3]) {
@@ -219,12 +249,45 @@ __device__ __forceinline__ void tn_pixel_ray(const float* __restrict__ c2w, int 
     for (int c = 0; c < 3; ++c) { d[c] = __fdiv_rn(w[c], n); o[c] = c2w[4 * c + 3]; }
 }
 
+// Flat pixel index of ray r (camera / dataset sources).
+__device__ __forceinline__ int64_t tn_ray_pixel(const RaySource& rs, int64_t r) {
+    if (rs.step) return (int64_t)(tn_philox_u32(rs.seed ^ TN_PIX_KEY, (uint64_t)(rs.first + r)) % (uint32_t)(rs.H * rs.W));
+    return rs.index ? rs.index[r] : rs.first + r;
+}
+
 __device__ __forceinline__ void tn_fetch_ray(const RaySource& rs, int64_t r, float (&o)[3], float (&d)[3]) {
     if (rs.c2w) {
-        tn_pixel_ray(rs.c2w, rs.H, rs.W, rs.focal, rs.index ? rs.index[r] : rs.first + r, o, d);
+        tn_pixel_ray(rs.c2w, rs.H, rs.W, rs.focal, tn_ray_pixel(rs, r), o, d);
     } else {
         const int64_t i = rs.index ? rs.index[r] : r;
 #pragma unroll
         for (int c = 0; c < 3; ++c) { o[c] = rs.rays_o[3 * i + c]; d[c] = rs.rays_d[3 * i + c]; }
     }
+}
+
+// ------------------------------------------------------------------------------ loss folded into the forward
+// MSE of the train step (reference src/train.py:122) evaluated where the composited colour is produced: the ray's wave
+// writes  ray_ws[4r + c] = dL/dC_c = 2 (C_c - target_c) / denom  and  ray_ws[4r + 3] = sum_c (C_c - target_c)^2;
+// the finishing kernel sums the fourth column in a fixed order into the loss.
+struct LossArgs {
+    const float* target;            // table source: [R,3] (or [.,3] indexed by target_index); camera: this image's [H*W,3]; dataset: [n_images,H*W,3]
+    const int64_t* target_index;    // NULL: row = ray (tables) / the ray's pixel (camera, dataset)
+    float inv_denom;
+    float* ray_ws;                  // [R,4]; NULL = no loss (inference / autograd path)
+    int32_t* pix_out;               // [R] or NULL: the pixel each ray trained on (dataset mode; lets a test replay the step)
+};
+__device__ __forceinline__ void tn_ray_loss(const LossArgs& la, const RaySource& rs, int64_t ray, float cr, float cg, float cb) {
+    int64_t row = ray;
+    if (rs.c2w) {
+        const int64_t p = tn_ray_pixel(rs, ray);
+        row = rs.step ? (int64_t)rs.image * rs.H * rs.W + p : p;
+        if (la.pix_out) la.pix_out[ray] = (int32_t)p;
+    } else if (la.target_index) {
+        row = la.target_index[ray];
+    }
+    const float d0 = cr - la.target[3 * row], d1 = cg - la.target[3 * row + 1], d2 = cb - la.target[3 * row + 2];
+    f32x4 w;
+    w[0] = (2.0f * d0) * la.inv_denom; w[1] = (2.0f * d1) * la.inv_denom; w[2] = (2.0f * d2) * la.inv_denom;
+    w[3] = (d0 * d0 + d1 * d1) + d2 * d2;
+    *reinterpret_cast<f32x4*>(la.ray_ws + 4 * ray) = w;
 }

@@ -90,7 +90,7 @@ extern "C" int tnerf_input_pairing(int32_t in_dim, int32_t* emap, int32_t* n_ste
 extern "C" int tn_build_layout(const tnerf_mlp_desc* d, MlpLayout* L) {
     int rc = check_desc(d); if (rc) return rc;
     memset(L, 0, sizeof(*L));
-    L->in_dim = d->in_dim; L->hidden = d->hidden; L->depth = d->depth; L->skip_at = d->skip_at;
+    L->in_dim = d->in_dim; L->hidden = d->hidden; L->depth = d->depth; L->skip_at = d->skip_at; L->flags = d->flags;
     L->NT = d->hidden / 32;
     int32_t em[64], ne;
     rc = tnerf_input_pairing(d->in_dim, em, &ne); if (rc) return rc;
@@ -150,6 +150,10 @@ extern "C" int tnerf_param_layout(const tnerf_mlp_desc* d, int64_t* offsets, int
 }
 
 // ------------------------------------------------------------------------------- wgrad plan
+#ifndef TN_X3_TILE
+#define TN_X3_TILE 875.0
+#define TN_X3_FIXED 2670.0
+#endif
 namespace {
 struct JobClass {
     int a_row0, a_rows, b_row0, b_rows, n_at, n_bt, wa, has_bias;
@@ -211,7 +215,10 @@ static int build_classes(const MlpLayout& L, int64_t M, int n_cu, std::vector<Jo
             if (cls[i].chunks >= MB) continue;
             // cycles per 32-sample block, measured (tools/wgrad_probe.py, LDS-DMA staging): 17.86k / 5.2k / 3.2k for
             // 8 / 2 / 1 tiles per wave, i.e. ~2107 per tile (16 MFMA steps of 64 cycles, two waves per SIMD) + ~1000 fixed
-            const double t = ((double)cls[i].cost * 2107.0 + 1000.0) * (double)((MB + cls[i].chunks - 1) / cls[i].chunks);
+            // The split-bf16 kernel (default pipe): ~TN_X3_TILE per tile + TN_X3_FIXED (tools/wgrad_x3_probe.py, -DTN_STAMPS build)
+            const double per_block = (L.flags & TNERF_FLAG_FP32_MFMA) ? (double)cls[i].cost * 2107.0 + 1000.0
+                                                                      : (double)cls[i].cost * TN_X3_TILE + TN_X3_FIXED;
+            const double t = per_block * (double)((MB + cls[i].chunks - 1) / cls[i].chunks);
             if (t > best_t) { best_t = t; best = (int)i; }
         }
         if (best < 0) break;

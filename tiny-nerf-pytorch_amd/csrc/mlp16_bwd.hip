@@ -106,7 +106,9 @@ __global__ __launch_bounds__(512, 2) void k_dgrad16(Fwd16Args a) {
     const int lane = tn_lane();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int j = lane & 31, h = lane >> 5;
-    const int S = a.sa.S;
+    RaySource rs = a.rs; SampleArgs sa = a.sa;
+    tn_resolve_step(rs, sa);
+    const int S = sa.S;
     const uint32_t sel_off = TN16_SEL_OFF(a.n.n_bias);
     Pipe16 p;
     tn16_prologue(p, lds, a.packed, a.n, a.packed + (int64_t)a.n.n_frag * 1024, a.n.n_bw_stage, lane, wave, true);
@@ -121,9 +123,10 @@ __global__ __launch_bounds__(512, 2) void k_dgrad16(Fwd16Args a) {
         const bool rvalid = ray < a.R;
         const int64_t rayc = rvalid ? ray : a.R - 1;
         float ro_[3], rd_[3];
-        tn_fetch_ray(a.rs, rayc, ro_, rd_);
+        tn_fetch_ray(rs, rayc, ro_, rd_);
         const float dn = tn_norm3(rd_[0], rd_[1], rd_[2]);
-        const float gr = rvalid ? a.g_comp[3 * rayc] : 0.f, gg = rvalid ? a.g_comp[3 * rayc + 1] : 0.f, gb = rvalid ? a.g_comp[3 * rayc + 2] : 0.f;
+        const int64_t gi = (int64_t)a.g_stride * rayc;
+        const float gr = rvalid ? a.g_comp[gi] : 0.f, gg = rvalid ? a.g_comp[gi + 1] : 0.f, gb = rvalid ? a.g_comp[gi + 2] : 0.f;
         const float gbg = a.white ? (gr + gg + gb) : 0.0f;
         const int64_t tile0 = rayc * TPR;                                   // head outputs are read from the real tiles
         auto outv = [&](int sc) TN_INLINE_LAMBDA { return out4[(tile0 + (sc >> 5)) * 32 + (sc & 31)]; };
@@ -132,8 +135,8 @@ __global__ __launch_bounds__(512, 2) void k_dgrad16(Fwd16Args a) {
         if (nseg > 1) {
             for (int sg_ = 0; sg_ < nseg; ++sg_) {
                 const int s = sg_ * 64 + lane; const bool ok = s < S; const int sc = ok ? s : S - 1;
-                const float z = tn_depth(a.sa, rayc, sc);
-                const float zn = (s + 1 < S) ? tn_depth(a.sa, rayc, s + 1) : z;
+                const float z = tn_depth(sa, rayc, sc);
+                const float zn = (s + 1 < S) ? tn_depth(sa, rayc, s + 1) : z;
                 const CompTerms t = tn_comp_terms(ok ? outv(sc)[3] : 0.f, z, zn, s == S - 1, dn);
                 const float pr = tn_wave_prod(ok ? t.om : 1.0f);
                 if (lane == sg_) segprod = pr;
@@ -148,8 +151,8 @@ __global__ __launch_bounds__(512, 2) void k_dgrad16(Fwd16Args a) {
             const f32x4 o4 = outv(sc);
             const float c0 = o4[0], c1 = o4[1], c2 = o4[2];
             const float sg = ok ? o4[3] : 0.f;
-            const float z = tn_depth(a.sa, rayc, sc);
-            const float zn = (s + 1 < S) ? tn_depth(a.sa, rayc, s + 1) : z;
+            const float z = tn_depth(sa, rayc, sc);
+            const float zn = (s + 1 < S) ? tn_depth(sa, rayc, s + 1) : z;
             const CompTerms t = tn_comp_terms(sg, z, zn, s == S - 1, dn);
             const float om = ok ? t.om : 1.0f;
             const float incl = tn_wave_scan_mul(om, lane);
@@ -210,6 +213,7 @@ int tn16_launch_dgrad(const Fwd16Args& a, hipStream_t stream, const char* who) {
 #define TN16W_SLOT 32768                 // A fragments at +0 (<= 16 KB), B fragments at +16 KB
 struct Wgrad16Args {
     const unsigned char* stash; const int32_t* jobs; float* slabs; int32_t n_ft;
+    int64_t* step_inc;      // dataset mode: the device step counter advances in this kernel (see k_wgrad)
 };
 
 // (A non-temporal DMA for this once-read stream measured 5 % slower.)
@@ -302,6 +306,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad16(Wgrad16Args a) {
     const int lane = tn_lane();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int32_t* job = a.jobs + (int64_t)blockIdx.x * TN_JOB_INTS;
+    if (a.step_inc && blockIdx.x == 0 && threadIdx.x == 0) *a.step_inc += 1;
     const int n_at = job[JOB_N_AT], n_bt = job[JOB_N_BT], WA = job[JOB_WA];
     const int ta = (n_at + WA - 1) / WA, tb = (n_bt + 8 / WA - 1) / (8 / WA);
     if (job[JOB_MBLKN] <= 0) return;
@@ -315,8 +320,8 @@ __global__ __launch_bounds__(512, 2) void k_wgrad16(Wgrad16Args a) {
            else                  tn16w_body<1, 1, 3>(a, job, lds, lane, wave); }    // heads 1 x 8: 18
 }
 
-int tn16_launch_wgrad(const Net16& n, const unsigned char* stash, const int32_t* jobs, int64_t n_jobs, float* slabs, hipStream_t stream) {
-    Wgrad16Args a{stash, jobs, slabs, n.n_ft};
+int tn16_launch_wgrad(const Net16& n, const unsigned char* stash, const int32_t* jobs, int64_t n_jobs, float* slabs, int64_t* step_inc, hipStream_t stream) {
+    Wgrad16Args a{stash, jobs, slabs, n.n_ft, step_inc};
     const size_t lds_bytes = TN16W_NS * TN16W_SLOT;
     static std::atomic<uint32_t> seen_[TN_MAX_DEVICES];
     if (int rc = tn_grant_dyn_lds(reinterpret_cast<const void*>(&k_wgrad16), lds_bytes, tn_stream_device(stream), seen_, "tnerf_wgrad_bf16")) return rc;
@@ -336,30 +341,34 @@ static int train16_args(const char* who, Fwd16Args& a, const tnerf_mlp_desc* d, 
     return TNERF_OK;
 }
 
-static int train16_fwd_impl(const char* who, const tnerf_mlp_desc* d, const void* packed16, const RaySource& rs, int64_t R, int32_t S,
+static int train16_fwd_impl(const char* who, const tnerf_mlp_desc* d, const void* packed16, const RaySource& rs, const TnStepRef& sr,
+                            const LossArgs& loss, int64_t R, int32_t S,
                             const float* ztab, int32_t randomized, const float* t_rand, uint64_t seed, uint64_t offset, int32_t white,
                             float* comp, void* stash16, hipStream_t stream) {
     Fwd16Args a{};
     int rc = train16_args(who, a, d, packed16, rs, R, S, ztab, randomized, t_rand, seed, offset, white, stash16); if (rc) return rc;
     if (!comp) { tn_set_error("%s: comp_rgb is NULL", who); return TNERF_EINVAL; }
-    a.comp = comp;
+    a.comp = comp; a.loss = loss;
+    a.sa.step = sr.step; a.sa.per_step = sr.per_step;
     return tn16_launch_fwd(a, true, stream, who);
 }
 
-static int train16_dgrad_impl(const char* who, const tnerf_mlp_desc* d, const void* packed16, const RaySource& rs, int64_t R, int32_t S,
+static int train16_dgrad_impl(const char* who, const tnerf_mlp_desc* d, const void* packed16, const RaySource& rs, const TnStepRef& sr,
+                              int64_t R, int32_t S,
                               const float* ztab, int32_t randomized, const float* t_rand, uint64_t seed, uint64_t offset, int32_t white,
-                              const float* g_comp, void* stash16, hipStream_t stream) {
+                              const float* g_comp, int32_t g_stride, void* stash16, hipStream_t stream) {
     Fwd16Args a{};
     int rc = train16_args(who, a, d, packed16, rs, R, S, ztab, randomized, t_rand, seed, offset, white, stash16); if (rc) return rc;
     if (!g_comp) { tn_set_error("%s: g_comp is NULL", who); return TNERF_EINVAL; }
-    a.g_comp = g_comp;
+    a.g_comp = g_comp; a.g_stride = g_stride;
+    a.sa.step = sr.step; a.sa.per_step = sr.per_step;
     return tn16_launch_dgrad(a, stream, who);
 }
 
 extern "C" int tnerf_train_fwd_fused_bf16(const tnerf_mlp_desc* d, const void* packed16, const float* rays_o, const float* rays_d,
                                           int64_t R, int32_t S, const float* ztab, int32_t randomized, const float* t_rand,
                                           uint64_t seed, uint64_t offset, int32_t white, float* comp, void* stash16, tnerf_stream_t stream) {
-    return train16_fwd_impl("tnerf_train_fwd_fused_bf16", d, packed16, tn_table_source(rays_o, rays_d), R, S, ztab, randomized, t_rand, seed,
+    return train16_fwd_impl("tnerf_train_fwd_fused_bf16", d, packed16, tn_table_source(rays_o, rays_d), TnStepRef{}, LossArgs{}, R, S, ztab, randomized, t_rand, seed,
                             offset, white, comp, stash16, (hipStream_t)stream);
 }
 
@@ -367,15 +376,27 @@ extern "C" int tnerf_train_dgrad_fused_bf16(const tnerf_mlp_desc* d, const void*
                                             int64_t R, int32_t S, const float* ztab, int32_t randomized, const float* t_rand,
                                             uint64_t seed, uint64_t offset, int32_t white, const float* g_comp, void* stash16,
                                             tnerf_stream_t stream) {
-    return train16_dgrad_impl("tnerf_train_dgrad_fused_bf16", d, packed16, tn_table_source(rays_o, rays_d), R, S, ztab, randomized, t_rand,
-                              seed, offset, white, g_comp, stash16, (hipStream_t)stream);
+    return train16_dgrad_impl("tnerf_train_dgrad_fused_bf16", d, packed16, tn_table_source(rays_o, rays_d), TnStepRef{}, R, S, ztab, randomized, t_rand,
+                              seed, offset, white, g_comp, 3, stash16, (hipStream_t)stream);
 }
 
 extern "C" int tnerf_wgrad_bf16(const tnerf_mlp_desc* d, const void* stash16, int64_t n_tiles, const int32_t* job_table, int64_t n_jobs,
                                 float* slabs, tnerf_stream_t stream) {
     Net16 n; int rc = tn_build_net16(d, &n); if (rc) return rc;
     if (!stash16 || n_tiles < 1 || !job_table || n_jobs < 1 || !slabs) { tn_set_error("tnerf_wgrad_bf16: bad arguments"); return TNERF_EINVAL; }
-    return tn16_launch_wgrad(n, static_cast<const unsigned char*>(stash16), job_table, n_jobs, slabs, (hipStream_t)stream);
+    return tn16_launch_wgrad(n, static_cast<const unsigned char*>(stash16), job_table, n_jobs, slabs, nullptr, (hipStream_t)stream);
+}
+
+// forward (+ loss gradient per ray) -> dgrad -> wgrad: the bf16 step up to the slabs (see tn_step32_core).
+int tn_step16_core(const char* who, const tnerf_mlp_desc* d, const void* packed16, const RaySource& rs, const TnStepRef& sr,
+                   const LossArgs& loss, int64_t R, int32_t S, const float* ztab, int32_t randomized, const float* t_rand,
+                   uint64_t seed, uint64_t offset, int32_t white, float* comp_rgb, void* stash16,
+                   const int32_t* job_table, int64_t n_jobs, float* slabs, hipStream_t stream) {
+    int rc = train16_fwd_impl(who, d, packed16, rs, sr, loss, R, S, ztab, randomized, t_rand, seed, offset, white, comp_rgb, stash16, stream);
+    if (rc) return rc;
+    if ((rc = train16_dgrad_impl(who, d, packed16, rs, sr, R, S, ztab, randomized, t_rand, seed, offset, white, loss.ray_ws, 4, stash16, stream))) return rc;
+    Net16 n; if ((rc = tn_build_net16(d, &n))) return rc;
+    return tn16_launch_wgrad(n, static_cast<const unsigned char*>(stash16), job_table, n_jobs, slabs, sr.step, stream);
 }
 
 static int train16_step_impl(const char* who, const tnerf_mlp_desc* d, const void* packed16, const RaySource& rs, const float* target,
@@ -390,13 +411,14 @@ static int train16_step_impl(const char* who, const tnerf_mlp_desc* d, const voi
                      (const void*)job_table, (long long)n_jobs, (void*)slabs, (const void*)reduce_table, (void*)grads);
         return TNERF_EINVAL;
     }
-    int rc = train16_fwd_impl(who, d, packed16, rs, R, S, ztab, randomized, t_rand, seed, offset, white, comp_rgb, stash16, stream);
+    const LossArgs loss{target, target_index, (float)(1.0 / loss_denominator), g_comp_ws, nullptr};
+    int rc = tn_step16_core(who, d, packed16, rs, TnStepRef{}, loss, R, S, ztab, randomized, t_rand, seed, offset, white, comp_rgb, stash16,
+                            job_table, n_jobs, slabs, stream);
     if (rc) return rc;
-    if ((rc = tn_launch_loss_grad(comp_rgb, target, target_index, R, loss_denominator, g_comp_ws, loss_out, stream))) return rc;
-    if ((rc = train16_dgrad_impl(who, d, packed16, rs, R, S, ztab, randomized, t_rand, seed, offset, white, g_comp_ws, stash16, stream))) return rc;
-    Net16 n; if ((rc = tn_build_net16(d, &n))) return rc;
-    if ((rc = tn16_launch_wgrad(n, static_cast<const unsigned char*>(stash16), job_table, n_jobs, slabs, stream))) return rc;
-    return tn_launch_reduce(slabs, reduce_table, tnerf_param_count(d), grads, stream);
+    FinishArgs f{};
+    f.slabs = slabs; f.reduce_table = reduce_table; f.n_params = tnerf_param_count(d); f.grads = grads;
+    f.ray_ws = g_comp_ws; f.R = R; f.inv_denom = loss.inv_denom; f.loss_out = loss_out;
+    return tn_launch_finish(f, stream);
 }
 
 extern "C" int tnerf_train_step_fused_bf16(const tnerf_mlp_desc* d, const void* packed16, const float* rays_o, const float* rays_d,

@@ -43,7 +43,9 @@ __global__ __launch_bounds__(512, 2) void k_render16(Fwd16Args a) {
     const int lane = tn_lane();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int j = lane & 31, h = lane >> 5;
-    const int S = a.sa.S, Lf = a.n.Lf;
+    RaySource rs = a.rs; SampleArgs sa = a.sa;
+    if (TRAIN) tn_resolve_step(rs, sa);                    // dataset mode: this step's image and Philox counters
+    const int S = sa.S, Lf = a.n.Lf;
     const uint32_t sel_off = TN16_SEL_OFF(a.n.n_bias);
     Pipe16 p;
     tn16_prologue(p, lds, a.packed, a.n, a.packed, a.n.n_stage, lane, wave, TRAIN);
@@ -57,7 +59,7 @@ __global__ __launch_bounds__(512, 2) void k_render16(Fwd16Args a) {
         const bool rvalid = ray < a.R;
         const int64_t rayc = rvalid ? ray : a.R - 1;
         float ro_[3], rd_[3];
-        tn_fetch_ray(a.rs, rayc, ro_, rd_);
+        tn_fetch_ray(rs, rayc, ro_, rd_);
         const float ox = ro_[0], oy = ro_[1], oz = ro_[2], dx = rd_[0], dy = rd_[1], dz = rd_[2];
         const float dn = tn_norm3(dx, dy, dz);
         float T_in = 1.0f, cr = 0.f, cg = 0.f, cb = 0.f, cd = 0.f, ca = 0.f;
@@ -68,7 +70,7 @@ __global__ __launch_bounds__(512, 2) void k_render16(Fwd16Args a) {
             {
                 const int s = sb + j;
                 const int sc = s < S ? s : S - 1;
-                const float z = tn_depth(a.sa, rayc, sc);
+                const float z = tn_depth(sa, rayc, sc);
                 bf16x8 enc[TN16_KE];
                 tn16_encode(tn_point(ox, dx, z), tn_point(oy, dy, z), tn_point(oz, dz, z), Lf, h, enc);
                 Stash16 st{};
@@ -99,8 +101,8 @@ __global__ __launch_bounds__(512, 2) void k_render16(Fwd16Args a) {
             const int s = s0 + lane;
             const bool ok = s < S && (s - s0) < ((sb & 32) ? 64 : 32);
             const int sc = s < S ? s : S - 1;
-            const float z = tn_depth(a.sa, rayc, sc);
-            const float zn = (s + 1 < S) ? tn_depth(a.sa, rayc, s + 1) : z;
+            const float z = tn_depth(sa, rayc, sc);
+            const float zn = (s + 1 < S) ? tn_depth(sa, rayc, s + 1) : z;
             const CompTerms t = tn_comp_terms(ok ? v[3] : 0.0f, z, zn, s == S - 1, dn);       // volume.py:18-31
             const float om = ok ? t.om : 1.0f;
             const float incl = tn_wave_scan_mul(om, lane);
@@ -117,6 +119,7 @@ __global__ __launch_bounds__(512, 2) void k_render16(Fwd16Args a) {
             a.comp[3 * ray] = cr + bg; a.comp[3 * ray + 1] = cg + bg; a.comp[3 * ray + 2] = cb + bg;
             if (a.depth) a.depth[ray] = cd;
             if (a.acc) a.acc[ray] = ca;
+            if (TRAIN && a.loss.ray_ws) tn_ray_loss(a.loss, rs, ray, cr + bg, cg + bg, cb + bg);      // train.py:122
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // no DMA may still be writing this workgroup's LDS at exit

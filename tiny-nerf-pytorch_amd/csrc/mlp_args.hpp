@@ -12,6 +12,8 @@ struct FwdArgs {
     const float* x; int64_t M; float* rgb_out; float* sigma_out;
     // training stash (NULL for inference)
     float* stash; int64_t Mp;
+    // training step: loss gradient written by the ray's wave (ray_ws == NULL: no loss)
+    LossArgs loss;
     // diagnostic builds only (-DTN_STAMPS): s_memtime stamps of the first ray of each workgroup
     unsigned long long* stamps;
 };
@@ -22,7 +24,7 @@ struct BwdArgs {
     float* stash; int64_t Mp;
     // fused mode
     RaySource rs; int64_t R; SampleArgs sa; int32_t white;
-    const float* g_comp;
+    const float* g_comp; int32_t g_stride;      // dL/dcomp_rgb of ray r at g_comp[g_stride * r + c] (3: [R,3] tensor, 4: ray_ws)
     // mlp-only mode
     int64_t M; const float* d_rgb; const float* d_sigma;
 };
@@ -38,6 +40,26 @@ inline RaySource tn_table_source(const float* rays_o, const float* rays_d) { ret
 int tn_launch_mlp_bwd(const BwdArgs& a, hipStream_t stream);
 int tn_launch_train_bwd(const BwdArgs& a, hipStream_t stream);
 // wgrad.hip
-int tn_launch_wgrad(const float* stash, int64_t stash_rows, int64_t M, const int32_t* jobs, int64_t n_jobs, float* slabs, hipStream_t stream);
+// x3: the products on the bf16 matrix pipe by exact 3-way splitting (wgrad.hip), else fp32 MFMA
+int tn_launch_wgrad(const float* stash, int64_t stash_rows, int64_t M, const int32_t* jobs, int64_t n_jobs, float* slabs, int64_t* step_inc, hipStream_t stream, bool x3);
 int tn_launch_reduce(const float* slabs, const int32_t* reduce_table, int64_t n_params, float* grads, hipStream_t stream);
-int tn_launch_loss_grad(const float* comp, const float* target, const int64_t* target_index, int64_t R, double denom, float* g_comp, float* loss_out, hipStream_t stream);
+// Dataset mode: the device step counter and the Philox counters consumed per step (zero = per-call mode)
+struct TnStepRef { int64_t* step; uint64_t per_step; };
+int tn_step32_core(const char* who, const tnerf_mlp_desc* d, const float* packed, const RaySource& rs, const TnStepRef& sr,
+                   const LossArgs& loss, int64_t R, int32_t S, const float* ztab, int32_t randomized, const float* t_rand,
+                   uint64_t seed, uint64_t offset, int32_t white, float* comp_rgb, float* stash, int64_t Mp,
+                   const int32_t* job_table, int64_t n_jobs, float* slabs, hipStream_t stream);
+// The finishing kernel of a step: [slab reduction -> grads] [+ loss = inv_denom * sum ray_ws[.,3]] [+ Adam + re-pack of the updated weights]
+struct FinishArgs {
+    // reduce (slabs == NULL: grads already hold the gradient, e.g. after the all-reduce)
+    const float* slabs; const int32_t* reduce_table;
+    int64_t n_params; float* grads;
+    // loss (loss_out == NULL: none)
+    const float* ray_ws; int64_t R; float inv_denom; float* loss_out;
+    // Adam (params == NULL: none).  t = *step (already incremented by the weight-gradient kernel) or step_host
+    float* params; float* m; float* v; float lr, b1, b2, eps, gscale; const int64_t* step; int64_t step_host;
+    // re-pack: parameter i goes to packed position scatter[i * width + k] (< 0: none); positions < bf16_elems are bf16
+    // elements of the fragment stream, the rest fp32 (biases) counted from bias_base
+    const int32_t* scatter; int32_t width; void* packed; int64_t bf16_elems; int64_t bias_off_bytes;
+};
+int tn_launch_finish(const FinishArgs& f, hipStream_t stream);

@@ -106,12 +106,14 @@ __global__ __launch_bounds__(256, HID == 128 ? 2 : 1) void k_train_bwd(BwdArgs a
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t ray = (int64_t)blockIdx.x * 4 + wave;
     if (ray >= a.R) return;
-    const int S = a.sa.S;
+    RaySource rs = a.rs; SampleArgs sa = a.sa;
+    tn_resolve_step(rs, sa);
+    const int S = sa.S;
     const int nseg = (S + 63) / 64;
     float ro_[3], rd_[3];
-    tn_fetch_ray(a.rs, ray, ro_, rd_);
+    tn_fetch_ray(rs, ray, ro_, rd_);
     const float dn = tn_norm3(rd_[0], rd_[1], rd_[2]);
-    const float gr = a.g_comp[3 * ray], gg = a.g_comp[3 * ray + 1], gb = a.g_comp[3 * ray + 2];
+    const float gr = a.g_comp[a.g_stride * ray], gg = a.g_comp[a.g_stride * ray + 1], gb = a.g_comp[a.g_stride * ray + 2];
     const float gbg = a.white ? (gr + gg + gb) : 0.0f;
     const int64_t mray = ray * S; const int orow = a.L.out_row0 * 32; const int64_t SR = a.L.stash_rows;
     auto outv = [&](int i, int sc) TN_INLINE_LAMBDA { return tn_stash_at(a.stash, SR, mray + sc)[orow + 32 * i]; };
@@ -120,8 +122,8 @@ __global__ __launch_bounds__(256, HID == 128 ? 2 : 1) void k_train_bwd(BwdArgs a
     if (nseg > 1) {
         for (int g = 0; g < nseg; ++g) {
             const int s = g * 64 + lane; const bool ok = s < S; const int sc = ok ? s : S - 1;
-            const float z = tn_depth(a.sa, ray, sc);
-            const float zn = (s + 1 < S) ? tn_depth(a.sa, ray, s + 1) : z;
+            const float z = tn_depth(sa, ray, sc);
+            const float zn = (s + 1 < S) ? tn_depth(sa, ray, s + 1) : z;
             const CompTerms t = tn_comp_terms(ok ? outv(3, sc) : 0.f, z, zn, s == S - 1, dn);
             const float p = tn_wave_prod(ok ? t.om : 1.0f);
             if (lane == g) segprod = p;
@@ -135,8 +137,8 @@ __global__ __launch_bounds__(256, HID == 128 ? 2 : 1) void k_train_bwd(BwdArgs a
         const int s = g * 64 + lane; const bool ok = s < S; const int sc = ok ? s : S - 1;
         const float c0 = outv(0, sc), c1 = outv(1, sc), c2 = outv(2, sc);
         const float sg = ok ? outv(3, sc) : 0.f;
-        const float z = tn_depth(a.sa, ray, sc);
-        const float zn = (s + 1 < S) ? tn_depth(a.sa, ray, s + 1) : z;
+        const float z = tn_depth(sa, ray, sc);
+        const float zn = (s + 1 < S) ? tn_depth(sa, ray, s + 1) : z;
         const CompTerms t = tn_comp_terms(sg, z, zn, s == S - 1, dn);
         const float om = ok ? t.om : 1.0f;
         const float incl = tn_wave_scan_mul(om, lane);

@@ -154,10 +154,12 @@ __global__ __launch_bounds__(256, HID == 128 ? 2 : 1) void k_render_fused(FwdArg
     const int64_t ray = (int64_t)blockIdx.x * 4 + wave;
     if (ray >= a.R) return;
     const int j = lane & 31, h = lane >> 5;
-    const int S = a.sa.S;
+    RaySource rs = a.rs; SampleArgs sa = a.sa;
+    if (TRAIN) tn_resolve_step(rs, sa);                    // dataset mode: this step's image and Philox counters
+    const int S = sa.S;
     const int Lf = (a.L.in_dim - 3) / 6;
     float ro_[3], rd_[3];
-    tn_fetch_ray(a.rs, ray, ro_, rd_);
+    tn_fetch_ray(rs, ray, ro_, rd_);
     const float ox = ro_[0], oy = ro_[1], oz = ro_[2], dx = rd_[0], dy = rd_[1], dz = rd_[2];
     const float dn = tn_norm3(dx, dy, dz);
     TN_STAMP(0);
@@ -171,7 +173,7 @@ __global__ __launch_bounds__(256, HID == 128 ? 2 : 1) void k_render_fused(FwdArg
             const int s = sb + j;
             const bool valid = s < S;
             const int sc = valid ? s : S - 1;
-            const float z = tn_depth(a.sa, ray, sc);
+            const float z = tn_depth(sa, ray, sc);
             const float px = tn_point(ox, dx, z), py = tn_point(oy, dy, z), pz = tn_point(oz, dz, z);
             float enc[NE];
             tn_encode_point<NE>(px, py, pz, Lf, h, enc);
@@ -189,8 +191,8 @@ __global__ __launch_bounds__(256, HID == 128 ? 2 : 1) void k_render_fused(FwdArg
         const int s = s0 + lane;
         const bool ok = s < S && (s - s0) < ((sb & 32) ? 64 : 32);
         const int sc = s < S ? s : S - 1;
-        const float z = tn_depth(a.sa, ray, sc);
-        const float zn = (s + 1 < S) ? tn_depth(a.sa, ray, s + 1) : z;
+        const float z = tn_depth(sa, ray, sc);
+        const float zn = (s + 1 < S) ? tn_depth(sa, ray, s + 1) : z;
         const CompTerms t = tn_comp_terms(ok ? v[3] : 0.0f, z, zn, s == S - 1, dn);       // volume.py:18-31
         const float om = ok ? t.om : 1.0f;
         const float incl = tn_wave_scan_mul(om, lane);
@@ -212,6 +214,7 @@ __global__ __launch_bounds__(256, HID == 128 ? 2 : 1) void k_render_fused(FwdArg
         a.comp[3 * ray] = cr + bg; a.comp[3 * ray + 1] = cg + bg; a.comp[3 * ray + 2] = cb + bg;
         if (a.depth) a.depth[ray] = cd;
         if (a.acc) a.acc[ray] = ca;
+        if (TRAIN && a.loss.ray_ws) tn_ray_loss(a.loss, rs, ray, cr + bg, cg + bg, cb + bg);      // train.py:122
     }
     TN_STAMP(14);
 }

@@ -18,6 +18,7 @@ enum {
 // Everything the kernels need to know about one model; passed by value as a kernel argument.
 struct MlpLayout {
     int32_t in_dim, hidden, depth, skip_at;
+    int32_t flags;              // TNERF_FLAG_*
     int32_t NE;                 // input k-steps (20 or 32)
     int32_t NT;                 // hidden/32
     int16_t emap[TN_MAX_STEPS][2];

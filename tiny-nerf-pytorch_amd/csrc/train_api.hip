@@ -5,6 +5,12 @@
 #include <mutex>
 #include "mlp_args.hpp"
 
+int tn_launch_reduce(const float* slabs, const int32_t* reduce_table, int64_t n_params, float* grads, hipStream_t stream) {
+    FinishArgs f{};
+    f.slabs = slabs; f.reduce_table = reduce_table; f.n_params = n_params; f.grads = grads;
+    return tn_launch_finish(f, stream);
+}
+
 static int bwd_common_check(const char* who, const float* packed, float* stash, int64_t Mp, int64_t M, const int32_t* job_table,
                             int64_t n_jobs, float* slabs, const int32_t* reduce_table, float* grads) {
     if (!packed || !stash || Mp < M || !job_table || n_jobs < 1 || !slabs || !reduce_table || !grads) {
@@ -26,23 +32,27 @@ extern "C" int tnerf_mlp_bwd(const tnerf_mlp_desc* d, const float* packed, int64
     a.packed = packed; a.stash = stash; a.Mp = Mp; a.M = M; a.d_rgb = d_rgb; a.d_sigma = d_sigma;
     hipStream_t s = (hipStream_t)stream;
     if ((rc = tn_launch_mlp_bwd(a, s))) return rc;
-    if ((rc = tn_launch_wgrad(stash, a.L.stash_rows, M, job_table, n_jobs, slabs, s))) return rc;
+    if ((rc = tn_launch_wgrad(stash, a.L.stash_rows, M, job_table, n_jobs, slabs, nullptr, s, !(a.L.flags & TNERF_FLAG_FP32_MFMA)))) return rc;
     return tn_launch_reduce(slabs, reduce_table, a.L.n_params, grads, s);
 }
 
-static int train_bwd_impl(const char* who, const tnerf_mlp_desc* d, const float* packed, const RaySource& rs,
+// dgrad + wgrad (+ slab reduction when reduce_table != NULL).  g_comp: dL/dcomp_rgb with row stride g_stride.
+static int train_bwd_impl(const char* who, const tnerf_mlp_desc* d, const float* packed, const RaySource& rs, const TnStepRef& sr,
                           int64_t R, int32_t S, const float* ztab, int32_t randomized, const float* t_rand, uint64_t seed,
-                          uint64_t offset, int32_t white, const float* g_comp, float* stash, int64_t Mp, const int32_t* job_table,
-                          int64_t n_jobs, float* slabs, const int32_t* reduce_table, float* grads, hipStream_t s) {
+                          uint64_t offset, int32_t white, const float* g_comp, int32_t g_stride, float* stash, int64_t Mp,
+                          const int32_t* job_table, int64_t n_jobs, float* slabs, const int32_t* reduce_table, float* grads, hipStream_t s) {
     FwdArgs f{};
     int rc = tn_fused_args(who, f, d, packed, rs, R, S, ztab, randomized, t_rand, seed, offset, white); if (rc) return rc;
     if (R < 1 || !g_comp) { tn_set_error("%s: R=%lld g_comp=%p", who, (long long)R, (const void*)g_comp); return TNERF_EINVAL; }
-    rc = bwd_common_check(who, packed, stash, Mp, R * S, job_table, n_jobs, slabs, reduce_table, grads); if (rc) return rc;
+    static const int32_t no_table = 0;
+    rc = bwd_common_check(who, packed, stash, Mp, R * S, job_table, n_jobs, slabs, reduce_table ? reduce_table : &no_table, grads ? grads : slabs); if (rc) return rc;
     BwdArgs a{};
     a.L = f.L; a.packed = packed; a.stash = stash; a.Mp = Mp; a.rs = f.rs; a.R = R; a.sa = f.sa;
-    a.white = white; a.g_comp = g_comp;
+    a.sa.step = sr.step; a.sa.per_step = sr.per_step;
+    a.white = white; a.g_comp = g_comp; a.g_stride = g_stride;
     if ((rc = tn_launch_train_bwd(a, s))) return rc;
-    if ((rc = tn_launch_wgrad(stash, a.L.stash_rows, R * S, job_table, n_jobs, slabs, s))) return rc;
+    if ((rc = tn_launch_wgrad(stash, a.L.stash_rows, R * S, job_table, n_jobs, slabs, sr.step, s, !(a.L.flags & TNERF_FLAG_FP32_MFMA)))) return rc;
+    if (!reduce_table) return TNERF_OK;
     return tn_launch_reduce(slabs, reduce_table, a.L.n_params, grads, s);
 }
 
@@ -51,8 +61,8 @@ extern "C" int tnerf_train_bwd_fused(const tnerf_mlp_desc* d, const float* packe
                                      uint64_t seed, uint64_t offset, int32_t white, const float* g_comp, float* stash, int64_t Mp,
                                      const int32_t* job_table, int64_t n_jobs, float* slabs, const int32_t* reduce_table,
                                      float* grads, tnerf_stream_t stream) {
-    return train_bwd_impl("tnerf_train_bwd_fused", d, packed, tn_table_source(rays_o, rays_d), R, S, ztab, randomized, t_rand, seed, offset, white,
-                          g_comp, stash, Mp, job_table, n_jobs, slabs, reduce_table, grads, (hipStream_t)stream);
+    return train_bwd_impl("tnerf_train_bwd_fused", d, packed, tn_table_source(rays_o, rays_d), TnStepRef{}, R, S, ztab, randomized, t_rand, seed, offset, white,
+                          g_comp, 3, stash, Mp, job_table, n_jobs, slabs, reduce_table, grads, (hipStream_t)stream);
 }
 
 extern "C" int tnerf_train_dgrad_fused(const tnerf_mlp_desc* d, const float* packed, const float* rays_o, const float* rays_d,
@@ -65,7 +75,7 @@ extern "C" int tnerf_train_dgrad_fused(const tnerf_mlp_desc* d, const float* pac
     if (R < 1 || !g_comp || !stash || Mp < R * S) { tn_set_error("tnerf_train_dgrad_fused: R=%lld g_comp=%p stash=%p Mp=%lld", (long long)R, (const void*)g_comp, (void*)stash, (long long)Mp); return TNERF_EINVAL; }
     BwdArgs a{};
     a.L = f.L; a.packed = packed; a.stash = stash; a.Mp = Mp; a.rs = f.rs; a.R = R; a.sa = f.sa;
-    a.white = white; a.g_comp = g_comp;
+    a.white = white; a.g_comp = g_comp; a.g_stride = 3;
     return tn_launch_train_bwd(a, (hipStream_t)stream);
 }
 
@@ -73,7 +83,7 @@ extern "C" int tnerf_wgrad(const tnerf_mlp_desc* d, const float* stash, int64_t 
                            float* slabs, tnerf_stream_t stream) {
     MlpLayout L; int rc = tn_build_layout(d, &L); if (rc) return rc;
     if (!stash || Mp < M || M < 1 || !job_table || n_jobs < 1 || !slabs) { tn_set_error("tnerf_wgrad: bad arguments"); return TNERF_EINVAL; }
-    return tn_launch_wgrad(stash, L.stash_rows, M, job_table, n_jobs, slabs, (hipStream_t)stream);
+    return tn_launch_wgrad(stash, L.stash_rows, M, job_table, n_jobs, slabs, nullptr, (hipStream_t)stream, !(L.flags & TNERF_FLAG_FP32_MFMA));
 }
 
 extern "C" int tnerf_wgrad_reduce(const float* slabs, const int32_t* reduce_table, int64_t n_params, float* grads, tnerf_stream_t stream) {
@@ -81,15 +91,28 @@ extern "C" int tnerf_wgrad_reduce(const float* slabs, const int32_t* reduce_tabl
     return tn_launch_reduce(slabs, reduce_table, n_params, grads, (hipStream_t)stream);
 }
 
-int tn_train_fwd_impl(const char* who, const tnerf_mlp_desc* d, const float* packed, const RaySource& rs, int64_t R, int32_t S,
-                      const float* ztab, int32_t randomized, const float* t_rand, uint64_t seed, uint64_t offset, int32_t white,
-                      float* comp, float* stash, int64_t Mp, hipStream_t stream) {
+static int tn_train_fwd_impl(const char* who, const tnerf_mlp_desc* d, const float* packed, const RaySource& rs, const TnStepRef& sr,
+                             const LossArgs& loss, int64_t R, int32_t S, const float* ztab, int32_t randomized, const float* t_rand,
+                             uint64_t seed, uint64_t offset, int32_t white, float* comp, float* stash, int64_t Mp, hipStream_t stream) {
     FwdArgs a{};
     int rc = tn_fused_args(who, a, d, packed, rs, R, S, ztab, randomized, t_rand, seed, offset, white);
     if (rc) return rc;
     if (!comp || !stash || Mp < R * S) { tn_set_error("%s: comp=%p stash=%p Mp=%lld < R*S=%lld", who, (void*)comp, (void*)stash, (long long)Mp, (long long)(R * S)); return TNERF_EINVAL; }
-    a.comp = comp; a.stash = stash; a.Mp = Mp;
+    a.comp = comp; a.stash = stash; a.Mp = Mp; a.loss = loss;
+    a.sa.step = sr.step; a.sa.per_step = sr.per_step;
     return tn_launch_fwd(a, true, true, R, stream, who);
+}
+
+// forward (+ loss gradient per ray) -> dgrad -> wgrad: the step up to the slabs.  Shared by the per-call entry points below
+// and by tnerf_train_step_dataset (step_api.hip).
+int tn_step32_core(const char* who, const tnerf_mlp_desc* d, const float* packed, const RaySource& rs, const TnStepRef& sr,
+                   const LossArgs& loss, int64_t R, int32_t S, const float* ztab, int32_t randomized, const float* t_rand,
+                   uint64_t seed, uint64_t offset, int32_t white, float* comp_rgb, float* stash, int64_t Mp,
+                   const int32_t* job_table, int64_t n_jobs, float* slabs, hipStream_t stream) {
+    int rc = tn_train_fwd_impl(who, d, packed, rs, sr, loss, R, S, ztab, randomized, t_rand, seed, offset, white, comp_rgb, stash, Mp, stream);
+    if (rc) return rc;
+    return train_bwd_impl(who, d, packed, rs, sr, R, S, ztab, randomized, t_rand, seed, offset, white, loss.ray_ws, 4, stash, Mp,
+                          job_table, n_jobs, slabs, nullptr, nullptr, stream);
 }
 
 static int train_step_impl(const char* who, const tnerf_mlp_desc* d, const float* packed, const RaySource& rs, const float* target,
@@ -103,11 +126,15 @@ static int train_step_impl(const char* who, const tnerf_mlp_desc* d, const float
                      (void*)g_comp_ws, (void*)loss_out, loss_denominator, (long long)R);
         return TNERF_EINVAL;
     }
-    int rc = tn_train_fwd_impl(who, d, packed, rs, R, S, ztab, randomized, t_rand, seed, offset, white, comp_rgb, stash, Mp, stream);
+    if (!reduce_table || !grads) { tn_set_error("%s: reduce_table=%p grads=%p", who, (const void*)reduce_table, (void*)grads); return TNERF_EINVAL; }
+    const LossArgs loss{target, target_index, (float)(1.0 / loss_denominator), g_comp_ws, nullptr};
+    int rc = tn_step32_core(who, d, packed, rs, TnStepRef{}, loss, R, S, ztab, randomized, t_rand, seed, offset, white, comp_rgb, stash, Mp,
+                            job_table, n_jobs, slabs, stream);
     if (rc) return rc;
-    if ((rc = tn_launch_loss_grad(comp_rgb, target, target_index, R, loss_denominator, g_comp_ws, loss_out, stream))) return rc;
-    return train_bwd_impl(who, d, packed, rs, R, S, ztab, randomized, t_rand, seed, offset, white,
-                          g_comp_ws, stash, Mp, job_table, n_jobs, slabs, reduce_table, grads, stream);
+    FinishArgs f{};
+    f.slabs = slabs; f.reduce_table = reduce_table; f.n_params = tnerf_param_count(d); f.grads = grads;
+    f.ray_ws = g_comp_ws; f.R = R; f.inv_denom = loss.inv_denom; f.loss_out = loss_out;
+    return tn_launch_finish(f, stream);
 }
 
 extern "C" int tnerf_train_step_fused(const tnerf_mlp_desc* d, const float* packed, const float* rays_o, const float* rays_d,

@@ -19,6 +19,45 @@
 // LDS image of one operand block: row r holds its 8 16-byte chunks permuted by (r>>1)&7.
 __device__ __forceinline__ int wg_lds_off(int row, int chunk) { return row * 32 + ((chunk ^ ((row >> 1) & 7)) << 2); }
 
+// fp32 products on the bf16 matrix pipe, exactly: an fp32 value is the sum of three bf16 numbers (its 24-bit mantissa cut
+// into 8 + 8 + 8 bits: x = p1 + p2 + p3 with p1 = x truncated to bf16, p2 = (x - p1) truncated, p3 = the rest — every step
+// exact), a product of two bf16 numbers is exact in fp32, so  a*b = sum_ij a_i b_j  with nothing lost but the three smallest
+// terms (a2 b3, a3 b2, a3 b3 <= 2^-24 |ab|: below one fp32 rounding).  Six v_mfma_f32_32x32x16_bf16 (fp32 accumulate) thus
+// give a dot product that is as accurate as — measured: slightly more accurate than — the fp32 MFMA's fma chain, at 6/16 of
+// its matrix-pipe time.  8 consecutive fp32 (lo, hi) -> three 8-element bf16 operand registers.
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void tn_split3(const f32x4& lo, const f32x4& hi, bf16x8_t& p1, bf16x8_t& p2, bf16x8_t& p3) {
+    u32x4_t w1, w2, w3;
+#ifdef WX_NO_SPLIT      // diagnostic build (tools/wgrad_x3_probe.py): the operand packing only, WRONG numerics
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const uint32_t u0 = __float_as_uint(e < 2 ? lo[2 * e] : hi[2 * e - 4]), u1 = __float_as_uint(e < 2 ? lo[2 * e + 1] : hi[2 * e - 3]);
+        w1[e] = __builtin_amdgcn_perm(u1, u0, 0x07060302u); w2[e] = w1[e]; w3[e] = w1[e];
+    }
+    p1 = __builtin_bit_cast(bf16x8_t, w1); p2 = __builtin_bit_cast(bf16x8_t, w2); p3 = __builtin_bit_cast(bf16x8_t, w3);
+    return;
+#endif
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        // two elements at a time: the subtractions are packed (v_pk_add_f32), the truncations are bit masks, v_perm_b32
+        // gathers the two high halves into one operand dword
+        const f32x2_t x = {e < 2 ? lo[2 * e] : hi[2 * e - 4], e < 2 ? lo[2 * e + 1] : hi[2 * e - 3]};
+        const u32x2_t u = __builtin_bit_cast(u32x2_t, x);
+        const f32x2_t r = x - __builtin_bit_cast(f32x2_t, u & 0xFFFF0000u);
+        const u32x2_t v = __builtin_bit_cast(u32x2_t, r);
+        const f32x2_t t = r - __builtin_bit_cast(f32x2_t, v & 0xFFFF0000u);
+        const u32x2_t w = __builtin_bit_cast(u32x2_t, t);                            // <= 8 significant bits left: exact
+        w1[e] = __builtin_amdgcn_perm(u[1], u[0], 0x07060302u);                       // (hi16 of x1) : (hi16 of x0)
+        w2[e] = __builtin_amdgcn_perm(v[1], v[0], 0x07060302u);
+        w3[e] = __builtin_amdgcn_perm(w[1], w[0], 0x07060302u);
+    }
+    p1 = __builtin_bit_cast(bf16x8_t, w1); p2 = __builtin_bit_cast(bf16x8_t, w2); p3 = __builtin_bit_cast(bf16x8_t, w3);
+}
+#define TN_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+
 template <int TA, int TB>
 __device__ __forceinline__ void wgrad_body(const float* __restrict__ stash, int64_t stash_rows, int64_t M, const int32_t* __restrict__ job,
                                            float* __restrict__ slabs, float* lds) {
@@ -169,11 +208,198 @@ __device__ __forceinline__ void wgrad_body(const float* __restrict__ stash, int6
     }
 }
 
+// ------------------------------------------------------------------------------------- split-bf16 ("x3") body
+// The same job (an (A rows x B rows) block of <= 256 x 256 outputs for a chunk of samples, 8 waves, <= 2 x 4 tiles per wave)
+// with the products on the bf16 matrix pipe (tn_split3 above).  Its MFMA time per 32 samples is 6/16 of the fp32 form's, which
+// makes the kernel HBM-bound — and a two-slot pipeline (one block in flight during one block of compute) cannot cover HBM
+// latency + transfer any more.  So the operands are staged in STAGES of 16 samples (= one k-step of v_mfma_f32_32x32x16_bf16):
+// 512 rows x 64 B = 32 KB per stage, a ring of 4 slots, three stages in flight behind the one being consumed, tracked with
+// a counted vmcnt; one raw barrier per stage.  LDS image of a stage: row r is 4 chunks of 16 B, chunk position p holds source
+// chunk p ^ ((r >> 2) & 3) (applied on the DMA's source address), which makes the ds_read_b128 of 16 consecutive rows at one
+// chunk index conflict-free on 64-byte rows.
+// A stage is as large as the job's operands are (rows x 64 B: 32 KB for a 256 x 256 block, 18-20 KB for the input / head
+// classes) and the ring takes as many slots as fit in the kernel's 128 KB (4 .. 7): the small, bandwidth-hungry classes
+// keep more bytes in flight per CU.
+#define WX_MAX_NS 7
+__device__ __forceinline__ int wx_lds_off(int row, int chunk) { return row * 16 + ((chunk ^ ((row >> 2) & 3)) << 2); }   // in floats
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction takes an immediate); waits for n or fewer
+__device__ __forceinline__ void wx_wait_vm(int n) {
+#define WX_W(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+    switch (n < 24 ? n : 24) {
+        WX_W(0) WX_W(1) WX_W(2) WX_W(3) WX_W(4) WX_W(5) WX_W(6) WX_W(7) WX_W(8) WX_W(9) WX_W(10) WX_W(11) WX_W(12)
+        WX_W(13) WX_W(14) WX_W(15) WX_W(16) WX_W(17) WX_W(18) WX_W(19) WX_W(20) WX_W(21) WX_W(22) WX_W(23) WX_W(24)
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+#undef WX_W
+}
+
+template <int TA, int TB>
+__device__ __forceinline__ void wgrad_x3_body(const float* __restrict__ stash, int64_t stash_rows, int64_t M, const int32_t* __restrict__ job,
+                                              float* __restrict__ slabs, float* lds) {
+    const int tid = (int)threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_at = job[JOB_N_AT], n_bt = job[JOB_N_BT], WA = job[JOB_WA];
+    const int a_rows = job[JOB_A_ROWS], b_rows = job[JOB_B_ROWS];
+    const int64_t a_row0 = job[JOB_A_ROW0], b_row0 = job[JOB_B_ROW0];
+    const int blk0 = job[JOB_MBLK0], nblk = job[JOB_MBLKN];
+    const int wa = wave % WA, wb = wave / WA;
+    const int a_t0 = wa * TA, b_t0 = wb * TB;
+    const int rows_a = n_at * 32, rows_b = n_bt * 32, rows = rows_a + rows_b;
+    f32x16 acc[TA][TB];
+#pragma unroll
+    for (int i = 0; i < TA; ++i)
+#pragma unroll
+        for (int j = 0; j < TB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    float bsum[TA];
+#pragma unroll
+    for (int i = 0; i < TA; ++i) bsum[i] = 0.0f;
+
+    // DMA pieces: 16 rows x 64 B = 1 KB per wave instruction; lane l -> row l>>2 of the piece, chunk position l&3.
+    // Piece pc covers combined rows 16 pc .. 16 pc + 15 of [A | B]; wave w moves pieces w, w+8, w+16, w+24.
+    const uint32_t lds0 = (uint32_t)(uintptr_t)lds;
+    constexpr int MAXP = (2 * WG_LDS_ROWS) / 128;            // 4 pieces per wave and stage
+    const int npieces = rows / 16;
+    uint32_t voff[MAXP], pdst[MAXP];
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i) {
+        const int pc = wave + 8 * i;
+        const int cr = 16 * pc + (lane >> 2);
+        const bool isA = cr < rows_a;
+        const int lr = isA ? cr : cr - rows_a;
+        const int lim = (isA ? a_rows : b_rows) - 1;
+        const int srow_ = (int)(isA ? a_row0 : b_row0) + (lr < lim ? lr : lim);           // rows that do not exist: clamped (never referenced)
+        voff[i] = (uint32_t)srow_ * 128u + (uint32_t)(((lane & 3) ^ ((lr >> 2) & 3)) << 4);
+#ifdef WX_CONTIG_DMA     // diagnostic build (WRONG data): what a stash laid out in 16-sample blocks would let the DMA read — 1 KB contiguous per instruction
+        voff[i] = (uint32_t)(isA ? a_row0 : b_row0) * 128u + (uint32_t)(lr >> 4) * 2048u + (uint32_t)lane * 16u;
+#endif
+        const int lr0 = (16 * pc < rows_a) ? 16 * pc : 16 * pc - rows_a;
+        pdst[i] = ((16 * pc < rows_a) ? 0u : (uint32_t)rows_a * 64u) + (uint32_t)lr0 * 64u;
+    }
+    const int nst = 2 * nblk;                                   // stages of 16 samples
+    const int slot_floats = rows * 16;                          // [A rows | B rows] x 16 samples
+    int NS = (WG_LDS_FLOATS) / slot_floats;
+    if (NS > WX_MAX_NS) NS = WX_MAX_NS;
+    int slot_i = 0, slot_c = 0;                                 // ring slots of the next stage to issue / to consume
+    auto issue = [&](int st) TN_INLINE_LAMBDA {                 // stage st -> ring slot slot_i
+        const float* src = stash + (int64_t)(blk0 + (st >> 1)) * stash_rows * 32 + (st & 1) * 16;
+        const uint32_t slot = lds0 + (uint32_t)(slot_i * slot_floats) * 4u;
+        slot_i = slot_i + 1 == NS ? 0 : slot_i + 1;
+        tn_static_for<MAXP>([&](auto ic) TN_INLINE_LAMBDA {
+            constexpr int i = decltype(ic)::value;
+            if (wave + 8 * i < npieces) tn_glds16(src, voff[i], slot + __builtin_amdgcn_readfirstlane(pdst[i]));
+        });
+    };
+    // The last block of the batch may hold fewer than 32 samples: slots behind M were never written by the chain kernels.
+    // Each lane clears them in the 16 bytes it has just DMA'd (after its own vmcnt wait, before the publishing barrier).
+    auto clear_tail = [&](int st) TN_INLINE_LAMBDA {
+        const int nvalid = (int)(M - (int64_t)(blk0 + (st >> 1)) * 32) - (st & 1) * 16;     // valid samples of this stage (may be <= 0)
+        float* base = lds + slot_c * slot_floats;
+        tn_static_for<MAXP>([&](auto ic) TN_INLINE_LAMBDA {
+            constexpr int i = decltype(ic)::value;
+            if (wave + 8 * i < npieces) {
+                const int pc = wave + 8 * i, cr = 16 * pc + (lane >> 2);
+                const int lr = cr < rows_a ? cr : cr - rows_a;
+                const int s0 = (((lane & 3) ^ ((lr >> 2) & 3)) << 2);                      // first sample of this lane's chunk
+                f32x4* q = reinterpret_cast<f32x4*>(base + (__builtin_amdgcn_readfirstlane(pdst[i]) >> 2) + lane * 4);
+                f32x4 v = *q;
+                v[0] = s0 + 0 < nvalid ? v[0] : 0.f; v[1] = s0 + 1 < nvalid ? v[1] : 0.f;
+                v[2] = s0 + 2 < nvalid ? v[2] : 0.f; v[3] = s0 + 3 < nvalid ? v[3] : 0.f;
+                *q = v;
+            }
+        });
+    };
+    auto is_tail = [&](int st) TN_INLINE_LAMBDA { return (int64_t)(blk0 + (st >> 1)) * 32 + 32 > M; };      // wave-uniform
+
+    const int frow = lane & 31, fh = lane >> 5;
+    const bool active = (a_t0 < n_at) && (b_t0 < n_bt);
+    const bool do_bias = job[JOB_HAS_BIAS] && wb == 0;
+    // every wave issues exactly `mine` DMA instructions per stage: the counted waits below are in units of stages
+    const int mine = (npieces - wave + 7) / 8;                  // wave-uniform, 1..4 (npieces >= 8 for every job class? no: head = 2+..)
+
+#pragma unroll 1
+    for (int st = 0; st < NS - 1 && st < nst; ++st) issue(st);
+#pragma unroll 1
+    for (int st = 0; st < nst; ++st) {
+        // wait for this wave's DMA of stage st: the NS-2 younger stages (fewer at the end) may stay in flight
+        const int newer = (nst - 1 - st) < (NS - 2) ? (nst - 1 - st) : (NS - 2);
+        wx_wait_vm(mine * newer);
+        if (is_tail(st)) { clear_tail(st); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+        __builtin_amdgcn_s_barrier();          // stage st is visible to everyone; everyone is done with stage st-1: its slot is free
+#ifndef WX_NO_DMA        // diagnostic build: compute on whatever the prologue staged
+        if (st + NS - 1 < nst) issue(st + NS - 1);
+#endif
+        const float* A = lds + slot_c * slot_floats;
+        const float* B = A + rows_a * 16;
+        slot_c = slot_c + 1 == NS ? 0 : slot_c + 1;
+        if (active) {
+            // lane (row, fh) holds samples 8 fh .. 8 fh + 7 of its row's 16: chunks 2 fh and 2 fh + 1
+            bf16x8_t a1[TA], a2[TA], a3[TA];
+#pragma unroll
+            for (int i = 0; i < TA; ++i) {
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(A + wx_lds_off((a_t0 + i) * 32 + frow, 2 * fh));
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(A + wx_lds_off((a_t0 + i) * 32 + frow, 2 * fh + 1));
+                if (do_bias) bsum[i] += ((lo[0] + lo[1]) + (lo[2] + lo[3])) + ((hi[0] + hi[1]) + (hi[2] + hi[3]));
+                tn_split3(lo, hi, a1[i], a2[i], a3[i]);
+            }
+#pragma unroll
+            for (int j = 0; j < TB; ++j) {
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(B + wx_lds_off((b_t0 + j) * 32 + frow, 2 * fh));
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(B + wx_lds_off((b_t0 + j) * 32 + frow, 2 * fh + 1));
+                bf16x8_t b1, b2, b3;
+                tn_split3(lo, hi, b1, b2, b3);
+                // six exact partial products per (i, j), small terms first; term outermost so that consecutive MFMAs go to
+                // different accumulators
+#ifndef WX_ONE_MFMA      // diagnostic build: only the leading product
+#pragma unroll
+                for (int i = 0; i < TA; ++i) acc[i][j] = TN_MFMA16(a3[i], b1, acc[i][j]);
+#pragma unroll
+                for (int i = 0; i < TA; ++i) acc[i][j] = TN_MFMA16(a2[i], b2, acc[i][j]);
+#pragma unroll
+                for (int i = 0; i < TA; ++i) acc[i][j] = TN_MFMA16(a1[i], b3, acc[i][j]);
+#pragma unroll
+                for (int i = 0; i < TA; ++i) acc[i][j] = TN_MFMA16(a2[i], b1, acc[i][j]);
+#pragma unroll
+                for (int i = 0; i < TA; ++i) acc[i][j] = TN_MFMA16(a1[i], b2, acc[i][j]);
+#endif
+#pragma unroll
+                for (int i = 0; i < TA; ++i) acc[i][j] = TN_MFMA16(a1[i], b1, acc[i][j]);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // epilogue: partial block -> this workgroup's slab  [n_at*32][n_bt*32] then bias [n_at*32]   (as wgrad_body)
+    if (active) {
+        float* slab = slabs + job[JOB_SLAB_OFF];
+        const int ld = n_bt * 32;
+#pragma unroll
+        for (int i = 0; i < TA; ++i)
+#pragma unroll
+            for (int j = 0; j < TB; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    slab[(int64_t)((a_t0 + i) * 32 + TN_ACC_ROW(r, fh)) * ld + (b_t0 + j) * 32 + frow] = acc[i][j][r];
+        if (do_bias) {
+#pragma unroll
+            for (int i = 0; i < TA; ++i) {
+                const float tot = bsum[i] + __shfl_xor(bsum[i], 32, 64);
+                if (fh == 0) slab[(int64_t)n_at * 32 * ld + (a_t0 + i) * 32 + frow] = tot;
+            }
+        }
+    }
+}
+
 // 512 threads = 8 waves = TWO per SIMD (<= 8 accumulator tiles = 128 registers per wave): while one wave of a SIMD
 // waits for LDS fragments, the staging writes or the barrier, the other one keeps the matrix pipe busy.
+template <bool X3>
 __global__ __launch_bounds__(512, 2) void k_wgrad(const float* __restrict__ stash, int64_t stash_rows, int64_t M,
-                                                  const int32_t* __restrict__ jobs, float* __restrict__ slabs) {
+                                                  const int32_t* __restrict__ jobs, float* __restrict__ slabs, int64_t* step_inc) {
     __shared__ __attribute__((aligned(16))) float lds[WG_LDS_FLOATS];
+    // Dataset mode: the step counter advances HERE — the forward and dgrad kernels of this step (which read it) are done,
+    // the finishing kernel (which needs the 1-based count for Adam's bias correction) has not started.
+    if (step_inc && blockIdx.x == 0 && threadIdx.x == 0) *step_inc += 1;
 #ifdef TN_STAMPS   // diagnostic build: per-workgroup duration, written over the (unused) tail of the job record
     const unsigned long long t_start = __builtin_amdgcn_s_memtime();
 #endif
@@ -181,10 +407,10 @@ __global__ __launch_bounds__(512, 2) void k_wgrad(const float* __restrict__ stas
     const int n_at = job[JOB_N_AT], n_bt = job[JOB_N_BT], WA = job[JOB_WA], WB = 8 / WA;
     const int ta = (n_at + WA - 1) / WA, tb = (n_bt + WB - 1) / WB;     // the host plan only emits full-or-idle waves
     switch (ta * 8 + tb) {
-        case 2 * 8 + 4: wgrad_body<2, 4>(stash, stash_rows, M, job, slabs, lds); break;
-        case 1 * 8 + 2: wgrad_body<1, 2>(stash, stash_rows, M, job, slabs, lds); break;
-        case 2 * 8 + 1: wgrad_body<2, 1>(stash, stash_rows, M, job, slabs, lds); break;
-        case 1 * 8 + 1: wgrad_body<1, 1>(stash, stash_rows, M, job, slabs, lds); break;
+        case 2 * 8 + 4: if (X3) wgrad_x3_body<2, 4>(stash, stash_rows, M, job, slabs, lds); else wgrad_body<2, 4>(stash, stash_rows, M, job, slabs, lds); break;
+        case 1 * 8 + 2: if (X3) wgrad_x3_body<1, 2>(stash, stash_rows, M, job, slabs, lds); else wgrad_body<1, 2>(stash, stash_rows, M, job, slabs, lds); break;
+        case 2 * 8 + 1: if (X3) wgrad_x3_body<2, 1>(stash, stash_rows, M, job, slabs, lds); else wgrad_body<2, 1>(stash, stash_rows, M, job, slabs, lds); break;
+        case 1 * 8 + 1: if (X3) wgrad_x3_body<1, 1>(stash, stash_rows, M, job, slabs, lds); else wgrad_body<1, 1>(stash, stash_rows, M, job, slabs, lds); break;
         default: break;   // unreachable: shapes are validated on the host (tnerf_plan_fill)
     }
 #ifdef TN_STAMPS
@@ -196,34 +422,95 @@ __global__ __launch_bounds__(512, 2) void k_wgrad(const float* __restrict__ stas
 #endif
 }
 
-int tn_launch_wgrad(const float* stash, int64_t stash_rows, int64_t M, const int32_t* jobs, int64_t n_jobs, float* slabs, hipStream_t stream) {
-    hipLaunchKernelGGL(k_wgrad, dim3((unsigned)n_jobs), dim3(512), 0, stream, stash, stash_rows, M, jobs, slabs);
+int tn_launch_wgrad(const float* stash, int64_t stash_rows, int64_t M, const int32_t* jobs, int64_t n_jobs, float* slabs, int64_t* step_inc, hipStream_t stream, bool x3) {
+    if (x3) hipLaunchKernelGGL(k_wgrad<true>, dim3((unsigned)n_jobs), dim3(512), 0, stream, stash, stash_rows, M, jobs, slabs, step_inc);
+    else    hipLaunchKernelGGL(k_wgrad<false>, dim3((unsigned)n_jobs), dim3(512), 0, stream, stash, stash_rows, M, jobs, slabs, step_inc);
     TN_HIP_CHECK_LAUNCH("wgrad");
     return TNERF_OK;
 }
 
-// grads[i] = sum over the chunks of its job class of slab[off + c * stride]   (fixed order)
-__global__ __launch_bounds__(256) void k_reduce(const float* __restrict__ slabs, const int32_t* __restrict__ table,
-                                                int64_t n_params, float* __restrict__ grads) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_params) return;
-    const int32_t off = table[TN_RED_HDR + 2 * i], cls = table[TN_RED_HDR + 2 * i + 1];
-    const int64_t base = (int64_t)table[1 + 4 * cls] + off;
-    const int64_t stride = table[1 + 4 * cls + 1];
-    const int n = table[1 + 4 * cls + 2];
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int c = 0;
-    for (; c + 3 < n; c += 4) {
-        s0 += slabs[base + (int64_t)c * stride];       s1 += slabs[base + (int64_t)(c + 1) * stride];
-        s2 += slabs[base + (int64_t)(c + 2) * stride]; s3 += slabs[base + (int64_t)(c + 3) * stride];
+// ------------------------------------------------------------------------------- finishing kernel
+// One thread per parameter i:
+//   REDUCE: grads[i] = sum over the chunks of its job class of slab[off + c * stride]   (fixed order: deterministic)
+//   ADAM  : torch.optim.Adam (no amsgrad, no weight decay, maximize=False), single-tensor formulation:
+//             m = lerp(m, g, 1-b1); v = b2 v + (1-b2) g^2; p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
+//           and the updated weight goes straight to its places in the packed (MFMA-fragment-ordered) copy the next
+//           forward reads — no separate pack launch.
+// One extra workgroup sums the per-ray squared errors (fixed order) into the loss.
+template <bool REDUCE, bool ADAM>
+__global__ __launch_bounds__(256) void k_finish(FinishArgs f) {
+    const int nb = (int)((f.n_params + 255) / 256);
+    if ((int)blockIdx.x == nb) {                                  // the loss block (only launched when loss_out != NULL)
+        __shared__ float part[4];
+        float s = 0.0f;
+        for (int64_t r = threadIdx.x; r < f.R; r += 256) s += f.ray_ws[4 * r + 3];
+        s = tn_wave_sum(s);
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) f.loss_out[0] = ((part[0] + part[1]) + (part[2] + part[3])) * f.inv_denom;
+        return;
     }
-    for (; c < n; ++c) s0 += slabs[base + (int64_t)c * stride];
-    grads[i] = (s0 + s1) + (s2 + s3);
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    __shared__ float bc[2];
+    if (ADAM) {
+        if (threadIdx.x == 0) {
+            const double t = (double)(f.step ? *f.step : f.step_host);
+            bc[0] = (float)((double)f.lr / (1.0 - pow((double)f.b1, t)));         // step size
+            bc[1] = (float)(1.0 / sqrt(1.0 - pow((double)f.b2, t)));
+        }
+        __syncthreads();
+    }
+    if (i >= f.n_params) return;
+    float g;
+    if (REDUCE) {
+        const int32_t* __restrict__ table = f.reduce_table;
+        const float* __restrict__ slabs = f.slabs;
+        const int32_t off = table[TN_RED_HDR + 2 * i], cls = table[TN_RED_HDR + 2 * i + 1];
+        const int64_t base = (int64_t)table[1 + 4 * cls] + off;
+        const int64_t stride = table[1 + 4 * cls + 1];
+        const int n = table[1 + 4 * cls + 2];
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int c = 0;
+        for (; c + 3 < n; c += 4) {
+            s0 += slabs[base + (int64_t)c * stride];       s1 += slabs[base + (int64_t)(c + 1) * stride];
+            s2 += slabs[base + (int64_t)(c + 2) * stride]; s3 += slabs[base + (int64_t)(c + 3) * stride];
+        }
+        for (; c < n; ++c) s0 += slabs[base + (int64_t)c * stride];
+        g = (s0 + s1) + (s2 + s3);
+        f.grads[i] = g;
+    } else {
+        g = f.grads[i];
+    }
+    if (ADAM) {
+        const float gi = g * f.gscale;
+        const float mi = f.m[i] + (gi - f.m[i]) * (1.0f - f.b1);
+        const float vi = f.v[i] * f.b2 + (gi * gi) * (1.0f - f.b2);
+        f.m[i] = mi; f.v[i] = vi;
+        const float denom = sqrtf(vi) * bc[1] + f.eps;
+        const float pn = f.params[i] - bc[0] * (mi / denom);
+        f.params[i] = pn;
+        if (f.scatter) {
+            for (int k = 0; k < f.width; ++k) {
+                const int32_t d = f.scatter[i * f.width + k];
+                if (d < 0) break;
+                if (d < f.bf16_elems) {                            // bf16 fragment stream: round to nearest even
+                    reinterpret_cast<unsigned short*>(f.packed)[d] = __builtin_bit_cast(unsigned short, (__bf16)pn);   // as k_pack16
+                } else {
+                    reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(f.packed) + f.bias_off_bytes)[d - f.bf16_elems] = pn;
+                }
+            }
+        }
+    }
 }
 
-int tn_launch_reduce(const float* slabs, const int32_t* table, int64_t n_params, float* grads, hipStream_t stream) {
-    hipLaunchKernelGGL(k_reduce, dim3((unsigned)((n_params + 255) / 256)), dim3(256), 0, stream, slabs, table, n_params, grads);
-    TN_HIP_CHECK_LAUNCH("wgrad/reduce");
+int tn_launch_finish(const FinishArgs& f, hipStream_t stream) {
+    const unsigned nb = (unsigned)((f.n_params + 255) / 256) + (f.loss_out ? 1u : 0u);
+    const bool red = f.slabs != nullptr, adam = f.params != nullptr;
+    if (red && adam)       hipLaunchKernelGGL((k_finish<true, true>), dim3(nb), dim3(256), 0, stream, f);
+    else if (red)          hipLaunchKernelGGL((k_finish<true, false>), dim3(nb), dim3(256), 0, stream, f);
+    else if (adam)         hipLaunchKernelGGL((k_finish<false, true>), dim3(nb), dim3(256), 0, stream, f);
+    else { tn_set_error("finish: nothing to do"); return TNERF_EINVAL; }
+    TN_HIP_CHECK_LAUNCH("step/finish");
     return TNERF_OK;
 }
 
@@ -246,60 +533,16 @@ extern "C" int tnerf_mlp_pack(const float* params, const int32_t* pack_table, in
     return TNERF_OK;
 }
 
-// ------------------------------------------------------------------------------- loss
-// loss = sum((comp - target)^2) / denom ; g = 2 (comp - target) / denom      [reference src/train.py:122]
-// One workgroup, fixed summation order (deterministic).
-__global__ __launch_bounds__(1024) void k_loss_grad(const float* __restrict__ comp, const float* __restrict__ target, const int64_t* __restrict__ tindex, int64_t n,
-                                                    float inv_denom, float* __restrict__ g, float* __restrict__ loss_out) {
-    __shared__ float part[16];
-    float s = 0.0f;
-    for (int64_t i = threadIdx.x; i < n; i += 1024) {
-        const float d = comp[i] - (tindex ? target[3 * tindex[i / 3] + i % 3] : target[i]);
-        s += d * d;
-        g[i] = (2.0f * d) * inv_denom;
-    }
-    s = tn_wave_sum(s);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float t = 0.0f;
-        for (int w = 0; w < 16; ++w) t += part[w];
-        loss_out[0] = t * inv_denom;
-    }
-}
-
-int tn_launch_loss_grad(const float* comp, const float* target, const int64_t* target_index, int64_t R, double denom, float* g_comp, float* loss_out, hipStream_t stream) {
-    hipLaunchKernelGGL(k_loss_grad, dim3(1), dim3(1024), 0, stream, comp, target, target_index, R * 3, (float)(1.0 / denom), g_comp, loss_out);
-    TN_HIP_CHECK_LAUNCH("train_step/loss");
-    return TNERF_OK;
-}
-
 // ------------------------------------------------------------------------------- Adam
-// torch.optim.Adam (no amsgrad, no weight decay, maximize=False), single-tensor formulation:
-//   m = lerp(m, g, 1-b1); v = b2 v + (1-b2) g^2; p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
-__global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                              float* __restrict__ v, int64_t n, float b1, float b2, float eps,
-                                              float step_size, float inv_sqrt_bc2, float gscale) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float gi = g[i] * gscale;
-    const float mi = m[i] + (gi - m[i]) * (1.0f - b1);
-    const float vi = v[i] * b2 + (gi * gi) * (1.0f - b2);
-    m[i] = mi; v[i] = vi;
-    const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
-    p[i] = p[i] - step_size * (mi / denom);
-}
-
 extern "C" int tnerf_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                                float beta1, float beta2, float eps, int64_t step, float grad_scale, tnerf_stream_t stream) {
     if (!params || !grads || !exp_avg || !exp_avg_sq || n < 1 || step < 1) {
         tn_set_error("tnerf_adam_step: n=%lld step=%lld or NULL buffer", (long long)n, (long long)step);
         return TNERF_EINVAL;
     }
-    const double bc1 = 1.0 - pow((double)beta1, (double)step);
-    const double bc2 = 1.0 - pow((double)beta2, (double)step);
-    hipLaunchKernelGGL(k_adam, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, n,
-                       beta1, beta2, eps, (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), grad_scale);
-    TN_HIP_CHECK_LAUNCH("tnerf_adam_step");
-    return TNERF_OK;
+    FinishArgs f{};
+    f.n_params = n; f.grads = const_cast<float*>(grads);
+    f.params = params; f.m = exp_avg; f.v = exp_avg_sq; f.lr = lr; f.b1 = beta1; f.b2 = beta2; f.eps = eps; f.gscale = grad_scale;
+    f.step_host = step;
+    return tn_launch_finish(f, (hipStream_t)stream);
 }

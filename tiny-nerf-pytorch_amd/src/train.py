@@ -59,6 +59,9 @@ class Config:
     skip_at: int = 2
     data_path: str = "data/tiny_nerf_data.npz"   # "synthetic" = the seeded stand-in scene (explicit opt-in; a missing file raises)
     gpus: int = 1               # > 1 from a plain shell: spawn that many rank processes (one per GPU, RCCL all-reduce)
+    rng: str = "torch"          # "torch": inds / jitter drawn with torch.randint / torch.rand like the reference (parity path);
+                                # "philox": drawn inside the kernels from a device-side step counter — the whole step is one
+                                # hipGraph replay (speed path, fused only)
     precision: str = "fp32"     # "bf16": bf16 weights/activations on MFMA, fp32 accumulate/compositing/master weights (fused only)
 
 
@@ -172,6 +175,8 @@ def main(cfg: Config):
 
     encoder = PositionalEncoding(num_freqs=cfg.num_freqs, include_input=True).to(device)
     model = TinyNeRF(in_dim=encoder.out_dim, hidden=cfg.hidden, depth=cfg.depth, skip_at=cfg.skip_at).to(device)
+    if cfg.rng not in ("torch", "philox") or (cfg.rng == "philox" and not cfg.fused):
+        raise SystemExit("--rng must be 'torch' or 'philox' (philox needs the fused step)")
     if cfg.fused:
         optimizer = _trainer.FlatAdam(model, lr=cfg.lr)
         step_fn = _trainer.FusedTrainer(model, optimizer, cfg.near, cfg.far, cfg.n_samples, precision=cfg.precision)
@@ -201,6 +206,10 @@ def main(cfg: Config):
         all_rays_d = torch.stack([r[1] for r in rays], dim=0)
     pixels = images.view(N, H * W, 3)
     lo, hi = _dist.shard_bounds(cfg.n_rand, rank, world)                        # this rank's rows of the global batch
+    graph_step = None
+    if cfg.fused and cfg.rng == "philox":
+        graph_step = _trainer.DatasetTrainer(model, optimizer, images, poses, focal, cfg.n_rand, cfg.n_samples, cfg.near, cfg.far,
+                                             seed=0, precision=cfg.precision, start_step=start_step)
 
     pbar = range(start_step, cfg.iters)
     if chief:
@@ -213,8 +222,11 @@ def main(cfg: Config):
     for step in pbar:
         model.train()
         img_i = step % N
-        inds = torch.randint(0, H * W, (cfg.n_rand,), device=device)             # train.py:109 — the GLOBAL draw on every rank
-        if cfg.fused:
+        if graph_step is None:
+            inds = torch.randint(0, H * W, (cfg.n_rand,), device=device)         # train.py:109 — the GLOBAL draw on every rank
+        if graph_step is not None:
+            loss, _ = graph_step.step()                                           # image index, pixel and jitter draws happen in the kernels
+        elif cfg.fused:
             t_rand = torch.rand(cfg.n_rand, cfg.n_samples, device=device)        # the draw of sampling.py:24
             loss, _ = step_fn.step_camera(poses[img_i], H, W, focal, inds[lo:hi], pixels[img_i], t_rand=t_rand[lo:hi],
                                           global_rays=cfg.n_rand)

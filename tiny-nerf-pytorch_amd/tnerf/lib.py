@@ -12,7 +12,10 @@ OK, EINVAL, EUNSUPPORTED, ESMALL = 0, -1, -2, -3
 
 
 class MlpDesc(C.Structure):
-    _fields_ = [("in_dim", C.c_int32), ("hidden", C.c_int32), ("depth", C.c_int32), ("skip_at", C.c_int32)]
+    _fields_ = [("in_dim", C.c_int32), ("hidden", C.c_int32), ("depth", C.c_int32), ("skip_at", C.c_int32), ("flags", C.c_int32)]
+
+
+FLAG_FP32_MFMA = 1        # fp32 products on v_mfma_f32_32x32x2_f32 instead of the exact bf16x3 split (include/tnerf.h)
 
 
 class Camera(C.Structure):
@@ -32,6 +35,24 @@ class Bf16Sizes(C.Structure):
 class Bf16TrainPlan(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("n_tiles", "stash_bytes", "slab_floats", "job_ints", "reduce_ints", "n_jobs")]
 
+
+class StepArgs(C.Structure):
+    """tnerf_step_args (include/tnerf.h): the whole train step on device-resident state."""
+    _fields_ = [("desc", MlpDesc), ("precision", C.c_int32), ("phases", C.c_int32),
+                ("poses", C.c_void_p), ("pixels", C.c_void_p), ("n_images", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("focal", C.c_float),
+                ("n_rays", C.c_int64), ("ray_first", C.c_int64), ("n_rays_global", C.c_int64), ("n_samples", C.c_int32), ("white_bkgd", C.c_int32),
+                ("ztab", C.c_void_p), ("seed", C.c_uint64), ("loss_denominator", C.c_double), ("step", C.c_void_p),
+                ("packed", C.c_void_p),
+                ("comp_rgb", C.c_void_p), ("ray_ws", C.c_void_p), ("pix_out", C.c_void_p), ("loss_out", C.c_void_p),
+                ("stash", C.c_void_p), ("stash_row_stride", C.c_int64),
+                ("job_table", C.c_void_p), ("n_jobs", C.c_int64), ("slabs", C.c_void_p), ("reduce_table", C.c_void_p), ("grads", C.c_void_p),
+                ("params", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
+                ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("scatter_table", C.c_void_p), ("scatter_width", C.c_int32)]
+
+
+PHASE_GRADIENT, PHASE_REDUCE, PHASE_UPDATE = 1, 2, 4
+ABI_VERSION = 2
 
 _P = C.c_void_p           # device pointers travel as integers (tensor.data_ptr())
 _I32, _I64, _U64, _F, _D = C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_double
@@ -83,6 +104,11 @@ SIGNATURES = {
     "tnerf_train_step_fused_cam_bf16": (C.c_int, [_DESC, _P, C.POINTER(Camera), _P, _I64, _I32, _P, _I32, _P, _U64, _U64, _I32, _D,
                                                   _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P]),
     "tnerf_adam_step": (C.c_int, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _I64, _F, _P]),
+    "tnerf_train_step_dataset": (C.c_int, [C.POINTER(StepArgs), _P]),
+    "tnerf_graph_begin": (C.c_int, [_P]),
+    "tnerf_graph_end": (C.c_int, [_P, C.POINTER(C.c_void_p)]),
+    "tnerf_graph_launch": (C.c_int, [_P, _P]),
+    "tnerf_graph_destroy": (C.c_int, [_P]),
     "tnerf_comm_unique_id": (C.c_int, [_P]),
     "tnerf_comm_init_rank": (C.c_int, [_P, _I32, _I32, C.POINTER(C.c_void_p)]),
     "tnerf_comm_destroy": (C.c_int, [_P]),
@@ -110,8 +136,8 @@ def load():
                     continue
                 raise
             fn.restype, fn.argtypes = res, args
-        if lib.tnerf_version() != 1:
-            raise RuntimeError(f"libtnerf_hip.so ABI version {lib.tnerf_version()} != 1")
+        if lib.tnerf_version() != ABI_VERSION:
+            raise RuntimeError(f"libtnerf_hip.so ABI version {lib.tnerf_version()} != {ABI_VERSION}: rebuild it (python __graft_entry__.py build)")
         _lib = lib
     return _lib
 

@@ -8,6 +8,7 @@ missing library raise.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, Optional, Tuple
 
 import numpy as np
@@ -245,9 +246,11 @@ class ModelState:
     """Device-side state of one TinyNeRF: flat fp32 parameters (the nn.Parameters are views into it),
     the MFMA-fragment-packed copy of the weights and the per-batch-size plans."""
 
-    def __init__(self, in_dim: int, hidden: int, depth: int, skip_at: int, device: torch.device):
+    def __init__(self, in_dim: int, hidden: int, depth: int, skip_at: int, device: torch.device, flags: Optional[int] = None):
         self.device = device
-        self.desc = _l.MlpDesc(int(in_dim), int(hidden), int(depth), int(skip_at))
+        if flags is None:      # TNERF_FP32_PIPE=mfma32 selects the plain fp32-MFMA kernels for models built from now on (A/B runs)
+            flags = _l.FLAG_FP32_MFMA if os.environ.get("TNERF_FP32_PIPE", "").lower() in ("mfma32", "fp32", "mfma") else 0
+        self.desc = _l.MlpDesc(int(in_dim), int(hidden), int(depth), int(skip_at), int(flags))
         n = _l.load().tnerf_param_count(C.byref(self.desc))
         if n < 0:
             _l.check(_l.EUNSUPPORTED, "TinyNeRF (HIP)")

@@ -9,6 +9,7 @@ from __future__ import annotations
 import ctypes as C
 from typing import Optional
 
+import numpy as np
 import torch
 
 from . import lib as _l
@@ -115,7 +116,7 @@ class FusedTrainer:
         R = rays_o.shape[0]
         if self._comp is None or self._comp.shape[0] != R:
             self._comp = torch.empty(R, 3, dtype=torch.float32, device=dev)
-            self._gws = torch.empty(R, 3, dtype=torch.float32, device=dev)
+            self._gws = torch.empty(R, 4, dtype=torch.float32, device=dev)      # per ray: dL/dcomp_rgb + squared error (ABI 2)
         ztab = _ops.depth_table(self.near, self.far, self.S, dev)
         rnd, tr, seed, off = _ops._rng_args(randomized, t_rand, philox)
         if tr is not None:
@@ -154,7 +155,7 @@ class FusedTrainer:
         R = int(inds.shape[0])
         if self._comp is None or self._comp.shape[0] != R:
             self._comp = torch.empty(R, 3, dtype=torch.float32, device=dev)
-            self._gws = torch.empty(R, 3, dtype=torch.float32, device=dev)
+            self._gws = torch.empty(R, 4, dtype=torch.float32, device=dev)      # per ray: dL/dcomp_rgb + squared error (ABI 2)
         ztab = _ops.depth_table(self.near, self.far, self.S, dev)
         rnd, tr, seed, off = _ops._rng_args(randomized, t_rand, philox)
         if tr is not None:
@@ -182,3 +183,205 @@ class FusedTrainer:
         _dist.all_reduce_sum_(st.grad)
         self.opt.step(grads_in_flat=True)
         return self.loss, self._comp
+
+
+def _scatter_table(pack_table: np.ndarray, n_params: int) -> np.ndarray:
+    """Inverse of a pack table (packed[i] = params[table[i]]): row p lists the packed positions of parameter p, -1 padded.
+    A weight sits in the forward AND in the transposed (dgrad) fragment stream, a bias once."""
+    pos = np.nonzero(pack_table >= 0)[0].astype(np.int64)
+    src = pack_table[pos].astype(np.int64)
+    order = np.argsort(src, kind="stable")
+    src, pos = src[order], pos[order]
+    counts = np.bincount(src, minlength=n_params)
+    width = max(1, int(counts.max()))
+    first = np.concatenate([[0], np.cumsum(counts)[:-1]])
+    out = np.full((n_params, width), -1, np.int32)
+    out[src, np.arange(src.shape[0]) - first[src]] = pos.astype(np.int32)
+    return out
+
+
+class DatasetTrainer:
+    """The reference loop body (src/train.py:106-128) on device-resident state: `step()` is ONE host call.
+
+    The dataset (poses, pixels) lives in HBM; which image (step % N), which pixels (the reference's torch.randint) and
+    which jitter (its rand_like) are drawn inside the kernels from a device-side step counter (Philox, include/tnerf.h
+    "the whole step on device-resident state"); Adam and the re-packing of the updated weights finish the same call.
+    On one GPU the 4 launches of a step are captured once into a hipGraph and replayed (graph=True).  With
+    torch.distributed initialised the rows of the global batch are sharded (dist.shard_bounds) and the flat gradient is
+    all-reduced between the gradient and the update phase (no graph: a collective sits in the middle).
+
+    This is the speed path; FusedTrainer.step / step_camera with torch-drawn `inds` / `t_rand` is the parity path."""
+
+    def __init__(self, model, optimizer: FlatAdam, images: torch.Tensor, poses: torch.Tensor, focal: float, n_rand: int,
+                 n_samples: int, near: float, far: float, seed: int = 0, white_bkgd: bool = True, precision: str = "fp32",
+                 graph: bool = True, start_step: int = 0, record_pixels: bool = False, rank: Optional[int] = None,
+                 world: Optional[int] = None):
+        """rank / world default to the torch.distributed process group (1 rank without one); pass them to shard by hand
+        (then call gradient_phase(), exchange `model.hip_state().grad` yourself, update_phase())."""
+        if precision not in ("fp32", "bf16"):
+            raise ValueError(f"precision must be 'fp32' or 'bf16', got {precision!r}")
+        self.model, self.opt, self.precision = model, optimizer, precision
+        st = self.st = model.hip_state()
+        dev = st.device
+        _ops._need_cuda(images, poses)
+        N, H, W, _ = images.shape
+        self.N, self.H, self.W, self.focal = int(N), int(H), int(W), float(focal)
+        self.pixels = _ops._f32c(images).reshape(N, H * W, 3)
+        self.poses = _ops._f32c(poses).reshape(N, 16)
+        self.S, self.white, self.seed = int(n_samples), int(bool(white_bkgd)), int(seed) & (2 ** 64 - 1)
+        self.ztab = _ops.depth_table(float(near), float(far), self.S, dev)
+        if rank is None or world is None:
+            rank, world = _dist.world()
+        self.world = world
+        self.R_global = int(n_rand)
+        lo, hi = _dist.shard_bounds(self.R_global, rank, world)
+        self.lo, self.R = lo, hi - lo
+        if self.R < 1:
+            raise ValueError(f"rank {rank} of {world} has no rays of a {n_rand}-ray batch")
+        if int(optimizer._t) != int(start_step):
+            raise ValueError(f"DatasetTrainer: the loop step ({start_step}) and Adam's step count ({optimizer._t}) must agree "
+                             "(one device counter serves both); use FusedTrainer.step_camera otherwise")
+        self.step_dev = torch.tensor([int(start_step)], dtype=torch.int64, device=dev)
+        self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.comp = torch.empty(self.R, 3, dtype=torch.float32, device=dev)
+        self.ray_ws = torch.empty(self.R, 4, dtype=torch.float32, device=dev)
+        self.pix = torch.empty(self.R, dtype=torch.int32, device=dev) if record_pixels else None
+        self._graph = None
+        self._graph_key = None
+        self._want_graph = bool(graph) and world == 1
+        self._calls = 0
+        self._own_stream = None
+        self._args_keep = None
+        # packed weights + the inverse of their pack table
+        if precision == "fp32":
+            model._ensure_packed()
+            self._packed = st.packed
+            self._plan = st.plan(self.R * self.S)
+            self._lease = self._plan.lease()                                  # this trainer's stash for as long as it lives
+            self._stash, self._stride = self._lease.buf, self._plan.Mp
+            tab = st.pack_table.cpu().numpy()
+        else:
+            b = st.repack_bf16(tuple(p._version for p in model._param_list()))
+            self._packed = b.packed
+            self._plan = b.train_plan(self.R, self.S)
+            self._stash, self._stride = self._plan.stash, 0
+            tab = b.table.cpu().numpy()
+        self._scatter = torch.from_numpy(_scatter_table(tab, st.n_params)).to(dev)
+
+    # ------------------------------------------------------------------ one step
+    def _args(self, phases: int) -> "_l.StepArgs":
+        st, g, plan = self.st, self.opt.param_groups[0], self._plan
+        a = _l.StepArgs()
+        a.desc = st.desc
+        a.precision = 0 if self.precision == "fp32" else 1
+        a.phases = phases
+        a.poses, a.pixels = self.poses.data_ptr(), self.pixels.data_ptr()
+        a.n_images, a.H, a.W, a.focal = self.N, self.H, self.W, self.focal
+        a.n_rays, a.ray_first, a.n_rays_global = self.R, self.lo, self.R_global
+        a.n_samples, a.white_bkgd = self.S, self.white
+        a.ztab, a.seed, a.loss_denominator = self.ztab.data_ptr(), self.seed, 3.0 * self.R_global
+        a.step, a.packed = self.step_dev.data_ptr(), self._packed.data_ptr()
+        a.comp_rgb, a.ray_ws, a.loss_out = self.comp.data_ptr(), self.ray_ws.data_ptr(), self.loss.data_ptr()
+        a.pix_out = self.pix.data_ptr() if self.pix is not None else None
+        a.stash, a.stash_row_stride = self._stash.data_ptr(), self._stride
+        a.job_table, a.n_jobs, a.slabs = plan.jobs.data_ptr(), plan.n_jobs, plan.slabs.data_ptr()
+        a.reduce_table, a.grads = plan.reduce.data_ptr(), st.grad.data_ptr()
+        a.params, a.exp_avg, a.exp_avg_sq = st.flat.data_ptr(), self.opt._m.data_ptr(), self.opt._v.data_ptr()
+        a.lr, a.beta1, a.beta2, a.eps = float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"])
+        a.scatter_table, a.scatter_width = self._scatter.data_ptr(), int(self._scatter.shape[1])
+        return a
+
+    def _hyper_key(self):
+        g = self.opt.param_groups[0]
+        return (float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]))
+
+    def _stream(self):
+        cur = torch.cuda.current_stream(self.st.device)
+        if cur.cuda_stream != 0:
+            return cur, False                      # the caller already works on a stream of its own: use it
+        if self._own_stream is None:
+            self._own_stream = torch.cuda.Stream(self.st.device)
+        return self._own_stream, True
+
+    @torch.no_grad()
+    def step(self):
+        """One training step.  Returns (loss [device scalar: this rank's share of the batch MSE], comp_rgb [R,3])."""
+        st = self.st
+        if not st.owns(self.model._param_list()):
+            raise RuntimeError("DatasetTrainer: a model parameter was rebound; build a new trainer")
+        if self.world > 1:                          # gradient -> all-reduce -> update
+            self.gradient_phase()
+            _dist.all_reduce_sum_(st.grad)
+            return self.update_phase()
+        elif not self._want_graph:
+            a = self._args(_l.PHASE_GRADIENT | _l.PHASE_REDUCE | _l.PHASE_UPDATE)
+            _l.call("tnerf_train_step_dataset", C.byref(a), torch.cuda.current_stream(st.device).cuda_stream)
+        else:
+            stream, own = self._stream()
+            if own:
+                stream.wait_stream(torch.cuda.current_stream(st.device))
+            if self._graph is not None and self._graph_key != self._hyper_key():
+                self._drop_graph()                 # lr / betas changed: the captured kernel arguments are stale
+            if self._graph is None and self._calls >= 1:
+                # capture (the first call ran eagerly: every kernel is loaded, every buffer exists)
+                a = self._args(_l.PHASE_GRADIENT | _l.PHASE_REDUCE | _l.PHASE_UPDATE)
+                _l.call("tnerf_graph_begin", stream.cuda_stream)
+                try:
+                    _l.call("tnerf_train_step_dataset", C.byref(a), stream.cuda_stream)
+                finally:
+                    gx = C.c_void_p()
+                    rc = _l.load().tnerf_graph_end(stream.cuda_stream, C.byref(gx))
+                _l.check(rc, "tnerf_graph_end")
+                self._graph, self._graph_key, self._args_keep = gx, self._hyper_key(), a
+            if self._graph is not None:
+                _l.call("tnerf_graph_launch", self._graph, stream.cuda_stream)
+            else:
+                a = self._args(_l.PHASE_GRADIENT | _l.PHASE_REDUCE | _l.PHASE_UPDATE)
+                _l.call("tnerf_train_step_dataset", C.byref(a), stream.cuda_stream)
+            if own:
+                torch.cuda.current_stream(st.device).wait_stream(stream)
+        self._calls += 1
+        self.opt._t += 1
+        # the finishing kernel re-packed THIS precision's copy of the weights; the other one is stale now
+        if self.precision == "fp32":
+            if st.bf16 is not None:
+                st.bf16.key = None
+        else:
+            st.packed_key = None
+        return self.loss, self.comp
+
+    @torch.no_grad()
+    def gradient_phase(self):
+        """forward + loss + backward of this rank's rows -> model.hip_state().grad (its share of the batch gradient);
+        advances the device step counter."""
+        a = self._args(_l.PHASE_GRADIENT | _l.PHASE_REDUCE)
+        _l.call("tnerf_train_step_dataset", C.byref(a), torch.cuda.current_stream(self.st.device).cuda_stream)
+
+    @torch.no_grad()
+    def update_phase(self):
+        """Adam on whatever model.hip_state().grad holds now (the all-reduced gradient) + re-pack."""
+        a = self._args(_l.PHASE_UPDATE)
+        _l.call("tnerf_train_step_dataset", C.byref(a), torch.cuda.current_stream(self.st.device).cuda_stream)
+        self._calls += 1
+        self.opt._t += 1
+        if self.precision == "fp32":
+            if self.st.bf16 is not None:
+                self.st.bf16.key = None
+        else:
+            self.st.packed_key = None
+        return self.loss, self.comp
+
+    @property
+    def steps_done(self) -> int:
+        return int(self.step_dev.item())
+
+    def _drop_graph(self):
+        if self._graph is not None:
+            _l.call("tnerf_graph_destroy", self._graph)
+            self._graph = None
+
+    def __del__(self):
+        try:
+            self._drop_graph()
+        except Exception:
+            pass
