@@ -151,8 +151,8 @@ extern "C" int tnerf_param_layout(const tnerf_mlp_desc* d, int64_t* offsets, int
 
 // ------------------------------------------------------------------------------- wgrad plan
 #ifndef TN_X3_TILE
-#define TN_X3_TILE 875.0
-#define TN_X3_FIXED 2670.0
+#define TN_X3_TILE 650.0
+#define TN_X3_FIXED 3160.0
 #endif
 namespace {
 struct JobClass {

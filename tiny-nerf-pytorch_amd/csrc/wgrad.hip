@@ -210,41 +210,58 @@ __device__ __forceinline__ void wgrad_body(const float* __restrict__ stash, int6
 
 // ------------------------------------------------------------------------------------- split-bf16 ("x3") body
 // The same job (an (A rows x B rows) block of <= 256 x 256 outputs for a chunk of samples, 8 waves, <= 2 x 4 tiles per wave)
-// with the products on the bf16 matrix pipe (tn_split3 above).  Its MFMA time per 32 samples is 6/16 of the fp32 form's, which
-// makes the kernel HBM-bound — and a two-slot pipeline (one block in flight during one block of compute) cannot cover HBM
-// latency + transfer any more.  So the operands are staged in STAGES of 16 samples (= one k-step of v_mfma_f32_32x32x16_bf16):
-// 512 rows x 64 B = 32 KB per stage, a ring of 4 slots, three stages in flight behind the one being consumed, tracked with
-// a counted vmcnt; one raw barrier per stage.  LDS image of a stage: row r is 4 chunks of 16 B, chunk position p holds source
-// chunk p ^ ((r >> 2) & 3) (applied on the DMA's source address), which makes the ds_read_b128 of 16 consecutive rows at one
-// chunk index conflict-free on 64-byte rows.
-// A stage is as large as the job's operands are (rows x 64 B: 32 KB for a 256 x 256 block, 18-20 KB for the input / head
-// classes) and the ring takes as many slots as fit in the kernel's 128 KB (4 .. 7): the small, bandwidth-hungry classes
-// keep more bytes in flight per CU.
-#define WX_MAX_NS 7
-__device__ __forceinline__ int wx_lds_off(int row, int chunk) { return row * 16 + ((chunk ^ ((row >> 2) & 3)) << 2); }   // in floats
-// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction takes an immediate); waits for n or fewer
-__device__ __forceinline__ void wx_wait_vm(int n) {
-#define WX_W(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
-    switch (n < 24 ? n : 24) {
-        WX_W(0) WX_W(1) WX_W(2) WX_W(3) WX_W(4) WX_W(5) WX_W(6) WX_W(7) WX_W(8) WX_W(9) WX_W(10) WX_W(11) WX_W(12)
-        WX_W(13) WX_W(14) WX_W(15) WX_W(16) WX_W(17) WX_W(18) WX_W(19) WX_W(20) WX_W(21) WX_W(22) WX_W(23) WX_W(24)
-        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+// with the products on the bf16 matrix pipe (tn_split3 above).  Its MFMA time per 32 samples is 6/16 of the fp32 form's, so
+// everything else had to shrink with it (tools/wgrad_x3_probe.py: splitting the operands in every wave that uses them — each
+// A tile in 2 waves, each B tile in 4 — made the kernel VALU-issue-bound at 10k cycles per block against 6.1k of MFMA):
+//   * every operand element is split ONCE per workgroup: the 512 threads fetch a 16-sample STAGE of the job's rows straight
+//     from the stash into registers (buffer loads, 4 lanes per 64-byte row half), two stages ahead; split it; and write the
+//     three bf16 pieces into an LDS image laid out as MFMA operands (row-piece = 16 samples = 32 B);
+//   * the MFMA phase is VALU-free: one ds_read_b128 per (tile, piece) and k-step, six MFMAs per tile pair;
+//   * the image is double-buffered, so converting stage s+1 overlaps the MFMAs of stage s: one raw barrier per stage.
+// Image: [buffer 2][piece 3][row 512] x 32 B; the two 16-byte halves of a row-piece are swapped when (row >> 3) & 1 — that
+// makes the ds_read_b128 of 16 consecutive rows conflict-free (the 8-byte writes of a wave cover 512 contiguous bytes).
+#define WX_IMG_BYTES (3 * 2 * WG_LDS_ROWS * 32)            // 48 KB per buffer
+static_assert(2 * WX_IMG_BYTES <= WG_LDS_FLOATS * 4, "the x3 operand images must fit the kernel's LDS");
+__device__ __forceinline__ uint32_t wx_img_off(int piece, int crow, int half) {
+    return (uint32_t)((piece * (2 * WG_LDS_ROWS) + crow) * 32 + ((half ^ ((crow >> 3) & 1)) << 4));
+}
+// 4 fp32 -> 3 x (4 bf16 in 8 bytes), exact (see tn_split3)
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void tn_split3x4(const f32x4& x, u32x2_t& p1, u32x2_t& p2, u32x2_t& p3) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const float x0 = x[2 * e], x1 = x[2 * e + 1];
+        const uint32_t u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
+#ifdef WX_NO_SPLIT      // diagnostic build: the operand packing only, WRONG numerics
+        p1[e] = __builtin_amdgcn_perm(u1, u0, 0x07060302u); p2[e] = p1[e]; p3[e] = p1[e];
+#else
+        const float r0 = x0 - __uint_as_float(u0 & 0xFFFF0000u), r1 = x1 - __uint_as_float(u1 & 0xFFFF0000u);
+        const uint32_t v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
+        const float s0 = r0 - __uint_as_float(v0 & 0xFFFF0000u), s1 = r1 - __uint_as_float(v1 & 0xFFFF0000u);
+        p1[e] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);                       // (hi16 of x1) : (hi16 of x0)
+        p2[e] = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+        p3[e] = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);   // <= 8 significant bits left: exact
+#endif
     }
-#undef WX_W
 }
 
-template <int TA, int TB>
+// PD = register sets of the fetch pipeline = stages between a fetch and its use: 2 for the 256 x 256 blocks (an iteration is
+// > 3k cycles of MFMA), 8 for the small, bandwidth-hungry input / head classes whose iterations are a few hundred cycles.
+template <int TA, int TB, int PD>
 __device__ __forceinline__ void wgrad_x3_body(const float* __restrict__ stash, int64_t stash_rows, int64_t M, const int32_t* __restrict__ job,
-                                              float* __restrict__ slabs, float* lds) {
+                                              float* __restrict__ slabs, float* lds_f) {
+    static_assert(PD % 2 == 0, "the image parity must follow the unrolled stage index");
+    unsigned char* lds = reinterpret_cast<unsigned char*>(lds_f);
     const int tid = (int)threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n_at = job[JOB_N_AT], n_bt = job[JOB_N_BT], WA = job[JOB_WA];
     const int a_rows = job[JOB_A_ROWS], b_rows = job[JOB_B_ROWS];
-    const int64_t a_row0 = job[JOB_A_ROW0], b_row0 = job[JOB_B_ROW0];
+    const int a_row0 = job[JOB_A_ROW0], b_row0 = job[JOB_B_ROW0];
     const int blk0 = job[JOB_MBLK0], nblk = job[JOB_MBLKN];
     const int wa = wave % WA, wb = wave / WA;
     const int a_t0 = wa * TA, b_t0 = wb * TB;
     const int rows_a = n_at * 32, rows_b = n_bt * 32, rows = rows_a + rows_b;
+    const bool has_bias = job[JOB_HAS_BIAS] != 0;
     f32x16 acc[TA][TB];
 #pragma unroll
     for (int i = 0; i < TA; ++i)
@@ -252,103 +269,97 @@ __device__ __forceinline__ void wgrad_x3_body(const float* __restrict__ stash, i
         for (int j = 0; j < TB; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-    float bsum[TA];
-#pragma unroll
-    for (int i = 0; i < TA; ++i) bsum[i] = 0.0f;
 
-    // DMA pieces: 16 rows x 64 B = 1 KB per wave instruction; lane l -> row l>>2 of the piece, chunk position l&3.
-    // Piece pc covers combined rows 16 pc .. 16 pc + 15 of [A | B]; wave w moves pieces w, w+8, w+16, w+24.
-    const uint32_t lds0 = (uint32_t)(uintptr_t)lds;
-    constexpr int MAXP = (2 * WG_LDS_ROWS) / 128;            // 4 pieces per wave and stage
-    const int npieces = rows / 16;
-    uint32_t voff[MAXP], pdst[MAXP];
+    // Converter side: item k of thread t = (combined row (t >> 2) + 128 k of [A | B], 16-byte chunk t & 3 of the stage's 64 B).
+    // Rows that do not exist (head: 4 of 32, input: 40 of 64) are clamped to a real row: they only feed slab rows / columns
+    // that the reduce table never references.
+    const int chunk = tid & 3;
+    int goff[4]; bool live[4], isA[4]; int crow[4];
 #pragma unroll
-    for (int i = 0; i < MAXP; ++i) {
-        const int pc = wave + 8 * i;
-        const int cr = 16 * pc + (lane >> 2);
-        const bool isA = cr < rows_a;
-        const int lr = isA ? cr : cr - rows_a;
-        const int lim = (isA ? a_rows : b_rows) - 1;
-        const int srow_ = (int)(isA ? a_row0 : b_row0) + (lr < lim ? lr : lim);           // rows that do not exist: clamped (never referenced)
-        voff[i] = (uint32_t)srow_ * 128u + (uint32_t)(((lane & 3) ^ ((lr >> 2) & 3)) << 4);
-#ifdef WX_CONTIG_DMA     // diagnostic build (WRONG data): what a stash laid out in 16-sample blocks would let the DMA read — 1 KB contiguous per instruction
-        voff[i] = (uint32_t)(isA ? a_row0 : b_row0) * 128u + (uint32_t)(lr >> 4) * 2048u + (uint32_t)lane * 16u;
-#endif
-        const int lr0 = (16 * pc < rows_a) ? 16 * pc : 16 * pc - rows_a;
-        pdst[i] = ((16 * pc < rows_a) ? 0u : (uint32_t)rows_a * 64u) + (uint32_t)lr0 * 64u;
+    for (int k = 0; k < 4; ++k) {
+        crow[k] = (tid >> 2) + 128 * k;
+        live[k] = crow[k] < rows;
+        isA[k] = crow[k] < rows_a;
+        const int lr = isA[k] ? crow[k] : crow[k] - rows_a;
+        const int lim = (isA[k] ? a_rows : b_rows) - 1;
+        const int srow_ = (isA[k] ? a_row0 : b_row0) + (lr < lim ? lr : lim);          // combined rows past the job's (dead items) land on B's last row
+        goff[k] = srow_ * 128 + chunk * 16;
     }
+    (void)live;
+    float bs[4] = {0.f, 0.f, 0.f, 0.f};
     const int nst = 2 * nblk;                                   // stages of 16 samples
-    const int slot_floats = rows * 16;                          // [A rows | B rows] x 16 samples
-    int NS = (WG_LDS_FLOATS) / slot_floats;
-    if (NS > WX_MAX_NS) NS = WX_MAX_NS;
-    int slot_i = 0, slot_c = 0;                                 // ring slots of the next stage to issue / to consume
-    auto issue = [&](int st) TN_INLINE_LAMBDA {                 // stage st -> ring slot slot_i
-        const float* src = stash + (int64_t)(blk0 + (st >> 1)) * stash_rows * 32 + (st & 1) * 16;
-        const uint32_t slot = lds0 + (uint32_t)(slot_i * slot_floats) * 4u;
-        slot_i = slot_i + 1 == NS ? 0 : slot_i + 1;
-        tn_static_for<MAXP>([&](auto ic) TN_INLINE_LAMBDA {
-            constexpr int i = decltype(ic)::value;
-            if (wave + 8 * i < npieces) tn_glds16(src, voff[i], slot + __builtin_amdgcn_readfirstlane(pdst[i]));
-        });
+    const int64_t blk_bytes = stash_rows * 128;
+    f32x4 raw[PD][4];
+    // The hot loop must be ONE basic block (a branch ends the scheduling region: the conversion would no longer be placed in the
+    // MFMAs' shadow): dead items (combined rows past the job's) are converted like live ones into image rows nobody reads, the
+    // bias sums are formed for every item and only A rows are stored at the end, and the stages that need care — the batch's
+    // ragged last block, the last PD+1 stages of the job — run in a guarded copy of the iteration.
+    auto fetch1 = [&](int st, auto setc, auto kc) TN_INLINE_LAMBDA {      // item k of stage st -> register set
+        constexpr int set = decltype(setc)::value, k = decltype(kc)::value;
+        const unsigned char* base = reinterpret_cast<const unsigned char*>(stash) + (int64_t)(blk0 + (st >> 1)) * blk_bytes;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(base), 0, (int)blk_bytes, 0x00020000);
+        raw[set][k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, goff[k], (st & 1) * 64, 0));
     };
-    // The last block of the batch may hold fewer than 32 samples: slots behind M were never written by the chain kernels.
-    // Each lane clears them in the 16 bytes it has just DMA'd (after its own vmcnt wait, before the publishing barrier).
-    auto clear_tail = [&](int st) TN_INLINE_LAMBDA {
-        const int nvalid = (int)(M - (int64_t)(blk0 + (st >> 1)) * 32) - (st & 1) * 16;     // valid samples of this stage (may be <= 0)
-        float* base = lds + slot_c * slot_floats;
-        tn_static_for<MAXP>([&](auto ic) TN_INLINE_LAMBDA {
-            constexpr int i = decltype(ic)::value;
-            if (wave + 8 * i < npieces) {
-                const int pc = wave + 8 * i, cr = 16 * pc + (lane >> 2);
-                const int lr = cr < rows_a ? cr : cr - rows_a;
-                const int s0 = (((lane & 3) ^ ((lr >> 2) & 3)) << 2);                      // first sample of this lane's chunk
-                f32x4* q = reinterpret_cast<f32x4*>(base + (__builtin_amdgcn_readfirstlane(pdst[i]) >> 2) + lane * 4);
-                f32x4 v = *q;
-                v[0] = s0 + 0 < nvalid ? v[0] : 0.f; v[1] = s0 + 1 < nvalid ? v[1] : 0.f;
-                v[2] = s0 + 2 < nvalid ? v[2] : 0.f; v[3] = s0 + 3 < nvalid ? v[3] : 0.f;
-                *q = v;
-            }
-        });
+    auto convert1 = [&](int st, auto setc, auto kc, auto guardc) TN_INLINE_LAMBDA {    // item k: register set -> image buffer st & 1 (+ bias row sums)
+        constexpr int set = decltype(setc)::value, k = decltype(kc)::value;
+        constexpr bool GUARD = decltype(guardc)::value;
+        unsigned char* img = lds + (st & 1) * WX_IMG_BYTES;
+        f32x4 x = raw[set][k];
+        if constexpr (GUARD) {                                   // slots behind M were never written by the chain kernels
+            const int nvalid = (int)(M - (int64_t)(blk0 + (st >> 1)) * 32) - (st & 1) * 16;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[e] = 4 * chunk + e < nvalid ? x[e] : 0.0f;
+        }
+        bs[k] += (x[0] + x[1]) + (x[2] + x[3]);
+        u32x2_t p1, p2, p3;
+        tn_split3x4(x, p1, p2, p3);
+        const uint32_t o = wx_img_off(0, crow[k], chunk >> 1) + (chunk & 1) * 8;
+        *reinterpret_cast<u32x2_t*>(img + o) = p1;
+        *reinterpret_cast<u32x2_t*>(img + o + 2 * WG_LDS_ROWS * 32) = p2;
+        *reinterpret_cast<u32x2_t*>(img + o + 2 * (2 * WG_LDS_ROWS * 32)) = p3;
     };
-    auto is_tail = [&](int st) TN_INLINE_LAMBDA { return (int64_t)(blk0 + (st >> 1)) * 32 + 32 > M; };      // wave-uniform
-
     const int frow = lane & 31, fh = lane >> 5;
     const bool active = (a_t0 < n_at) && (b_t0 < n_bt);
-    const bool do_bias = job[JOB_HAS_BIAS] && wb == 0;
-    // every wave issues exactly `mine` DMA instructions per stage: the counted waits below are in units of stages
-    const int mine = (npieces - wave + 7) / 8;                  // wave-uniform, 1..4 (npieces >= 8 for every job class? no: head = 2+..)
+    uint32_t oa[TA], ob[TB];                                     // piece-0 image offsets of this lane's fragments
+#pragma unroll
+    for (int i = 0; i < TA; ++i) oa[i] = wx_img_off(0, (a_t0 + i) * 32 + frow, fh);
+#pragma unroll
+    for (int j = 0; j < TB; ++j) ob[j] = wx_img_off(0, rows_a + (b_t0 + j) * 32 + frow, fh);
+    constexpr uint32_t PS = 2 * WG_LDS_ROWS * 32;                // bytes between pieces
 
-#pragma unroll 1
-    for (int st = 0; st < NS - 1 && st < nst; ++st) issue(st);
-#pragma unroll 1
-    for (int st = 0; st < nst; ++st) {
-        // wait for this wave's DMA of stage st: the NS-2 younger stages (fewer at the end) may stay in flight
-        const int newer = (nst - 1 - st) < (NS - 2) ? (nst - 1 - st) : (NS - 2);
-        wx_wait_vm(mine * newer);
-        if (is_tail(st)) { clear_tail(st); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-        __builtin_amdgcn_s_barrier();          // stage st is visible to everyone; everyone is done with stage st-1: its slot is free
-#ifndef WX_NO_DMA        // diagnostic build: compute on whatever the prologue staged
-        if (st + NS - 1 < nst) issue(st + NS - 1);
-#endif
-        const float* A = lds + slot_c * slot_floats;
-        const float* B = A + rows_a * 16;
-        slot_c = slot_c + 1 == NS ? 0 : slot_c + 1;
-        if (active) {
-            // lane (row, fh) holds samples 8 fh .. 8 fh + 7 of its row's 16: chunks 2 fh and 2 fh + 1
-            bf16x8_t a1[TA], a2[TA], a3[TA];
+    // One iteration: the MFMAs of stage s (image s & 1) with the conversion of stage s+1 (register set -> image (s+1) & 1)
+    // and the re-fill of that set with stage s+1+PD woven BETWEEN the MFMA groups: the two waves of a SIMD run in lockstep
+    // (one barrier per stage), so conversion work that is not in an MFMA's shadow leaves the matrix pipe idle.
+    auto iteration = [&](int s, auto uc, auto activec, auto guardc) TN_INLINE_LAMBDA {
+        constexpr int u = decltype(uc)::value;                   // s % PD
+        constexpr int set = (u + 1) % PD;
+        constexpr bool ACTIVE = decltype(activec)::value, GUARD = decltype(guardc)::value;
+        using SetC = std::integral_constant<int, set>;
+        const bool conv = !GUARD || s + 1 < nst, fill = !GUARD || s + 1 + PD < nst;
+        const unsigned char* img = lds + (u & 1) * WX_IMG_BYTES;
+        bf16x8_t a1[TA], a2[TA], a3[TA];
+        if constexpr (ACTIVE) {
 #pragma unroll
             for (int i = 0; i < TA; ++i) {
-                const f32x4 lo = *reinterpret_cast<const f32x4*>(A + wx_lds_off((a_t0 + i) * 32 + frow, 2 * fh));
-                const f32x4 hi = *reinterpret_cast<const f32x4*>(A + wx_lds_off((a_t0 + i) * 32 + frow, 2 * fh + 1));
-                if (do_bias) bsum[i] += ((lo[0] + lo[1]) + (lo[2] + lo[3])) + ((hi[0] + hi[1]) + (hi[2] + hi[3]));
-                tn_split3(lo, hi, a1[i], a2[i], a3[i]);
+                a1[i] = *reinterpret_cast<const bf16x8_t*>(img + oa[i]);
+                a2[i] = *reinterpret_cast<const bf16x8_t*>(img + oa[i] + PS);
+                a3[i] = *reinterpret_cast<const bf16x8_t*>(img + oa[i] + 2 * PS);
             }
-#pragma unroll
-            for (int j = 0; j < TB; ++j) {
-                const f32x4 lo = *reinterpret_cast<const f32x4*>(B + wx_lds_off((b_t0 + j) * 32 + frow, 2 * fh));
-                const f32x4 hi = *reinterpret_cast<const f32x4*>(B + wx_lds_off((b_t0 + j) * 32 + frow, 2 * fh + 1));
-                bf16x8_t b1, b2, b3;
-                tn_split3(lo, hi, b1, b2, b3);
+        }
+        tn_static_for<TB>([&](auto jc) TN_INLINE_LAMBDA {
+            constexpr int j = decltype(jc)::value;
+#ifndef WX_NO_CONVERT    // diagnostic build: MFMA phase only
+            tn_static_for<4 / TB>([&](auto qc) TN_INLINE_LAMBDA {
+                constexpr int k = j * (4 / TB) + decltype(qc)::value;
+                using KC = std::integral_constant<int, k>;
+                if (conv) convert1(s + 1, SetC{}, KC{}, guardc);
+                if (fill) fetch1(s + 1 + PD, SetC{}, KC{});
+            });
+#endif
+            if constexpr (ACTIVE) {
+                const bf16x8_t b1 = *reinterpret_cast<const bf16x8_t*>(img + ob[j]);
+                const bf16x8_t b2 = *reinterpret_cast<const bf16x8_t*>(img + ob[j] + PS);
+                const bf16x8_t b3 = *reinterpret_cast<const bf16x8_t*>(img + ob[j] + 2 * PS);
                 // six exact partial products per (i, j), small terms first; term outermost so that consecutive MFMAs go to
                 // different accumulators
 #ifndef WX_ONE_MFMA      // diagnostic build: only the leading product
@@ -365,15 +376,70 @@ __device__ __forceinline__ void wgrad_x3_body(const float* __restrict__ stash, i
 #endif
 #pragma unroll
                 for (int i = 0; i < TA; ++i) acc[i][j] = TN_MFMA16(a1[i], b1, acc[i][j]);
+#ifndef WX_NO_SGB
+                // Left alone, the scheduler emits the 6 TA MFMAs of a group back to back and the conversion of one item (22 VALU,
+                // 3 LDS writes, 1 buffer load) after them — in the shadow of the LAST MFMA only.  Pin "one MFMA, two VALU".
+                if constexpr (TA * 6 >= 12 && !GUARD) {
+#pragma unroll
+                    for (int m = 0; m < 6 * TA; ++m) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // 1 MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);       // 2 VALU
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x200, 3, 0);           // the item's 3 LDS writes
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);           // its re-fill load
+                    __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);           // the next group's B fragments
+                }
+#endif
             }
+        });
+    };
+
+    // Prologue: stages 0 .. PD-1 into the register sets, stage 0 converted (guarded), its set re-filled with stage PD.
+    using T_ = std::true_type; using F_ = std::false_type;
+    tn_static_for<PD>([&](auto pc) TN_INLINE_LAMBDA {
+        constexpr int p_ = decltype(pc)::value;
+        using PC = std::integral_constant<int, p_>;
+        tn_static_for<4>([&](auto kc) TN_INLINE_LAMBDA { if (p_ < nst) fetch1(p_, PC{}, kc); });
+    });
+    using C0 = std::integral_constant<int, 0>;
+    tn_static_for<4>([&](auto kc) TN_INLINE_LAMBDA {
+        if (nst > 0) convert1(0, C0{}, kc, T_{});
+        if (PD < nst) fetch1(PD, C0{}, kc);
+    });
+    // Unguarded iterations: s + 1 + PD < nst, and stage s + 1 lies in a full block (the ragged last block of the batch, if this
+    // job reaches it, is left to the guarded loop).
+    const int64_t full_blocks = M / 32 - blk0;
+    const int n_safe = 2 * (int)(full_blocks < nblk ? (full_blocks > 0 ? full_blocks : 0) : nblk);      // stages 0 .. n_safe-1 are in full blocks
+    int n_fast = nst - 1 - PD < n_safe - 1 ? nst - 1 - PD : n_safe - 1;                                   // iterations 0 .. n_fast-1 need no guard
+    n_fast = n_fast > 0 ? n_fast / PD * PD : 0;
+    // (a raw s_barrier does not wait for this wave's outstanding LDS writes: lgkmcnt(0) in front of every barrier.  The barrier
+    // orders "image s & 1 complete" (written in iteration s-1) and "everyone is done reading image (s+1) & 1" (read in s-1).)
+    auto run = [&](auto activec) TN_INLINE_LAMBDA {
+#pragma unroll 1
+        for (int s0 = 0; s0 < n_fast; s0 += PD) {
+            tn_static_for<PD>([&](auto uc) TN_INLINE_LAMBDA {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                iteration(s0 + decltype(uc)::value, uc, activec, F_{});
+            });
         }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll 1
+        for (int s0 = n_fast; s0 < nst; s0 += PD) {
+            tn_static_for<PD>([&](auto uc) TN_INLINE_LAMBDA {
+                if (s0 + decltype(uc)::value < nst) {            // wave-uniform
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    iteration(s0 + decltype(uc)::value, uc, activec, T_{});
+                }
+            });
+        }
+    };
+    if (active) run(T_{}); else run(F_{});
 
     // epilogue: partial block -> this workgroup's slab  [n_at*32][n_bt*32] then bias [n_at*32]   (as wgrad_body)
+    float* slab = slabs + job[JOB_SLAB_OFF];
+    const int ld = n_bt * 32;
     if (active) {
-        float* slab = slabs + job[JOB_SLAB_OFF];
-        const int ld = n_bt * 32;
 #pragma unroll
         for (int i = 0; i < TA; ++i)
 #pragma unroll
@@ -381,12 +447,13 @@ __device__ __forceinline__ void wgrad_x3_body(const float* __restrict__ stash, i
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     slab[(int64_t)((a_t0 + i) * 32 + TN_ACC_ROW(r, fh)) * ld + (b_t0 + j) * 32 + frow] = acc[i][j][r];
-        if (do_bias) {
+    }
+    if (has_bias) {                                              // row sums of A: the 4 lanes of a row hold its 4 chunks
 #pragma unroll
-            for (int i = 0; i < TA; ++i) {
-                const float tot = bsum[i] + __shfl_xor(bsum[i], 32, 64);
-                if (fh == 0) slab[(int64_t)n_at * 32 * ld + (a_t0 + i) * 32 + frow] = tot;
-            }
+        for (int k = 0; k < 4; ++k) {
+            float t = bs[k];
+            t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64);
+            if (chunk == 0 && isA[k]) slab[(int64_t)n_at * 32 * ld + crow[k]] = t;          // (isA implies the row exists in the slab)
         }
     }
 }
@@ -407,10 +474,10 @@ __global__ __launch_bounds__(512, 2) void k_wgrad(const float* __restrict__ stas
     const int n_at = job[JOB_N_AT], n_bt = job[JOB_N_BT], WA = job[JOB_WA], WB = 8 / WA;
     const int ta = (n_at + WA - 1) / WA, tb = (n_bt + WB - 1) / WB;     // the host plan only emits full-or-idle waves
     switch (ta * 8 + tb) {
-        case 2 * 8 + 4: if (X3) wgrad_x3_body<2, 4>(stash, stash_rows, M, job, slabs, lds); else wgrad_body<2, 4>(stash, stash_rows, M, job, slabs, lds); break;
-        case 1 * 8 + 2: if (X3) wgrad_x3_body<1, 2>(stash, stash_rows, M, job, slabs, lds); else wgrad_body<1, 2>(stash, stash_rows, M, job, slabs, lds); break;
-        case 2 * 8 + 1: if (X3) wgrad_x3_body<2, 1>(stash, stash_rows, M, job, slabs, lds); else wgrad_body<2, 1>(stash, stash_rows, M, job, slabs, lds); break;
-        case 1 * 8 + 1: if (X3) wgrad_x3_body<1, 1>(stash, stash_rows, M, job, slabs, lds); else wgrad_body<1, 1>(stash, stash_rows, M, job, slabs, lds); break;
+        case 2 * 8 + 4: if (X3) wgrad_x3_body<2, 4, 2>(stash, stash_rows, M, job, slabs, lds); else wgrad_body<2, 4>(stash, stash_rows, M, job, slabs, lds); break;
+        case 1 * 8 + 2: if (X3) wgrad_x3_body<1, 2, 4>(stash, stash_rows, M, job, slabs, lds); else wgrad_body<1, 2>(stash, stash_rows, M, job, slabs, lds); break;
+        case 2 * 8 + 1: if (X3) wgrad_x3_body<2, 1, 4>(stash, stash_rows, M, job, slabs, lds); else wgrad_body<2, 1>(stash, stash_rows, M, job, slabs, lds); break;
+        case 1 * 8 + 1: if (X3) wgrad_x3_body<1, 1, 4>(stash, stash_rows, M, job, slabs, lds); else wgrad_body<1, 1>(stash, stash_rows, M, job, slabs, lds); break;
         default: break;   // unreachable: shapes are validated on the host (tnerf_plan_fill)
     }
 #ifdef TN_STAMPS
