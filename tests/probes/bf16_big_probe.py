@@ -32,7 +32,7 @@ for R in (2500, 5000):
     w16 = torch.cat([x.reshape(-1) for x in g16])
     b = st.repack_bf16(); bp = b.train_plan(R, S)
     ztab = ops.depth_table(2.0, 6.0, S, dev)
-    comp = torch.empty(R, 3, device=dev); gws = torch.empty(R, 3, device=dev); loss = torch.zeros(1, device=dev)
+    comp = torch.empty(R, 3, device=dev); gws = torch.empty(R, 4, device=dev); loss = torch.zeros(1, device=dev)
     od, dd, tg, td = o.to(dev), d.to(dev), tgt.to(dev), t.to(dev)
     s_ = torch.cuda.current_stream(dev).cuda_stream
     st.grad.zero_()

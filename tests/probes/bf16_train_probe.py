@@ -24,7 +24,7 @@ def grads_bf16(model, st, o, d, tgt, t, S, denom=None):
     b = st.repack_bf16()
     bp = b.train_plan(R, S)
     ztab = ops.depth_table(2.0, 6.0, S, dev)
-    comp = torch.empty(R, 3, device=dev); gws = torch.empty(R, 3, device=dev); loss = torch.zeros(1, device=dev)
+    comp = torch.empty(R, 3, device=dev); gws = torch.empty(R, 4, device=dev); loss = torch.zeros(1, device=dev)
     st.grad.zero_()
     L.call("tnerf_train_step_fused_bf16", C.byref(st.desc), b.packed.data_ptr(), o.data_ptr(), d.data_ptr(), tgt.data_ptr(), R, S,
            ztab.data_ptr(), 1, t.data_ptr(), 0, 0, 1, float(denom or 3 * R), comp.data_ptr(), gws.data_ptr(), loss.data_ptr(),

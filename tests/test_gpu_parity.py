@@ -201,7 +201,7 @@ def test_mlp_rejects_what_it_cannot_do(mods, dev):
     with pytest.raises(RuntimeError):
         m(torch.zeros(4, 40, device=dev))
     with pytest.raises(NotImplementedError):
-        mods["nerf"].TinyNeRF(39, 200, 8, 4).to(dev)(torch.zeros(4, 39, device=dev))
+        mods["nerf"].TinyNeRF(39, 512, 8, 4).to(dev)(torch.zeros(4, 39, device=dev))      # widths above 256: no kernel
 
 
 # -------------------------------------------------------------------------- fused render / train
@@ -616,7 +616,7 @@ def _bf16_step_grads(mods, dev, model, st, o, d, tgt, t, S, cam=None, pixels=Non
     R = t.shape[0]
     b = st.repack_bf16(); bp = b.train_plan(R, S)
     ztab = ops.depth_table(2.0, 6.0, S, dev)
-    comp = torch.empty(R, 3, device=dev); gws = torch.empty(R, 3, device=dev); loss = torch.zeros(1, device=dev)
+    comp = torch.empty(R, 3, device=dev); gws = torch.empty(R, 4, device=dev); loss = torch.zeros(1, device=dev)
     st.grad.zero_()
     s_ = torch.cuda.current_stream(dev).cuda_stream
     tail = (comp.data_ptr(), gws.data_ptr(), loss.data_ptr(), bp.stash.data_ptr(), bp.jobs.data_ptr(), bp.n_jobs, bp.slabs.data_ptr(),

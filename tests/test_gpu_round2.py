@@ -521,3 +521,68 @@ def test_dataset_step_equals_the_per_call_path_bitwise(mods, dev, prec):
     assert torch.equal(torch.cat(pix_parts), full.pix)
     assert abs(l_parts - l_full) <= 1e-5 * l_full
     assert float((parts[0] + parts[1] - g_full).abs().max()) <= (2e-5 if prec == "fp32" else 2e-3) * float(g_full.abs().max())
+
+
+# ------------------------------------------------------------------------------- any hidden width up to 256
+@pytest.mark.parametrize("arch", [(39, 200, 3, 2), (63, 64, 4, 2), (39, 100, 2, 0), (27, 31, 3, 1)])
+def test_hidden_widths_other_than_128_and_256(mods, dev, arch):
+    """TinyNeRF(in_dim, hidden, ...) with any hidden <= 256 (reference src/nerf.py:10 takes any): zero-padded onto the 128- /
+    256-wide kernels.  MLP forward / backward, fused render, three whole train steps (speed path) and the bf16 render against
+    the oracle; state_dict shapes are the true ones."""
+    in_dim, hidden, depth, skip = arch
+    L = (in_dim - 3) // 6
+    torch.manual_seed(1)
+    model = mods["nerf"].TinyNeRF(in_dim, hidden, depth, skip).to(dev)
+    with torch.no_grad():
+        model.sigma[0].bias += 0.5
+    params = [p.detach().cpu().clone() for p in model.parameters()]
+    assert [tuple(p.shape) for p in params] == O.mlp_shapes(in_dim, hidden, depth, skip)
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(777, in_dim, generator=g)
+    gr, gs = torch.randn(777, 3, generator=g) * 0.1, torch.randn(777, 1, generator=g) * 0.1
+    leaves = [p.clone().requires_grad_(True) for p in params]
+    ro_, so_ = O.mlp_forward(leaves, x, skip)
+    go = torch.autograd.grad((ro_ * gr).sum() + (so_ * gs).sum(), leaves)
+    rgb, sig = model(x.to(dev))
+    assert float((rgb.detach().cpu() - ro_.detach()).abs().max()) <= 2e-6 and float((sig.detach().cpu() - so_.detach()).abs().max()) <= 1e-5 * max(1.0, float(so_.abs().max()))
+    ((rgb * gr.to(dev)).sum() + (sig * gs.to(dev)).sum()).backward()
+    worst = max(relmax(p.grad.cpu(), q) for p, q in zip(model.parameters(), go))
+    assert worst <= 5e-5, worst
+    assert model.state_dict()["layers.0.weight"].shape == (hidden, in_dim) and model.hip_state().n_params == sum(p.numel() for p in params)
+    # fused render
+    R, S = 96, 40
+    d = torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=-1)
+    o = -4.0 * d + 0.3 * torch.randn(R, 3, generator=g)
+    st, plist = model._ensure_packed(), model._param_list()
+    with torch.no_grad():
+        comp, dep, acc = mods["ops"].render_rays_fused(st, plist, o.to(dev), d.to(dev), 2.0, 6.0, S, False)
+    co, do_, ao, _ = O.render_rays(params, skip, L, o, d, 2.0, 6.0, S, None)
+    assert float((comp.cpu() - co).abs().max()) <= RGB_TOL and float((acc.cpu() - ao).abs().max()) <= RGB_TOL
+    c16 = mods["ops"].render_rays_fused_bf16(st, o.to(dev), d.to(dev), 2.0, 6.0, S)[0]
+    assert float((c16.cpu() - O.render_rays_bf16(params, skip, L, o, d, 2.0, 6.0, S, None)[0]).abs().max()) <= 2e-3
+    assert float((c16.cpu() - co).abs().max()) <= 2e-2
+    # three whole train steps on device-resident state, fp32 and bf16, against the oracle on the emulated draws
+    images, poses, focal = _small_scene(mods, dev)
+    N, H, W, _ = images.shape
+    pixs = images.reshape(N, H * W, 3)
+    Rg, seed = 64, 9
+    for prec in ("fp32", "bf16"):
+        torch.manual_seed(1)
+        m = mods["nerf"].TinyNeRF(in_dim, hidden, depth, skip).to(dev)
+        with torch.no_grad():
+            m.sigma[0].bias += 0.5
+        opt = mods["trainer"].FlatAdam(m, lr=5e-4)
+        tr = mods["trainer"].DatasetTrainer(m, opt, images.to(dev), poses.to(dev), focal, Rg, S, 2.0, 6.0, seed=seed, precision=prec, record_pixels=True)
+        ps = [p.clone() for p in params]
+        adam = O.AdamState(ps, lr=5e-4)
+        for s in range(3):
+            loss, _ = tr.step()
+            torch.cuda.synchronize()
+            pix, u = _emulated_draws(seed, s, Rg, S, H * W)
+            assert torch.equal(tr.pix.cpu().long(), pix)
+            ro, rd = O.pinhole_rays(H, W, focal, poses[s % N])
+            lo_, _, grads = O.loss_and_grads(ps, skip, L, ro[pix], rd[pix], pixs[s % N, pix], 2.0, 6.0, S, u)
+            assert math.isclose(float(loss), float(lo_), rel_tol=3e-4 if prec == "fp32" else 3e-2), (prec, s, float(loss), float(lo_))
+            adam.step(ps, grads)
+        err = max(float((p.detach().cpu() - q).abs().max()) for p, q in zip(m.parameters(), ps))
+        assert err <= (5e-5 if prec == "fp32" else 2e-3), (prec, err)      # bf16: 3 Adam steps of lr 5e-4 may flip the sign of tiny gradients

@@ -40,9 +40,9 @@ def test_library_exports_every_declared_symbol():
 
 def test_error_reporting_no_throw():
     lib = tl.load()
-    d = _desc(39, 200, 8, 4)
+    d = _desc(39, 300, 8, 4)
     assert lib.tnerf_param_count(C.byref(d)) == -1
-    assert "hidden=200" in tl.last_error()
+    assert "hidden=300" in tl.last_error()
     with pytest.raises(NotImplementedError):
         tl.check(tl.EUNSUPPORTED, "x")
     d = _desc(39, 256, 8, 8)     # skip_at == depth: heads would see hidden+in_dim (reference raises too)
@@ -595,3 +595,85 @@ def test_scatter_table_is_the_inverse_of_the_pack_table():
                     assert not (sc[~ok, k + 1] >= 0).any()          # -1 terminated rows
             assert np.array_equal(rebuilt, t)
             assert (sc[:, 0] >= 0).all()                            # every parameter is packed somewhere
+
+
+# ------------------------------------------------------------------------------- round 2: any hidden width up to 256
+def _embed_true_params(cfg_true, hk, params_true):
+    """Independent statement of the zero padding: true-width parameters placed into the flat vector of the hk-wide model
+    (weights at [:Ht, :Ht] and — skip layer — the input columns behind column hk; everything else 0), and for every true
+    parameter its index in that vector."""
+    in_dim, ht, depth, skip_at = cfg_true
+    flat, index = [], []
+    off = 0
+    fan_t, fan_k = in_dim, in_dim
+    for l in range(depth):
+        Wt, bt = params_true[2 * l].numpy(), params_true[2 * l + 1].numpy()
+        Wk = np.zeros((hk, fan_k)); idx = -np.ones((hk, fan_k), np.int64)
+        grid = off + np.arange(hk * fan_k).reshape(hk, fan_k)
+        if l == 0:
+            Wk[:ht, :] = Wt; sel = grid[:ht, :]
+        else:
+            Wk[:ht, :ht] = Wt[:, :ht]
+            sel = grid[:ht, :ht]
+            if fan_t > ht:                                  # skip layer: [hidden | input]
+                Wk[:ht, hk:] = Wt[:, ht:]
+                sel = np.concatenate([grid[:ht, :ht], grid[:ht, hk:]], axis=1)
+        flat.append(Wk.reshape(-1)); index.append(sel.reshape(-1)); off += hk * fan_k
+        bk = np.zeros(hk); bk[:ht] = bt
+        flat.append(bk); index.append(off + np.arange(ht)); off += hk
+        fan_t = ht + in_dim if (skip_at > 0 and l == skip_at - 1) else ht
+        fan_k = hk + in_dim if (skip_at > 0 and l == skip_at - 1) else hk
+    ws, bsig, wc, bc = (p.numpy() for p in params_true[2 * depth:])
+    wk = np.zeros((1, hk)); wk[:, :ht] = ws
+    flat.append(wk.reshape(-1)); index.append(off + np.arange(ht)); off += hk
+    flat.append(bsig); index.append(off + np.arange(1)); off += 1
+    wk = np.zeros((3, hk)); wk[:, :ht] = wc
+    flat.append(wk.reshape(-1)); index.append((off + np.arange(3 * hk).reshape(3, hk))[:, :ht].reshape(-1)); off += 3 * hk
+    flat.append(bc); index.append(off + np.arange(3)); off += 3
+    return np.concatenate(flat), np.concatenate(index)
+
+
+@pytest.mark.parametrize("cfg", [(39, 200, 3, 2), (63, 64, 4, 2), (39, 100, 2, 0), (27, 31, 3, 1)])
+def test_any_hidden_width_runs_on_the_padded_kernels(cfg):
+    """hidden = 31 / 64 / 100 / 200 (reference src/nerf.py:10 takes any width): the tables handed to the 128- / 256-wide
+    kernels must be exactly the wide model's tables with the true parameters embedded and zeros elsewhere — pack tables
+    (fp32 fragments, bf16 streams) and the slab -> gradient reduce tables (fp32 and bf16 plans)."""
+    in_dim, ht, depth, skip_at = cfg
+    hk = 128 if ht <= 128 else 256
+    lib = tl.load()
+    g = torch.Generator().manual_seed(11)
+    params = O.mlp_init(in_dim, ht, depth, skip_at, g)
+    flat_true = torch.cat([p.reshape(-1) for p in params]).double().numpy()
+    d_t, d_k = _desc(in_dim, ht, depth, skip_at), _desc(in_dim, hk, depth, skip_at)
+    assert lib.tnerf_param_count(C.byref(d_t)) == flat_true.shape[0]
+    k = 2 * depth + 4
+    off = np.zeros(k, np.int64); rows = np.zeros(k, np.int64); cols = np.zeros(k, np.int64)
+    tl.call("tnerf_param_layout", C.byref(d_t), _ptr(off), _ptr(rows), _ptr(cols))
+    assert [tuple(int(v) for v in rc) for rc in zip(rows, cols)] == [tuple(p.shape) if p.dim() == 2 else (p.shape[0], 1) for p in params]
+    assert off.tolist() == np.concatenate([[0], np.cumsum([p.numel() for p in params])[:-1]]).tolist()
+    flat_k, index = _embed_true_params(cfg, hk, [p.double() for p in params])
+    assert index.shape[0] == flat_true.shape[0] and np.array_equal(flat_k[index], flat_true)
+    M, n_cu = 96, 16
+    sz_t, pack_t, jobs_t, red_t, _, _ = _plan(cfg, M, n_cu)
+    sz_k, pack_k, jobs_k, red_k, _, _ = _plan((in_dim, hk, depth, skip_at), M, n_cu)
+    assert sz_t.packed_floats == sz_k.packed_floats and sz_t.stash_floats == sz_k.stash_floats and sz_t.slab_floats == sz_k.slab_floats
+    assert sz_t.n_params == flat_true.shape[0] and np.array_equal(jobs_t, jobs_k)
+    got = np.where(pack_t >= 0, flat_true[np.clip(pack_t, 0, None)], 0.0)
+    want = np.where(pack_k >= 0, flat_k[np.clip(pack_k, 0, None)], 0.0)
+    assert np.array_equal(got, want)                                        # what the kernels read is the embedded model, zeros included
+    HDR = 260
+    assert np.array_equal(red_t[:HDR], red_k[:HDR])
+    assert np.array_equal(red_t[HDR:].reshape(-1, 2), red_k[HDR:].reshape(-1, 2)[index])
+    if in_dim >= 9 and (in_dim - 3) % 6 == 0:                               # bf16 mode
+        tabs = []
+        for d in (d_t, d_k):
+            bs = tl.Bf16Sizes(); tl.call("tnerf_bf16_plan_sizes", C.byref(d), C.byref(bs))
+            t16 = np.empty(int(bs.pack_entries), np.int32); tl.call("tnerf_bf16_pack_table", C.byref(d), _ptr(t16))
+            tp = tl.Bf16TrainPlan(); tl.call("tnerf_bf16_train_sizes", C.byref(d), 5, 33, n_cu, C.byref(tp))
+            jb = np.empty(tp.job_ints, np.int32); rd = np.empty(tp.reduce_ints, np.int32)
+            tl.call("tnerf_bf16_train_fill", C.byref(d), 5, 33, n_cu, _ptr(jb), _ptr(rd))
+            tabs.append((t16, jb, rd, tp.stash_bytes))
+        (p_t, j_t, r_t, s_t), (p_k, j_k, r_k, s_k) = tabs
+        assert p_t.shape == p_k.shape and s_t == s_k and np.array_equal(j_t, j_k)
+        assert np.array_equal(np.where(p_t >= 0, flat_true[np.clip(p_t, 0, None)], 0.0), np.where(p_k >= 0, flat_k[np.clip(p_k, 0, None)], 0.0))
+        assert np.array_equal(r_t[:HDR], r_k[:HDR]) and np.array_equal(r_t[HDR:].reshape(-1, 2), r_k[HDR:].reshape(-1, 2)[index])

@@ -55,8 +55,10 @@ extern "C" int tnerf_sample_tables(float near_, float far_, int32_t S, float* zt
 // ------------------------------------------------------------------------------ model layout
 static int check_desc(const tnerf_mlp_desc* d) {
     if (!d) { tn_set_error("NULL tnerf_mlp_desc"); return TNERF_EINVAL; }
-    if (d->hidden != 128 && d->hidden != 256) {
-        tn_set_error("hidden=%d: only 128 and 256 are built", d->hidden); return TNERF_EUNSUPPORTED; }
+    if (d->hidden < 1 || d->hidden > 256) {
+        // any width up to 256 runs on the 128- or 256-wide kernels with zero-padded weights (the padding units stay exactly 0
+        // through bias 0 + ReLU and receive no gradient that is ever read); wider layers need kernels that are not built
+        tn_set_error("hidden=%d: widths 1..256 are built", d->hidden); return TNERF_EUNSUPPORTED; }
     if (d->depth < 1 || d->depth > TN_MAXD) { tn_set_error("depth=%d out of [1,%d]", d->depth, TN_MAXD); return TNERF_EUNSUPPORTED; }
     if (d->in_dim < 1 || d->in_dim > 64) { tn_set_error("in_dim=%d out of [1,64]", d->in_dim); return TNERF_EUNSUPPORTED; }
     if (d->skip_at < 0 || d->skip_at >= d->depth) {
@@ -87,10 +89,23 @@ extern "C" int tnerf_input_pairing(int32_t in_dim, int32_t* emap, int32_t* n_ste
     return TNERF_OK;
 }
 
-extern "C" int tn_build_layout(const tnerf_mlp_desc* d, MlpLayout* L) {
-    int rc = check_desc(d); if (rc) return rc;
+static int64_t true_param_count(const tnerf_mlp_desc* d) {
+    int64_t n = 0; int fan = d->in_dim;
+    for (int l = 0; l < d->depth; ++l) {
+        n += (int64_t)d->hidden * fan + d->hidden;
+        fan = (d->skip_at > 0 && l == d->skip_at - 1) ? d->hidden + d->in_dim : d->hidden;
+    }
+    return n + 4 * (int64_t)d->hidden + 4;
+}
+
+extern "C" int tn_build_layout(const tnerf_mlp_desc* d_true, MlpLayout* L) {
+    int rc = check_desc(d_true); if (rc) return rc;
+    tnerf_mlp_desc padded = *d_true;
+    padded.hidden = d_true->hidden <= 128 ? 128 : 256;                 // the kernel width
+    const tnerf_mlp_desc* d = &padded;
     memset(L, 0, sizeof(*L));
     L->in_dim = d->in_dim; L->hidden = d->hidden; L->depth = d->depth; L->skip_at = d->skip_at; L->flags = d->flags;
+    L->hidden_true = d_true->hidden;
     L->NT = d->hidden / 32;
     int32_t em[64], ne;
     rc = tnerf_input_pairing(d->in_dim, em, &ne); if (rc) return rc;
@@ -104,7 +119,8 @@ extern "C" int tn_build_layout(const tnerf_mlp_desc* d, MlpLayout* L) {
         fan = (d->skip_at > 0 && l == d->skip_at - 1) ? H + d->in_dim : H;
     }
     L->p_ws = off; off += H; L->p_bs = off; off += 1; L->p_wc = off; off += 3 * (int64_t)H; L->p_bc = off; off += 3;
-    L->n_params = off;
+    L->n_params_padded = off;
+    L->n_params = true_param_count(d_true);
     // packed segments
     int64_t po = 0;
     for (int l = 0; l < d->depth; ++l) {
@@ -129,6 +145,43 @@ extern "C" int tn_build_layout(const tnerf_mlp_desc* d, MlpLayout* L) {
     return TNERF_OK;
 }
 
+// Padded parameter space (what the table builders below index) <-> the caller's flat parameters (state_dict order, true
+// width): to_true[padded index] = true index or -1 (padding).  Identity when hidden is 128 or 256.
+static void param_maps(const MlpLayout& L, std::vector<int32_t>& to_true, std::vector<int32_t>* to_padded) {
+    const int Hk = L.hidden, Ht = L.hidden_true;
+    to_true.assign((size_t)L.n_params_padded, -1);
+    if (to_padded) to_padded->assign((size_t)L.n_params, -1);
+    int64_t t = 0;
+    auto link = [&](int64_t pp) { to_true[(size_t)pp] = (int32_t)t; if (to_padded) (*to_padded)[(size_t)t] = (int32_t)pp; ++t; };
+    for (int l = 0; l < L.depth; ++l) {
+        const int fan_k = L.fan_in[l];                                   // padded fan-in: in_dim | Hk | Hk + in_dim
+        for (int n = 0; n < Ht; ++n)
+            for (int k = 0; k < fan_k; ++k) {
+                if (l > 0 && k >= Ht && k < Hk) continue;                // padding columns of the hidden part
+                link(L.p_w[l] + (int64_t)n * fan_k + k);
+            }
+        for (int n = 0; n < Ht; ++n) link(L.p_b[l] + n);
+    }
+    for (int k = 0; k < Ht; ++k) link(L.p_ws + k);
+    link(L.p_bs);
+    for (int n = 0; n < 3; ++n) for (int k = 0; k < Ht; ++k) link(L.p_wc + (int64_t)n * Hk + k);
+    for (int n = 0; n < 3; ++n) link(L.p_bc + n);
+}
+// A reduce table built in the padded space -> the caller's table (header + 2 ints per TRUE parameter)
+static void reduce_to_true(const MlpLayout& L, const int32_t* padded, int32_t* out) {
+    std::vector<int32_t> to_true, to_padded; param_maps(L, to_true, &to_padded);
+    memcpy(out, padded, sizeof(int32_t) * TN_RED_HDR);
+    for (int64_t t = 0; t < L.n_params; ++t) {
+        out[TN_RED_HDR + 2 * t] = padded[TN_RED_HDR + 2 * (int64_t)to_padded[(size_t)t]];
+        out[TN_RED_HDR + 2 * t + 1] = padded[TN_RED_HDR + 2 * (int64_t)to_padded[(size_t)t] + 1];
+    }
+}
+static void remap_sources(const MlpLayout& L, int32_t* table, int64_t n) {      // pack-table entries: padded -> true index
+    if (L.hidden_true == L.hidden) return;
+    std::vector<int32_t> to_true; param_maps(L, to_true, nullptr);
+    for (int64_t i = 0; i < n; ++i) if (table[i] >= 0) table[i] = to_true[(size_t)table[i]];
+}
+
 extern "C" int64_t tnerf_param_count(const tnerf_mlp_desc* d) {
     MlpLayout L; if (tn_build_layout(d, &L)) return -1;
     return L.n_params;
@@ -137,22 +190,20 @@ extern "C" int64_t tnerf_param_count(const tnerf_mlp_desc* d) {
 extern "C" int tnerf_param_layout(const tnerf_mlp_desc* d, int64_t* offsets, int64_t* rows, int64_t* cols) {
     MlpLayout L; int rc = tn_build_layout(d, &L); if (rc) return rc;
     if (!offsets || !rows || !cols) { tn_set_error("tnerf_param_layout: NULL output"); return TNERF_EINVAL; }
-    int k = 0;
+    int k = 0; int64_t off = 0; int fan = d->in_dim;                    // the caller's (true-width) flat layout, state_dict order
+    auto put = [&](int64_t r, int64_t c) { offsets[k] = off; rows[k] = r; cols[k] = c; off += r * c; ++k; };
     for (int l = 0; l < d->depth; ++l) {
-        offsets[k] = L.p_w[l]; rows[k] = d->hidden; cols[k] = L.fan_in[l]; ++k;
-        offsets[k] = L.p_b[l]; rows[k] = d->hidden; cols[k] = 1; ++k;
+        put(d->hidden, fan); put(d->hidden, 1);
+        fan = (d->skip_at > 0 && l == d->skip_at - 1) ? d->hidden + d->in_dim : d->hidden;
     }
-    offsets[k] = L.p_ws; rows[k] = 1; cols[k] = d->hidden; ++k;
-    offsets[k] = L.p_bs; rows[k] = 1; cols[k] = 1; ++k;
-    offsets[k] = L.p_wc; rows[k] = 3; cols[k] = d->hidden; ++k;
-    offsets[k] = L.p_bc; rows[k] = 3; cols[k] = 1; ++k;
+    put(1, d->hidden); put(1, 1); put(3, d->hidden); put(3, 1);
     return TNERF_OK;
 }
 
 // ------------------------------------------------------------------------------- wgrad plan
 #ifndef TN_X3_TILE
 #define TN_X3_TILE 650.0
-#define TN_X3_FIXED 3160.0
+#define TN_X3_FIXED 2500.0
 #endif
 namespace {
 struct JobClass {
@@ -307,8 +358,11 @@ extern "C" int tnerf_plan_fill(const tnerf_mlp_desc* d, int64_t M, int32_t n_cu,
     if (M < 1 || n_cu < 1) { tn_set_error("tnerf_plan_fill: M=%lld n_cu=%d", (long long)M, n_cu); return TNERF_EINVAL; }
     std::vector<JobClass> cls; int64_t slab = 0;
     rc = build_classes(L, M, n_cu, cls, &slab); if (rc) return rc;
-    if (pack_table) fill_pack_table(L, pack_table);
+    if (pack_table) { fill_pack_table(L, pack_table); remap_sources(L, pack_table, L.packed_floats); }
     const int64_t MB = (M + 31) / 32;
+    std::vector<int32_t> red_padded;                                     // the table below is built in the padded parameter space
+    int32_t* const reduce_out = reduce_table;
+    if (reduce_table && L.hidden_true != L.hidden) { red_padded.assign((size_t)(TN_RED_HDR + 2 * L.n_params_padded), 0); reduce_table = red_padded.data(); }
     if (job_table) {
         // interleave classes so that heavy and light workgroups are spread over the dispatch order
         int64_t j = 0;
@@ -368,6 +422,7 @@ extern "C" int tnerf_plan_fill(const tnerf_mlp_desc* d, int64_t M, int32_t n_cu,
         }
         put(L.p_bs, cls_head, (int64_t)32 * ldh + 3);
         for (int n = 0; n < 3; ++n) put(L.p_bc + n, cls_head, (int64_t)32 * ldh + n);
+        if (reduce_table != reduce_out) reduce_to_true(L, reduce_table, reduce_out);
     }
     return TNERF_OK;
 }
@@ -380,6 +435,9 @@ extern "C" int tn_build_net16(const tnerf_mlp_desc* d, Net16* n) {
         return TNERF_EUNSUPPORTED;
     }
     memset(n, 0, sizeof(*n));
+    tnerf_mlp_desc padded = *d;
+    padded.hidden = d->hidden <= 128 ? 128 : 256;                       // the kernel width (zero-padded weights, see check_desc)
+    d = &padded;
     n->in_dim = d->in_dim; n->hidden = d->hidden; n->depth = d->depth; n->skip_at = d->skip_at;
     n->Lf = (d->in_dim - 3) / 6;
     const int NT = d->hidden / 32, KH = d->hidden / 16;
@@ -470,6 +528,7 @@ extern "C" int tnerf_bf16_pack_table(const tnerf_mlp_desc* d, int32_t* T) {
     for (int l = 0; l < L.depth; ++l) for (int j = 0; j < H; ++j) B[l * H + j] = (int32_t)(L.p_b[l] + j);
     for (int j = 0; j < 3; ++j) B[L.depth * H + j] = (int32_t)(L.p_bc + j);
     B[L.depth * H + 3] = (int32_t)L.p_bs;
+    remap_sources(L, T, n.pack_entries);
     return TNERF_OK;
 }
 
@@ -566,6 +625,9 @@ extern "C" int tnerf_bf16_train_fill(const tnerf_mlp_desc* d, int64_t n_rays, in
                 ++j;
             }
     }
+    std::vector<int32_t> red_padded;                                     // built in the padded parameter space
+    int32_t* const reduce_out = reduce_table;
+    if (reduce_table && L.hidden_true != L.hidden) { red_padded.assign((size_t)(TN_RED_HDR + 2 * L.n_params_padded), 0); reduce_table = red_padded.data(); }
     if (reduce_table) {
         int32_t* hdr = reduce_table;
         memset(hdr, 0, sizeof(int32_t) * TN_RED_HDR);
@@ -606,6 +668,7 @@ extern "C" int tnerf_bf16_train_fill(const tnerf_mlp_desc* d, int64_t n_rays, in
         }
         put(L.p_bs, cls_head, (int64_t)32 * ldh + 3);
         for (int row = 0; row < 3; ++row) put(L.p_bc + row, cls_head, (int64_t)32 * ldh + row);
+        if (reduce_table != reduce_out) reduce_to_true(L, reduce_table, reduce_out);
     }
     return TNERF_OK;
 }

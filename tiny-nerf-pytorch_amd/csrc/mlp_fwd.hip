@@ -15,8 +15,11 @@
 #endif
 #ifdef TN_STAMPS
 #define TN_STAMP(k) do { if (a.stamps && lane == 0) a.stamps[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 32 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+// the constant 100 MHz counter next to the shader-clock counter: their ratio is the clock the kernel really ran at
+#define TN_STAMP_RT(k) do { if (a.stamps && lane == 0) a.stamps[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 32 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define TN_STAMP(k) do {} while (0)
+#define TN_STAMP_RT(k) do {} while (0)
 #endif
 
 // 16 ReLU sign bits (bit r <-> v[r] > 0) of an n-tile's non-negative outputs, merged into the low (ODD = 0) or high half
@@ -162,7 +165,7 @@ __global__ __launch_bounds__(256, HID == 128 ? 2 : 1) void k_render_fused(FwdArg
     tn_fetch_ray(rs, ray, ro_, rd_);
     const float ox = ro_[0], oy = ro_[1], oz = ro_[2], dx = rd_[0], dy = rd_[1], dz = rd_[2];
     const float dn = tn_norm3(dx, dy, dz);
-    TN_STAMP(0);
+    TN_STAMP(0); TN_STAMP_RT(20);
     float T_in = 1.0f, cr = 0.f, cg = 0.f, cb = 0.f, cd = 0.f, ca = 0.f;
 
     // March the ray 32 samples at a time (ONE inlined copy of the MLP body); every second tile (or the
@@ -216,7 +219,7 @@ __global__ __launch_bounds__(256, HID == 128 ? 2 : 1) void k_render_fused(FwdArg
         if (a.acc) a.acc[ray] = ca;
         if (TRAIN && a.loss.ray_ws) tn_ray_loss(a.loss, rs, ray, cr + bg, cg + bg, cb + bg);      // train.py:122
     }
-    TN_STAMP(14);
+    TN_STAMP(14); TN_STAMP_RT(21);
 }
 
 // ----------------------------------------------------------------------------------- dispatch

@@ -30,7 +30,9 @@ struct MlpLayout {
     // flat parameter offsets
     int64_t p_w[TN_MAXD], p_b[TN_MAXD];
     int32_t fan_in[TN_MAXD];
-    int64_t p_ws, p_bs, p_wc, p_bc, n_params;
+    int64_t p_ws, p_bs, p_wc, p_bc, n_params;        // n_params: of the caller's (true-width) model; the offsets above: PADDED space
+    int32_t hidden_true;        // the caller's hidden width (<= hidden, the kernel width 128 / 256 it is zero-padded to)
+    int64_t n_params_padded;
     // stash rows (feature-major matrices, row stride Mp floats)
     int32_t enc_row0, h_row0[TN_MAXD], out_row0, dz_row0[TN_MAXD], dzh_row0, stash_rows;
 };

@@ -300,23 +300,54 @@ __device__ __forceinline__ void wgrad_x3_body(const float* __restrict__ stash, i
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(base), 0, (int)blk_bytes, 0x00020000);
         raw[set][k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, goff[k], (st & 1) * 64, 0));
     };
-    auto convert1 = [&](int st, auto setc, auto kc, auto guardc) TN_INLINE_LAMBDA {    // item k: register set -> image buffer st & 1 (+ bias row sums)
+    // Conversion of one item in six small steps (so that the hot loop can place one step behind every MFMA pair):
+    //   0, 3: r = x - trunc_bf16(x) for elements (0,1) / (2,3)     1, 4: s = r - trunc_bf16(r)     2, 5: pack the three pieces;
+    //   step 5 also forms the bias row sum and stores the pieces.
+    struct Item { f32x4 x; float r[4], t[4]; u32x2_t p1, p2, p3; };
+    auto conv_begin = [&](Item& it, int st, auto setc, auto kc, auto guardc) TN_INLINE_LAMBDA {
         constexpr int set = decltype(setc)::value, k = decltype(kc)::value;
-        constexpr bool GUARD = decltype(guardc)::value;
-        unsigned char* img = lds + (st & 1) * WX_IMG_BYTES;
-        f32x4 x = raw[set][k];
-        if constexpr (GUARD) {                                   // slots behind M were never written by the chain kernels
+        it.x = raw[set][k];
+        if constexpr (decltype(guardc)::value) {                 // slots behind M were never written by the chain kernels
             const int nvalid = (int)(M - (int64_t)(blk0 + (st >> 1)) * 32) - (st & 1) * 16;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) x[e] = 4 * chunk + e < nvalid ? x[e] : 0.0f;
+            for (int e = 0; e < 4; ++e) it.x[e] = 4 * chunk + e < nvalid ? it.x[e] : 0.0f;
         }
-        bs[k] += (x[0] + x[1]) + (x[2] + x[3]);
-        u32x2_t p1, p2, p3;
-        tn_split3x4(x, p1, p2, p3);
-        const uint32_t o = wx_img_off(0, crow[k], chunk >> 1) + (chunk & 1) * 8;
-        *reinterpret_cast<u32x2_t*>(img + o) = p1;
-        *reinterpret_cast<u32x2_t*>(img + o + 2 * WG_LDS_ROWS * 32) = p2;
-        *reinterpret_cast<u32x2_t*>(img + o + 2 * (2 * WG_LDS_ROWS * 32)) = p3;
+    };
+    auto conv_step = [&](Item& it, int st, auto kc, auto stepc) TN_INLINE_LAMBDA {
+        constexpr int k = decltype(kc)::value, step = decltype(stepc)::value;
+        constexpr int e = step / 3;                               // element pair
+        if constexpr (step % 3 == 0) {
+#ifndef WX_NO_SPLIT
+            it.r[2 * e] = it.x[2 * e] - __uint_as_float(__float_as_uint(it.x[2 * e]) & 0xFFFF0000u);
+            it.r[2 * e + 1] = it.x[2 * e + 1] - __uint_as_float(__float_as_uint(it.x[2 * e + 1]) & 0xFFFF0000u);
+#endif
+        } else if constexpr (step % 3 == 1) {
+#ifndef WX_NO_SPLIT
+            it.t[2 * e] = it.r[2 * e] - __uint_as_float(__float_as_uint(it.r[2 * e]) & 0xFFFF0000u);
+            it.t[2 * e + 1] = it.r[2 * e + 1] - __uint_as_float(__float_as_uint(it.r[2 * e + 1]) & 0xFFFF0000u);
+#endif
+        } else {
+            it.p1[e] = __builtin_amdgcn_perm(__float_as_uint(it.x[2 * e + 1]), __float_as_uint(it.x[2 * e]), 0x07060302u);   // (hi16 of x1) : (hi16 of x0)
+#ifndef WX_NO_SPLIT
+            it.p2[e] = __builtin_amdgcn_perm(__float_as_uint(it.r[2 * e + 1]), __float_as_uint(it.r[2 * e]), 0x07060302u);
+            it.p3[e] = __builtin_amdgcn_perm(__float_as_uint(it.t[2 * e + 1]), __float_as_uint(it.t[2 * e]), 0x07060302u);   // <= 8 significant bits left: exact
+#else
+            it.p2[e] = it.p1[e]; it.p3[e] = it.p1[e];
+#endif
+            if constexpr (step == 5) {
+                bs[k] += (it.x[0] + it.x[1]) + (it.x[2] + it.x[3]);
+                unsigned char* img = lds + (st & 1) * WX_IMG_BYTES;
+                const uint32_t o = wx_img_off(0, crow[k], chunk >> 1) + (chunk & 1) * 8;
+                *reinterpret_cast<u32x2_t*>(img + o) = it.p1;
+                *reinterpret_cast<u32x2_t*>(img + o + 2 * WG_LDS_ROWS * 32) = it.p2;
+                *reinterpret_cast<u32x2_t*>(img + o + 2 * (2 * WG_LDS_ROWS * 32)) = it.p3;
+            }
+        }
+    };
+    auto convert1 = [&](int st, auto setc, auto kc, auto guardc) TN_INLINE_LAMBDA {    // a whole item at once (prologue)
+        Item it;
+        conv_begin(it, st, setc, kc, guardc);
+        tn_static_for<6>([&](auto sc) TN_INLINE_LAMBDA { conv_step(it, st, kc, sc); });
     };
     const int frow = lane & 31, fh = lane >> 5;
     const bool active = (a_t0 < n_at) && (b_t0 < n_bt);
@@ -346,51 +377,58 @@ __device__ __forceinline__ void wgrad_x3_body(const float* __restrict__ stash, i
                 a3[i] = *reinterpret_cast<const bf16x8_t*>(img + oa[i] + 2 * PS);
             }
         }
+        // Group j: the 6 TA MFMAs of B tile j, with the conversion of items j (4/TB) .. of stage s+1 cut into six steps, one
+        // behind every TA MFMAs; the order is pinned (left alone, the scheduler emits the MFMAs back to back and the whole
+        // conversion after them, in the shadow of the last one only).
+        constexpr int IPG = 4 / TB;                                  // items per group
+        bf16x8_t b1, b2, b3;
+        if constexpr (ACTIVE) {
+            b1 = *reinterpret_cast<const bf16x8_t*>(img + ob[0]);
+            b2 = *reinterpret_cast<const bf16x8_t*>(img + ob[0] + PS);
+            b3 = *reinterpret_cast<const bf16x8_t*>(img + ob[0] + 2 * PS);
+        }
         tn_static_for<TB>([&](auto jc) TN_INLINE_LAMBDA {
             constexpr int j = decltype(jc)::value;
+            Item it[IPG];
 #ifndef WX_NO_CONVERT    // diagnostic build: MFMA phase only
-            tn_static_for<4 / TB>([&](auto qc) TN_INLINE_LAMBDA {
-                constexpr int k = j * (4 / TB) + decltype(qc)::value;
-                using KC = std::integral_constant<int, k>;
-                if (conv) convert1(s + 1, SetC{}, KC{}, guardc);
-                if (fill) fetch1(s + 1 + PD, SetC{}, KC{});
+            if (conv) tn_static_for<IPG>([&](auto qc) TN_INLINE_LAMBDA {
+                conv_begin(it[decltype(qc)::value], s + 1, SetC{}, std::integral_constant<int, j * IPG + decltype(qc)::value>{}, guardc);
             });
 #endif
-            if constexpr (ACTIVE) {
-                const bf16x8_t b1 = *reinterpret_cast<const bf16x8_t*>(img + ob[j]);
-                const bf16x8_t b2 = *reinterpret_cast<const bf16x8_t*>(img + ob[j] + PS);
-                const bf16x8_t b3 = *reinterpret_cast<const bf16x8_t*>(img + ob[j] + 2 * PS);
-                // six exact partial products per (i, j), small terms first; term outermost so that consecutive MFMAs go to
-                // different accumulators
-#ifndef WX_ONE_MFMA      // diagnostic build: only the leading product
-#pragma unroll
-                for (int i = 0; i < TA; ++i) acc[i][j] = TN_MFMA16(a3[i], b1, acc[i][j]);
-#pragma unroll
-                for (int i = 0; i < TA; ++i) acc[i][j] = TN_MFMA16(a2[i], b2, acc[i][j]);
-#pragma unroll
-                for (int i = 0; i < TA; ++i) acc[i][j] = TN_MFMA16(a1[i], b3, acc[i][j]);
-#pragma unroll
-                for (int i = 0; i < TA; ++i) acc[i][j] = TN_MFMA16(a2[i], b1, acc[i][j]);
-#pragma unroll
-                for (int i = 0; i < TA; ++i) acc[i][j] = TN_MFMA16(a1[i], b2, acc[i][j]);
+            tn_static_for<6>([&](auto tc) TN_INLINE_LAMBDA {
+                constexpr int term = decltype(tc)::value;           // small terms first: a3 b1, a2 b2, a1 b3, a2 b1, a1 b2, a1 b1
+                if constexpr (ACTIVE) {
+#ifdef WX_ONE_MFMA       // diagnostic build: only the leading product
+                    if constexpr (term == 5)
 #endif
 #pragma unroll
-                for (int i = 0; i < TA; ++i) acc[i][j] = TN_MFMA16(a1[i], b1, acc[i][j]);
-#ifndef WX_NO_SGB
-                // Left alone, the scheduler emits the 6 TA MFMAs of a group back to back and the conversion of one item (22 VALU,
-                // 3 LDS writes, 1 buffer load) after them — in the shadow of the LAST MFMA only.  Pin "one MFMA, two VALU".
-                if constexpr (TA * 6 >= 12 && !GUARD) {
-#pragma unroll
-                    for (int m = 0; m < 6 * TA; ++m) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // 1 MFMA
-                        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);       // 2 VALU
+                    for (int i = 0; i < TA; ++i) {
+                        const bf16x8_t& av = (term == 0) ? a3[i] : ((term == 1 || term == 3) ? a2[i] : a1[i]);
+                        const bf16x8_t& bv = (term == 2) ? b3 : ((term == 1 || term == 4) ? b2 : b1);
+                        acc[i][j] = TN_MFMA16(av, bv, acc[i][j]);
                     }
-                    __builtin_amdgcn_sched_group_barrier(0x200, 3, 0);           // the item's 3 LDS writes
-                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);           // its re-fill load
-                    __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);           // the next group's B fragments
                 }
+#ifndef WX_NO_CONVERT
+                if (conv) tn_static_for<IPG>([&](auto qc) TN_INLINE_LAMBDA {
+                    conv_step(it[decltype(qc)::value], s + 1, std::integral_constant<int, j * IPG + decltype(qc)::value>{}, tc);
+                });
 #endif
-            }
+                if constexpr (term == 5) {
+#ifndef WX_NO_CONVERT
+                    if (fill) tn_static_for<IPG>([&](auto qc) TN_INLINE_LAMBDA {
+                        fetch1(s + 1 + PD, SetC{}, std::integral_constant<int, j * IPG + decltype(qc)::value>{});
+                    });
+#endif
+                    if constexpr (ACTIVE && j + 1 < TB) {            // the next group's B fragments
+                        b1 = *reinterpret_cast<const bf16x8_t*>(img + ob[j + 1]);
+                        b2 = *reinterpret_cast<const bf16x8_t*>(img + ob[j + 1] + PS);
+                        b3 = *reinterpret_cast<const bf16x8_t*>(img + ob[j + 1] + 2 * PS);
+                    }
+                }
+#ifndef WX_NO_PIN
+                if constexpr (!GUARD) __builtin_amdgcn_sched_barrier(0);
+#endif
+            });
         });
     };
 
@@ -485,6 +523,7 @@ __global__ __launch_bounds__(512, 2) void k_wgrad(const float* __restrict__ stas
         const unsigned long long dt = __builtin_amdgcn_s_memtime() - t_start;
         int32_t* rec = const_cast<int32_t*>(jobs) + (int64_t)blockIdx.x * TN_JOB_INTS;
         rec[14] = (int32_t)(dt & 0xffffffffu); rec[15] = (int32_t)(dt >> 32);
+        rec[12] = (int32_t)(t_start & 0xffffffffu); rec[13] = (int32_t)(t_start >> 32);
     }
 #endif
 }

@@ -22,7 +22,7 @@ for (L_, hidden, depth, skip, R, S) in ((6, 256, 8, 4, 4096, 64), (10, 128, 4, 2
     tgt = torch.rand(R, 3, device=dev); t = torch.rand(R, S, device=dev)
     b = st.repack_bf16(); bp = b.train_plan(R, S)
     ztab = ops.depth_table(2.0, 6.0, S, dev)
-    comp = torch.empty(R, 3, device=dev); gws = torch.empty(R, 3, device=dev); loss = torch.zeros(1, device=dev)
+    comp = torch.empty(R, 3, device=dev); gws = torch.empty(R, 4, device=dev); loss = torch.zeros(1, device=dev)
     s_ = torch.cuda.current_stream(dev).cuda_stream
     ref = None; bad = 0
     for i in range(N):
