@@ -583,6 +583,11 @@ def test_hidden_widths_other_than_128_and_256(mods, dev, arch):
             ro, rd = O.pinhole_rays(H, W, focal, poses[s % N])
             lo_, _, grads = O.loss_and_grads(ps, skip, L, ro[pix], rd[pix], pixs[s % N, pix], 2.0, 6.0, S, u)
             assert math.isclose(float(loss), float(lo_), rel_tol=3e-4 if prec == "fp32" else 3e-2), (prec, s, float(loss), float(lo_))
+            if s == 0:                                                     # identical weights on both sides: the gradient itself
+                go_ = torch.cat([x.reshape(-1) for x in grads])
+                assert relmax(m.hip_state().grad.cpu(), go_) <= (1e-3 if prec == "fp32" else 6e-2), (prec, relmax(m.hip_state().grad.cpu(), go_))
             adam.step(ps, grads)
         err = max(float((p.detach().cpu() - q).abs().max()) for p, q in zip(m.parameters(), ps))
-        assert err <= (5e-5 if prec == "fp32" else 2e-3), (prec, err)      # bf16: 3 Adam steps of lr 5e-4 may flip the sign of tiny gradients
+        # Adam's first steps move every weight by ~lr * g / (|g| + eps): units of these narrow random-init nets that are (almost)
+        # dead have |g| ~ eps = 1e-8, where fp32 noise in g changes the update by a fraction of lr = 5e-4
+        assert err <= (2.5e-4 if prec == "fp32" else 2e-3), (prec, err)
