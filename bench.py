@@ -384,6 +384,15 @@ def run(args):
         fl["wgrad_fp32_mfma"] = fl["wgrad"]
         out["kernels"] = {k: {"ms": kern[k], "tflops": (fl[k] / (kern[k] * 1e-3) / 1e12) if k in fl else None,
                               "mfma_frac": (fl[k] / (kern[k] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS) if k in fl else None} for k in kern}
+        # the weight-gradient kernel runs its products on the bf16 matrix pipe (exact 3-way split): it is HBM-bound — its own roofline
+        m_ = RAYS * SAMPLES
+        wg_bytes = m_ * 4 * ((HIDDEN + 64) * 2 + (DEPTH - 1) * 2 * HIDDEN + 32 + HIDDEN)        # every job class reads its A and B rows of the stash once
+        for k_ in ("wgrad", "wgrad_fp32_mfma"):
+            out["kernels"][k_].update(algorithmic_hbm_bytes=wg_bytes, hbm_gbs=wg_bytes / (kern[k_] * 1e-3) / 1e9,
+                                      hbm_frac=wg_bytes / (kern[k_] * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                                      traffic=cap[k_]["hbm_bytes"] if cap and k_ in cap else None)
+        out["kernels"]["wgrad"]["matrix_pipe"] = "bf16 MFMA, fp32 operands split exactly in three (6 of 9 partial products), fp32 accumulate"
+        out["kernels"]["wgrad_fp32_mfma"]["matrix_pipe"] = "fp32 MFMA (TNERF_FLAG_FP32_MFMA)"
         if args.scaling == "weak" or world == 1:
             step_flops = sum(fl[k] for k in step_kernels)
             out["step_mfma_frac"] = step_flops / (ms_per_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS

@@ -12,7 +12,9 @@
  *   - return int: 0 = ok, <0 = TNERF_E* (bad argument), >0 = hipError_t of a failed HIP call.
  *     tnerf_last_error_string() gives a thread-local description.  Nothing throws across the ABI.
  *   - the CALLER owns all memory (outputs, stashes, workspaces, tables); the library never
- *     allocates or frees device memory and keeps no mutable global state.
+ *     allocates or frees device memory.  Process-wide state is limited to values that are written once and never
+ *     change: per-device kernel facts (CU count, granted dynamic-LDS size; atomics indexed by device) and the dlopen'ed
+ *     RCCL function table (std::call_once).
  *   - every device entry point is asynchronous on the given stream (hipStream_t passed as void*)
  *     and performs no host synchronisation, so it can be captured into a hipGraph.
  *   - all tensors are contiguous fp32 unless stated; index tensors are int64.
@@ -38,7 +40,8 @@ typedef void* tnerf_stream_t;    /* hipStream_t */
 
 /* TinyNeRF(in_dim, hidden, depth, skip_at)                       [src/nerf.py:10-27]
  * skip_at: the input is concatenated after layer index skip_at-1 (cat([h, x]), nerf.py:37-38);
- * 1 <= skip_at <= depth-1, or 0 for "no skip".  hidden must be 128 or 256; in_dim <= 64. */
+ * 1 <= skip_at <= depth-1, or 0 for "no skip".  1 <= hidden <= 256 (widths other than 128 / 256 run zero-padded on the
+ * 128- / 256-wide kernels: the host tables embed the model, the padding units stay exactly 0); in_dim <= 64. */
 typedef struct tnerf_mlp_desc {
     int32_t in_dim;
     int32_t hidden;
@@ -46,11 +49,13 @@ typedef struct tnerf_mlp_desc {
     int32_t skip_at;
     int32_t flags;           /* TNERF_FLAG_* (ABI 2); 0 = defaults                                */
 } tnerf_mlp_desc;
-/* How the fp32 kernels form their fp32 products.  Default (0): on the bf16 matrix pipe by EXACT three-way splitting —
- * an fp32 value is the sum of three bf16 numbers (8+8+8 mantissa bits), products of bf16 numbers are exact in fp32, six
- * v_mfma_f32_32x32x16_bf16 with fp32 accumulation carry a*b up to terms below 2^-24 |ab| — fp32-grade results (measured
- * against fp64: at least as accurate as an fp32 fma chain) at 6/16 of the fp32-MFMA time (CDNA4's bf16 matrix rate is 16x
- * its fp32 rate).  TNERF_FLAG_FP32_MFMA selects v_mfma_f32_32x32x2_f32 (plain fp32 fma chains) instead. */
+/* How the fp32 WEIGHT-GRADIENT kernel (tnerf_wgrad, inside tnerf_mlp_bwd / tnerf_train_*) forms its fp32 products.
+ * Default (0): on the bf16 matrix pipe by EXACT three-way splitting — an fp32 value is the sum of three bf16 numbers
+ * (8+8+8 mantissa bits), a product of two bf16 numbers is exact in fp32, six v_mfma_f32_32x32x16_bf16 with fp32
+ * accumulation carry a*b up to terms below 2^-24 |ab| — fp32-grade results (measured against fp64: at least as accurate
+ * as an fp32 fma chain) at 6/16 of the fp32-MFMA time (CDNA4's bf16 matrix rate is 16x its fp32 rate).
+ * TNERF_FLAG_FP32_MFMA selects v_mfma_f32_32x32x2_f32 (plain fp32 fma chains) instead.  The forward and dgrad chain
+ * kernels always use fp32 MFMA. */
 #define TNERF_FLAG_FP32_MFMA 1
 
 /* Sizes (in elements) of everything the caller must allocate for a model + sample count. */
