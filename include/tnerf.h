@@ -230,7 +230,10 @@ int tnerf_train_step_fused(const tnerf_mlp_desc* d, const float* packed,
                            float* comp_rgb, float* g_comp_ws, float* loss_out,
                            float* stash, int64_t stash_row_stride,
                            const int32_t* job_table, int64_t n_jobs, float* slabs,
-                           const int32_t* reduce_table, float* grads, tnerf_stream_t stream);
+                           const int32_t* reduce_table, float* grads,
+                           const void* packed_x3 /* NULL, or the record stream of tnerf_mlp_pack_x3: the forward then runs on the
+                                                    x3 chain kernel (unless TNERF_FLAG_FP32_MFMA) */,
+                           tnerf_stream_t stream);
 
 /* Camera-sourced rays: instead of gathering from the (N,HW,3) tables that the reference
  * precomputes with get_rays (src/train.py:94-101,110-112), ray r is generated inside the fused kernels from the
@@ -259,7 +262,7 @@ int tnerf_train_step_fused_cam(const tnerf_mlp_desc* d, const float* packed, con
                                float* comp_rgb, float* g_comp_ws, float* loss_out,
                                float* stash, int64_t stash_row_stride,
                                const int32_t* job_table, int64_t n_jobs, float* slabs,
-                               const int32_t* reduce_table, float* grads, tnerf_stream_t stream);
+                               const int32_t* reduce_table, float* grads, const void* packed_x3, tnerf_stream_t stream);
 
 /* -------------------------------------------------------------- the whole step on device-resident state */
 /* The body of the reference training loop (src/train.py:106-128) with NO per-step host input: which image (step % N,
@@ -310,6 +313,11 @@ typedef struct tnerf_step_args {
     const int32_t* scatter_table; /* [n_params, scatter_width]: positions of parameter i in `packed` (-1 terminated),
                                      the inverse of the pack table; NULL = do not re-pack                            */
     int32_t scatter_width;
+    /* fp32 only: the x3 record stream (tnerf_mlp_pack_x3) — the forward then runs on the x3 chain kernel — and the inverse of
+     * its pack table so that the finishing kernel keeps it current.  NULL = fp32-MFMA forward.                       */
+    const void* packed_x3;
+    const int32_t* scatter_x3;
+    int32_t scatter_x3_width;
 } tnerf_step_args;
 int tnerf_train_step_dataset(const tnerf_step_args* args, tnerf_stream_t stream);
 
@@ -403,6 +411,35 @@ int tnerf_train_step_fused_cam_bf16(const tnerf_mlp_desc* d, const void* packed1
                                     float* comp_rgb, float* g_comp_ws, float* loss_out, void* stash16,
                                     const int32_t* job_table, int64_t n_jobs, float* slabs,
                                     const int32_t* reduce_table, float* grads, tnerf_stream_t stream);
+
+/* ------------------------------------------------------- fp32 chain on the bf16 matrix pipe ("x3", exact) */
+/* The fused fp32 paths with the MLP's fp32 products formed EXACTLY on the bf16 matrix pipe: weights and activations are
+ * split into three bf16 pieces each (8+8+8 mantissa bits, every cut exact; see TNERF_FLAG_FP32_MFMA above), six
+ * v_mfma_f32_32x32x16_bf16 with fp32 accumulation per k-step.  Inputs, outputs, sample bins, encoder, compositing, and the
+ * training stash are those of tnerf_render_fused / tnerf_train_fwd_fused: fp32 results to fp32 accuracy.  Requires
+ * in_dim = 6L+3.  packed3: the record stream of tnerf_mlp_pack_x3 (sizes / table: tnerf_x3_plan_sizes, tnerf_x3_pack_table;
+ * tnerf_bf16_sizes is reused: n_fragments = n_fwd_fragments = 1 KB fragments of the stream). */
+int tnerf_x3_plan_sizes(const tnerf_mlp_desc* d, tnerf_bf16_sizes* out);                     /* HOST */
+int tnerf_x3_pack_table(const tnerf_mlp_desc* d, int32_t* table);                           /* HOST: table[pack_entries] */
+int tnerf_mlp_pack_x3(const tnerf_mlp_desc* d, const float* params, const int32_t* table, void* packed3,
+                      tnerf_stream_t stream);
+int tnerf_render_fused_x3(const tnerf_mlp_desc* d, const void* packed3,
+                          const float* rays_o, const float* rays_d, int64_t n_rays, int32_t n_samples,
+                          const float* ztab, int32_t randomized, const float* t_rand,
+                          uint64_t seed, uint64_t offset, int32_t white_bkgd,
+                          float* comp_rgb, float* depth, float* acc, tnerf_stream_t stream);
+int tnerf_render_fused_cam_x3(const tnerf_mlp_desc* d, const void* packed3, const tnerf_camera* cam,
+                              int64_t n_rays, int32_t n_samples,
+                              const float* ztab, int32_t randomized, const float* t_rand,
+                              uint64_t seed, uint64_t offset, int32_t white_bkgd,
+                              float* comp_rgb, float* depth, float* acc, tnerf_stream_t stream);
+/* Training forward: comp_rgb + the fp32 stash of tnerf_train_fwd_fused (same layout: the dgrad / weight-gradient entry
+ * points consume it unchanged). */
+int tnerf_train_fwd_fused_x3(const tnerf_mlp_desc* d, const void* packed3,
+                             const float* rays_o, const float* rays_d, int64_t n_rays, int32_t n_samples,
+                             const float* ztab, int32_t randomized, const float* t_rand,
+                             uint64_t seed, uint64_t offset, int32_t white_bkgd,
+                             float* comp_rgb, float* stash, int64_t stash_row_stride, tnerf_stream_t stream);
 
 /* torch.optim.Adam(lr, betas, eps, weight_decay=0) on the flat buffers   [src/train.py:80,127]
  * step = 1-based step count t used for the bias corrections; grad_scale multiplies the gradient

@@ -672,3 +672,75 @@ extern "C" int tnerf_bf16_train_fill(const tnerf_mlp_desc* d, int64_t n_rays, in
     }
     return TNERF_OK;
 }
+
+// ------------------------------------------------------------------------------------ x3 chain (tnerf_internal.h, NetX3)
+extern "C" int tn_build_netx3(const tnerf_mlp_desc* d, NetX3* n) {
+    int rc = check_desc(d); if (rc) return rc;
+    if (d->in_dim < 9 || (d->in_dim - 3) % 6 != 0) {
+        tn_set_error("x3 chain: only the fused paths are built and they need in_dim = 6L+3; got %d", d->in_dim);
+        return TNERF_EUNSUPPORTED;
+    }
+    memset(n, 0, sizeof(*n));
+    const int H = d->hidden <= 128 ? 128 : 256;                            // the kernel width (zero-padded weights, see check_desc)
+    n->in_dim = d->in_dim; n->hidden = H; n->depth = d->depth; n->skip_at = d->skip_at; n->Lf = (d->in_dim - 3) / 6;
+    n->NT = H / 32; n->KH = H / 16; n->rec_frags = n->NT * 3;
+    int rec = TN16_KE;
+    for (int l = 1; l < d->depth; ++l) rec += n->KH + ((d->skip_at > 0 && l == d->skip_at) ? TN16_KE : 0);
+    rec += n->KH;                                                           // heads
+    if ((rec * n->rec_frags) % TX_STAGE != 0) { tn_set_error("x3 chain: the record stream is not a whole number of stages"); return TNERF_EUNSUPPORTED; }
+    n->n_rec = rec; n->n_stage = rec * n->rec_frags / TX_STAGE;
+    n->bias_off = rec * n->rec_frags * 1024;
+    n->n_bias = d->depth * H + 4;
+    n->packed_bytes = (int64_t)n->bias_off + (int64_t)n->n_bias * 4;
+    n->pack_entries = (int64_t)rec * n->rec_frags * 512 + n->n_bias;
+    return TNERF_OK;
+}
+
+extern "C" int tnerf_x3_plan_sizes(const tnerf_mlp_desc* d, tnerf_bf16_sizes* out) {
+    NetX3 n; int rc = tn_build_netx3(d, &n); if (rc) return rc;
+    if (!out) { tn_set_error("tnerf_x3_plan_sizes: NULL output"); return TNERF_EINVAL; }
+    out->packed_bytes = n.packed_bytes; out->pack_entries = n.pack_entries;
+    out->n_fragments = (int64_t)n.n_rec * n.rec_frags; out->bias_offset_bytes = n.bias_off;
+    out->n_fwd_fragments = out->n_fragments;
+    return TNERF_OK;
+}
+
+extern "C" int tnerf_x3_pack_table(const tnerf_mlp_desc* d, int32_t* T) {
+    NetX3 n; int rc = tn_build_netx3(d, &n); if (rc) return rc;
+    MlpLayout L; rc = tn_build_layout(d, &L); if (rc) return rc;
+    if (!T) { tn_set_error("tnerf_x3_pack_table: NULL table"); return TNERF_EINVAL; }
+    for (int64_t i = 0; i < n.pack_entries; ++i) T[i] = -1;
+    const int H = L.hidden, NT = n.NT, KH = n.KH, Lf = n.Lf;
+    int64_t rec = 0;                                                        // running record index
+    // all three piece fragments of (record, tile t) refer to the same parameters: the pack kernel derives the piece from the
+    // fragment's position (fragment index mod 3)
+    auto put = [&](int t, int lane, int e, int64_t src) {
+        for (int piece = 0; piece < 3; ++piece) T[(((rec * NT + t) * 3 + piece) * 64 + lane) * 8 + e] = (int32_t)src;
+    };
+    auto head_w = [&](int row, int k) -> int64_t { return row < 3 ? L.p_wc + (int64_t)row * H + k : (row == 3 ? L.p_ws + k : -1); };
+    for (int l = 0; l < L.depth; ++l) {
+        const int fan = L.fan_in[l];
+        const bool skip = L.skip_at > 0 && l == L.skip_at;
+        if (l > 0)
+            for (int s = 0; s < KH; ++s, ++rec)
+                for (int t = 0; t < NT; ++t) for (int lane = 0; lane < 64; ++lane) for (int e = 0; e < 8; ++e)
+                    put(t, lane, e, L.p_w[l] + (int64_t)(32 * t + (lane & 31)) * fan + hid_feature16(s, lane >> 5, e));
+        if (l == 0 || skip)
+            for (int u = 0; u < TN16_KE; ++u, ++rec)
+                for (int t = 0; t < NT; ++t) for (int lane = 0; lane < 64; ++lane) for (int e = 0; e < 8; ++e) {
+                    const int c = enc_column16(Lf, u, lane >> 5, e);
+                    if (c >= 0) put(t, lane, e, L.p_w[l] + (int64_t)(32 * t + (lane & 31)) * fan + (l == 0 ? 0 : H) + c);
+                }
+    }
+    for (int s = 0; s < KH; ++s, ++rec)                                     // heads: tile 0 rows r,g,b (rgb.0), sigma.0
+        for (int lane = 0; lane < 64; ++lane) for (int e = 0; e < 8; ++e) {
+            const int64_t src = head_w(lane & 31, hid_feature16(s, lane >> 5, e));
+            if (src >= 0) put(0, lane, e, src);
+        }
+    int32_t* B = T + (int64_t)n.n_rec * n.rec_frags * 512;
+    for (int l = 0; l < L.depth; ++l) for (int j = 0; j < H; ++j) B[l * H + j] = (int32_t)(L.p_b[l] + j);
+    for (int j = 0; j < 3; ++j) B[L.depth * H + j] = (int32_t)(L.p_bc + j);
+    B[L.depth * H + 3] = (int32_t)L.p_bs;
+    remap_sources(L, T, n.pack_entries);
+    return TNERF_OK;
+}

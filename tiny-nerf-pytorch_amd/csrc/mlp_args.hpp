@@ -45,10 +45,14 @@ int tn_launch_wgrad(const float* stash, int64_t stash_rows, int64_t M, const int
 int tn_launch_reduce(const float* slabs, const int32_t* reduce_table, int64_t n_params, float* grads, hipStream_t stream);
 // Dataset mode: the device step counter and the Philox counters consumed per step (zero = per-call mode)
 struct TnStepRef { int64_t* step; uint64_t per_step; };
-int tn_step32_core(const char* who, const tnerf_mlp_desc* d, const float* packed, const RaySource& rs, const TnStepRef& sr,
+// packed3 != NULL (and not TNERF_FLAG_FP32_MFMA): the forward runs on the x3 chain kernel (mlpx3.hip), same stash
+int tn_step32_core(const char* who, const tnerf_mlp_desc* d, const float* packed, const void* packed3, const RaySource& rs, const TnStepRef& sr,
                    const LossArgs& loss, int64_t R, int32_t S, const float* ztab, int32_t randomized, const float* t_rand,
                    uint64_t seed, uint64_t offset, int32_t white, float* comp_rgb, float* stash, int64_t Mp,
                    const int32_t* job_table, int64_t n_jobs, float* slabs, hipStream_t stream);
+int tnx3_train_fwd(const char* who, const tnerf_mlp_desc* d, const void* packed3, const RaySource& rs, const TnStepRef& sr,
+                   const LossArgs& loss, int64_t R, int32_t S, const float* ztab, int32_t randomized, const float* t_rand,
+                   uint64_t seed, uint64_t offset, int32_t white, float* comp, float* stash, int64_t Mp, hipStream_t stream);
 // The finishing kernel of a step: [slab reduction -> grads] [+ loss = inv_denom * sum ray_ws[.,3]] [+ Adam + re-pack of the updated weights]
 struct FinishArgs {
     // reduce (slabs == NULL: grads already hold the gradient, e.g. after the all-reduce)
@@ -61,5 +65,7 @@ struct FinishArgs {
     // re-pack: parameter i goes to packed position scatter[i * width + k] (< 0: none); positions < bf16_elems are bf16
     // elements of the fragment stream, the rest fp32 (biases) counted from bias_base
     const int32_t* scatter; int32_t width; void* packed; int64_t bf16_elems; int64_t bias_off_bytes;
+    // second re-pack target: the x3 record stream (element i carries piece (i >> 9) mod 3 of its parameter; biases behind x3_elems)
+    const int32_t* scatter3; int32_t width3; void* packed3; int64_t x3_elems; int64_t x3_bias_off_bytes;
 };
 int tn_launch_finish(const FinishArgs& f, hipStream_t stream);

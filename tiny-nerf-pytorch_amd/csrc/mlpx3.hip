@@ -1,0 +1,260 @@
+// "x3" chain kernels: the fused ray -> sample -> encode -> MLP -> composite path (reference src/train.py:46-56, :114-121)
+// with the MLP's fp32 products formed exactly on the bf16 matrix pipe (mlpx3_core.hpp).  Same inputs, outputs, sample bins,
+// encoder arithmetic (fp32-accurate sin/cos), compositing and — when training — the same block-major fp32 stash (activations,
+// ReLU sign bits, head outputs, loss gradient) as the fp32-MFMA kernels of mlp_fwd.hip, so the dgrad / weight-gradient kernels
+// and every caller are unchanged.  One persistent 256-thread workgroup per CU (4 waves = one per SIMD, 512-register budget);
+// a wave owns one ray at a time and marches it 32 samples per pass over the record stream.
+#include "mlpx3_core.hpp"
+#include "mlp_args.hpp"
+
+struct FwdX3Args {
+    FwdArgs f;                      // layout (stash rows), ray source, sampling, outputs, stash, loss — as the fp32 kernels
+    NetX3 n;
+    const unsigned char* packed3;   // record stream + biases (tnerf_mlp_pack_x3)
+};
+
+// The network for one 32-sample tile.  m: this lane's sample index in the stash (valid if `valid`).  res[4]: r,g,b after
+// sigmoid, sigma after ReLU (lane-half 0).
+template <int HID, bool TRAIN>
+__device__ __forceinline__ void tx_mlp_tile(PipeX& p, const unsigned char* lds, const FwdX3Args& a, int h, int lane, const EncX& E,
+                                            const float (&encf)[8 * TN16_KE], int64_t m, bool valid, float (&res)[4]) {
+    constexpr int NT = HID / 32;
+    constexpr int ST = 0;                                          // stores allowed outstanding at a stage boundary
+    const MlpLayout& L = a.f.L;
+    const int depth = a.n.depth, skip_at = a.n.skip_at;
+    const uint32_t vb0 = TX_RING + 16u * h;                        // + layer * HID * 4
+    float* __restrict__ stash = a.f.stash;
+    const int64_t Mp = a.f.Mp;
+    const int64_t ms = valid ? m : Mp + (lane & 31);               // padding lanes write to the dump block: stores need no branch
+    float* __restrict__ pl = TRAIN ? tn_stash_at(stash, L.stash_rows, ms) + 4 * h * 32 : nullptr;      // per-lane: (row 4h, sample ms)
+    uint32_t* __restrict__ mrow = TRAIN ? reinterpret_cast<uint32_t*>(stash + TN_STASH_BODY_FLOATS(L, Mp)) + (2 * ms + h) * (NT / 2) : nullptr;
+    if constexpr (TRAIN) {                                         // the network input rows of the stash (the fp32 path's pairing: step st = 8u + e)
+        tn_static_for<8 * TN16_KE>([&](auto sc) TN_INLINE_LAMBDA {
+            constexpr int st = decltype(sc)::value;
+            if (st < L.NE) TN_STASH_STORE(&pl[(L.enc_row0 + 2 * st - 3 * h) * 32], encf[st]);
+        });
+    }
+    ActX<HID> X;
+    f32x16 acc[NT];
+    uint32_t mb[NT / 2];
+    auto fin_layer = [&](int l) TN_INLINE_LAMBDA {
+        float* __restrict__ srow = TRAIN ? pl + L.h_row0[l] * 32 : nullptr;
+        tx_layer_epilogue<HID>(lds, vb0 + l * HID * 4, acc, X, [&](auto tc, const float (&v)[16]) TN_INLINE_LAMBDA {
+            constexpr int t = decltype(tc)::value;
+            if constexpr (TRAIN) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) TN_STASH_STORE(&srow[(32 * t + (r & 3) + 8 * (r >> 2)) * 32], v[r]);
+                uint32_t msk = 0u;
+#pragma unroll
+                for (int r = 15; r >= 0; --r) msk = __builtin_amdgcn_alignbit(msk, __float_as_uint(v[r]) + 0x7FFFFFFFu, 31);
+                if constexpr ((t & 1) == 0) mb[t / 2] = msk; else mb[t / 2] |= msk << 16;
+            }
+        });
+        if constexpr (TRAIN) {
+#pragma unroll
+            for (int w = 0; w < NT / 2; ++w) mrow[(int64_t)l * (Mp + 32) * NT + w] = mb[w];
+        }
+    };
+    tx_layer_mfma<HID, 0, ST>(p, lds, X, E, acc);
+    fin_layer(0);
+    for (int l = 1; l < depth; ++l) {
+        if (l == skip_at) tx_layer_mfma<HID, 2, ST>(p, lds, X, E, acc);
+        else              tx_layer_mfma<HID, 1, ST>(p, lds, X, E, acc);
+        fin_layer(l);
+    }
+    tx_layer_mfma<HID, 3, ST>(p, lds, X, E, acc);
+    // heads: rows 0..2 = rgb.0 (sigmoid), row 3 = sigma.0 (ReLU)                                   nerf.py:39-40
+    const f32x4 hb = *reinterpret_cast<const f32x4*>(lds + TX_RING + depth * HID * 4);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) res[i] = 1.0f / (1.0f + expf(-(acc[0][i] + hb[i])));
+    res[3] = fmaxf(acc[0][3] + hb[3], 0.0f);
+}
+
+template <int HID, bool TRAIN>
+__global__ __launch_bounds__(256, 1) void k_renderx3(FwdX3Args a) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    const int lane = tn_lane();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int j = lane & 31, h = lane >> 5;
+    RaySource rs = a.f.rs; SampleArgs sa = a.f.sa;
+    if (TRAIN) tn_resolve_step(rs, sa);                            // dataset mode: this step's image and Philox counters
+    const int S = sa.S, Lf = a.n.Lf;
+    PipeX p;
+    tx_prologue(p, lds, a.packed3, a.n, lane, wave);
+
+    // Every wave of the workgroup runs the same number of network passes (the stage barriers are workgroup-wide): rays beyond
+    // R are computed on a clamped index and stored nowhere (training: into the dump block).
+    const int64_t R = a.f.R;
+    const int64_t n_groups = (R + 3) / 4;
+    for (int64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
+        const int64_t ray = g * 4 + wave;
+        const bool rvalid = ray < R;
+        const int64_t rayc = rvalid ? ray : R - 1;
+        float ro_[3], rd_[3];
+        tn_fetch_ray(rs, rayc, ro_, rd_);
+        const float ox = ro_[0], oy = ro_[1], oz = ro_[2], dx = rd_[0], dy = rd_[1], dz = rd_[2];
+        const float dn = tn_norm3(dx, dy, dz);
+        float T_in = 1.0f, cr = 0.f, cg = 0.f, cb = 0.f, cd = 0.f, ca = 0.f;
+        // March the ray 32 samples per pass; every second pass (or the last one) the 64 lanes composite a segment: lane l <- sample s0 + l.
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int sb = 0; sb < S; sb += 32) {
+            {
+                const int s = sb + j;
+                const bool valid = rvalid && s < S;
+                const int sc = s < S ? s : S - 1;
+                const float z = tn_depth(sa, rayc, sc);
+                EncX E;
+                float encf[8 * TN16_KE];
+                tx_encode(tn_point(ox, dx, z), tn_point(oy, dy, z), tn_point(oz, dz, z), Lf, h, E,
+                          [&](auto stc, float val) TN_INLINE_LAMBDA { encf[decltype(stc)::value] = val; });
+                float res[4];
+                tx_mlp_tile<HID, TRAIN>(p, lds, a, h, lane, E, encf, rayc * S + sc, valid, res);
+                const bool upper = (sb & 32) != 0;                            // wave-uniform
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float mv = __shfl(res[i], lane & 31, 64);           // lanes 32..63 <- lanes 0..31
+                    v[i] = upper ? (h ? mv : v[i]) : res[i];
+                }
+            }
+            if ((sb & 32) == 0 && sb + 32 < S) continue;                      // wait for the upper half
+            const int s0 = sb & ~63;
+            const int s = s0 + lane;
+            const bool ok = s < S && (s - s0) < ((sb & 32) ? 64 : 32);
+            const int sc = s < S ? s : S - 1;
+            const float z = tn_depth(sa, rayc, sc);
+            const float zn = (s + 1 < S) ? tn_depth(sa, rayc, s + 1) : z;
+            const CompTerms t = tn_comp_terms(ok ? v[3] : 0.0f, z, zn, s == S - 1, dn);       // volume.py:18-31
+            const float om = ok ? t.om : 1.0f;
+            const float incl = tn_wave_scan_mul(om, lane);
+            float excl = __shfl_up(incl, 1, 64);
+            if (lane == 0) excl = 1.0f;
+            const float T = T_in * excl;
+            const float w = ok ? t.alpha * T : 0.0f;                                          // volume.py:34
+            cr += w * v[0]; cg += w * v[1]; cb += w * v[2]; cd += w * z; ca += w;             // volume.py:36-38
+            T_in *= __shfl(incl, 63, 64);
+            if (TRAIN && ok && rvalid) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) tn_stash_at(a.f.stash, a.f.L.stash_rows, rayc * S + s)[(a.f.L.out_row0 + i) * 32] = v[i];
+            }
+        }
+        cr = tn_wave_sum(cr); cg = tn_wave_sum(cg); cb = tn_wave_sum(cb); cd = tn_wave_sum(cd); ca = tn_wave_sum(ca);
+        if (lane == 0 && rvalid) {
+            const float bg = a.f.white ? (1.0f - ca) : 0.0f;                                  // volume.py:42
+            a.f.comp[3 * ray] = cr + bg; a.f.comp[3 * ray + 1] = cg + bg; a.f.comp[3 * ray + 2] = cb + bg;
+            if (a.f.depth) a.f.depth[ray] = cd;
+            if (a.f.acc) a.f.acc[ray] = ca;
+            if (TRAIN && a.f.loss.ray_ws) tn_ray_loss(a.f.loss, rs, ray, cr + bg, cg + bg, cb + bg);      // train.py:122
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // no DMA may still be writing this workgroup's LDS at exit
+}
+
+int tnx3_launch_fwd(const FwdX3Args& a, bool train, hipStream_t stream, const char* who) {
+    const int dev = tn_stream_device(stream), n_cu = tn_device_cus(dev);
+    const int64_t groups = (a.f.R + 3) / 4;
+    const dim3 grid((unsigned)(groups < n_cu ? groups : n_cu)), block(256);
+    const size_t lds_bytes = TX_RING + (size_t)((a.n.n_bias + 3) / 4 * 4) * 4;
+#define TX_CASE(H_, T_)                                                                                                      \
+    if (a.n.hidden == H_ && train == T_) {                                                                                    \
+        static std::atomic<uint32_t> seen_[TN_MAX_DEVICES];                                                                   \
+        if (int rc_ = tn_grant_dyn_lds(reinterpret_cast<const void*>(&k_renderx3<H_, T_>), lds_bytes, dev, seen_, who)) return rc_; \
+        hipLaunchKernelGGL((k_renderx3<H_, T_>), grid, block, lds_bytes, stream, a);                                          \
+        TN_HIP_CHECK_LAUNCH(who);                                                                                             \
+        return TNERF_OK;                                                                                                      \
+    }
+    TX_CASE(256, false) TX_CASE(256, true) TX_CASE(128, false) TX_CASE(128, true)
+#undef TX_CASE
+    tn_set_error("%s: no x3 kernel for hidden=%d", who, a.n.hidden);
+    return TNERF_EUNSUPPORTED;
+}
+
+// ----------------------------------------------------------------------------------- entry points
+static int x3_args(const char* who, FwdX3Args& a, const tnerf_mlp_desc* d, const void* packed3, const RaySource& rs, int64_t R, int32_t S,
+                   const float* ztab, int32_t randomized, const float* t_rand, uint64_t seed, uint64_t offset, int32_t white) {
+    int rc = tn_build_netx3(d, &a.n); if (rc) return rc;
+    // tn_fused_args validates the common arguments; the fp32 packed pointer is not used by these kernels
+    rc = tn_fused_args(who, a.f, d, reinterpret_cast<const float*>(packed3), rs, R, S, ztab, randomized, t_rand, seed, offset, white);
+    if (rc) return rc;
+    a.packed3 = static_cast<const unsigned char*>(packed3);
+    return TNERF_OK;
+}
+
+static int renderx3_impl(const char* who, const tnerf_mlp_desc* d, const void* packed3, const RaySource& rs, int64_t R, int32_t S,
+                         const float* ztab, int32_t randomized, const float* t_rand, uint64_t seed, uint64_t offset, int32_t white,
+                         float* comp, float* depth, float* acc, tnerf_stream_t stream) {
+    FwdX3Args a{};
+    int rc = x3_args(who, a, d, packed3, rs, R, S, ztab, randomized, t_rand, seed, offset, white); if (rc) return rc;
+    if (R == 0) return TNERF_OK;
+    if (!comp) { tn_set_error("%s: comp_rgb is NULL", who); return TNERF_EINVAL; }
+    a.f.comp = comp; a.f.depth = depth; a.f.acc = acc;
+    return tnx3_launch_fwd(a, false, (hipStream_t)stream, who);
+}
+
+extern "C" int tnerf_render_fused_x3(const tnerf_mlp_desc* d, const void* packed3, const float* rays_o, const float* rays_d,
+                                     int64_t R, int32_t S, const float* ztab, int32_t randomized, const float* t_rand,
+                                     uint64_t seed, uint64_t offset, int32_t white, float* comp, float* depth, float* acc,
+                                     tnerf_stream_t stream) {
+    return renderx3_impl("tnerf_render_fused_x3", d, packed3, tn_table_source(rays_o, rays_d), R, S, ztab, randomized, t_rand, seed,
+                         offset, white, comp, depth, acc, stream);
+}
+
+extern "C" int tnerf_render_fused_cam_x3(const tnerf_mlp_desc* d, const void* packed3, const tnerf_camera* cam, int64_t R, int32_t S,
+                                         const float* ztab, int32_t randomized, const float* t_rand, uint64_t seed, uint64_t offset,
+                                         int32_t white, float* comp, float* depth, float* acc, tnerf_stream_t stream) {
+    RaySource rs;
+    int rc = tn_camera_source("tnerf_render_fused_cam_x3", cam, R, &rs); if (rc) return rc;
+    return renderx3_impl("tnerf_render_fused_cam_x3", d, packed3, rs, R, S, ztab, randomized, t_rand, seed, offset, white, comp, depth,
+                         acc, stream);
+}
+
+// Training forward into the fp32 stash (tn_step32_core and tnerf_train_fwd_fused_x3 call this instead of the fp32-MFMA forward).
+int tnx3_train_fwd(const char* who, const tnerf_mlp_desc* d, const void* packed3, const RaySource& rs, const TnStepRef& sr,
+                   const LossArgs& loss, int64_t R, int32_t S, const float* ztab, int32_t randomized, const float* t_rand,
+                   uint64_t seed, uint64_t offset, int32_t white, float* comp, float* stash, int64_t Mp, hipStream_t stream) {
+    FwdX3Args a{};
+    int rc = x3_args(who, a, d, packed3, rs, R, S, ztab, randomized, t_rand, seed, offset, white); if (rc) return rc;
+    if (R < 1 || !comp || !stash || Mp < R * S) { tn_set_error("%s: comp=%p stash=%p Mp=%lld < R*S=%lld", who, (void*)comp, (void*)stash, (long long)Mp, (long long)(R * S)); return TNERF_EINVAL; }
+    a.f.comp = comp; a.f.stash = stash; a.f.Mp = Mp; a.f.loss = loss;
+    a.f.sa.step = sr.step; a.f.sa.per_step = sr.per_step;
+    return tnx3_launch_fwd(a, true, stream, who);
+}
+
+extern "C" int tnerf_train_fwd_fused_x3(const tnerf_mlp_desc* d, const void* packed3, const float* rays_o, const float* rays_d,
+                                        int64_t R, int32_t S, const float* ztab, int32_t randomized, const float* t_rand,
+                                        uint64_t seed, uint64_t offset, int32_t white, float* comp, float* stash, int64_t Mp,
+                                        tnerf_stream_t stream) {
+    return tnx3_train_fwd("tnerf_train_fwd_fused_x3", d, packed3, tn_table_source(rays_o, rays_d), TnStepRef{}, LossArgs{}, R, S, ztab,
+                          randomized, t_rand, seed, offset, white, comp, stash, Mp, (hipStream_t)stream);
+}
+
+// ----------------------------------------------------------------------------------- packing
+// stream element i (bf16) = piece ((i >> 9) mod 3) of params[table[i]]: p1 = trunc_bf16(x), p2 = trunc_bf16(x - p1),
+// p3 = x - p1 - p2 (exact); the entries behind the stream are the fp32 biases.
+__global__ __launch_bounds__(256) void k_packx3(const float* __restrict__ params, const int32_t* __restrict__ table, int64_t n_w,
+                                                int64_t n_all, unsigned short* __restrict__ out16, float* __restrict__ out32) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_all) return;
+    const int32_t s = table[i];
+    const float x = s >= 0 ? params[s] : 0.0f;
+    if (i >= n_w) { out32[i - n_w] = x; return; }
+    const int piece = (int)((i >> 9) % 3);
+    const float r = x - __uint_as_float(__float_as_uint(x) & 0xFFFF0000u);
+    const float t = r - __uint_as_float(__float_as_uint(r) & 0xFFFF0000u);
+    const float pv = piece == 0 ? x : (piece == 1 ? r : t);
+    out16[i] = (unsigned short)(__float_as_uint(pv) >> 16);
+}
+
+extern "C" int tnerf_mlp_pack_x3(const tnerf_mlp_desc* d, const float* params, const int32_t* table, void* packed3,
+                                 tnerf_stream_t stream) {
+    NetX3 n; int rc = tn_build_netx3(d, &n); if (rc) return rc;
+    if (!params || !table || !packed3) {
+        tn_set_error("tnerf_mlp_pack_x3: params=%p table=%p packed3=%p", (const void*)params, (const void*)table, packed3);
+        return TNERF_EINVAL;
+    }
+    const int64_t n_w = (int64_t)n.n_rec * n.rec_frags * 512;
+    hipLaunchKernelGGL(k_packx3, dim3((unsigned)((n.pack_entries + 255) / 256)), dim3(256), 0, (hipStream_t)stream, params, table, n_w,
+                       n.pack_entries, static_cast<unsigned short*>(packed3),
+                       reinterpret_cast<float*>(static_cast<unsigned char*>(packed3) + n.bias_off));
+    TN_HIP_CHECK_LAUNCH("tnerf_mlp_pack_x3");
+    return TNERF_OK;
+}

@@ -45,7 +45,7 @@ extern "C" int tnerf_train_step_dataset(const tnerf_step_args* a, tnerf_stream_t
         const LossArgs loss{a->pixels, nullptr, inv_denom, a->ray_ws, a->pix_out};
         const uint64_t off0 = (uint64_t)a->ray_first * (uint64_t)a->n_samples;         // + step * per_step in the kernels
         if (a->precision == 0)
-            rc = tn_step32_core("tnerf_train_step_dataset", &a->desc, static_cast<const float*>(a->packed), rs, sr, loss, a->n_rays, a->n_samples,
+            rc = tn_step32_core("tnerf_train_step_dataset", &a->desc, static_cast<const float*>(a->packed), a->packed_x3, rs, sr, loss, a->n_rays, a->n_samples,
                                 a->ztab, 1, nullptr, a->seed, off0, a->white_bkgd, a->comp_rgb, static_cast<float*>(a->stash), a->stash_row_stride,
                                 a->job_table, a->n_jobs, a->slabs, stream);
         else
@@ -67,6 +67,11 @@ extern "C" int tnerf_train_step_dataset(const tnerf_step_args* a, tnerf_stream_t
         if (a->precision == 1 && a->scatter_table) {
             Net16 n; if ((rc = tn_build_net16(&a->desc, &n))) return rc;
             f.bf16_elems = (int64_t)(n.n_frag + n.n_bw_frag) * 512; f.bias_off_bytes = n.bias_off;
+        }
+        if (a->precision == 0 && a->packed_x3 && a->scatter_x3) {
+            NetX3 n; if ((rc = tn_build_netx3(&a->desc, &n))) return rc;
+            f.scatter3 = a->scatter_x3; f.width3 = a->scatter_x3_width; f.packed3 = const_cast<void*>(a->packed_x3);
+            f.x3_elems = (int64_t)n.n_rec * n.rec_frags * 512; f.x3_bias_off_bytes = n.bias_off;
         }
     }
     return tn_launch_finish(f, stream);

@@ -77,9 +77,28 @@ struct Net16 {
 #define TN16_STASH_MASK_BYTES(n, tiles) ((int64_t)(n).depth * ((tiles) + 1) * 64 * ((n).hidden / 64) * 4)
 #define TN16_STASH_OUT_BYTES(n, tiles)  ((int64_t)((tiles) + 1) * 32 * 16)
 
+// "x3" chain kernels (mlpx3.hip): the fp32 MLP chain on the bf16 matrix pipe with exact three-way operand splitting
+// (DESIGN.md §13/§14).  The weights are a STREAM of k-step RECORDS in the order a wavefront consumes them; a record holds, for
+// every n-tile t, the three bf16 pieces W1, W2, W3 (W = W1 + W2 + W3 exactly) of the A fragment of (n-tile t, this k-step):
+//   record = [t = 0 .. NT-1][piece 0..2] x 1 KB,   fragment = lane (row l&31, half l>>5) x 8 bf16 (k-slots 8 (l>>5) + e)
+// Forward pass order: layer 0: TN16_KE input k-steps; layer l >= 1: hidden/16 hidden k-steps (+ TN16_KE input k-steps for the
+// skip layer); heads: hidden/16 k-steps whose records carry the head tile (rows r,g,b,sigma) at t = 0 and zeros elsewhere.
+// k-slot <-> feature maps as in the bf16 mode (above).  Records are cut into stages of TX_STAGE fragments (24 KB: one record of
+// a 256-wide net, two of a 128-wide one) for the LDS ring.  After the stream: the fp32 biases as in the bf16 mode.
+#define TX_STAGE 24
+struct NetX3 {
+    int32_t in_dim, hidden, depth, skip_at, Lf;
+    int32_t NT, KH;               // n-tiles (hidden/32), hidden k-steps (hidden/16)
+    int32_t rec_frags;            // NT * 3
+    int32_t n_rec, n_stage;       // forward stream, per pass
+    int32_t bias_off, n_bias;     // byte offset / count of the fp32 biases (depth*hidden + 4)
+    int64_t packed_bytes, pack_entries;     // pack_entries = n_rec * rec_frags * 512 + n_bias
+};
+
 #ifdef __cplusplus
 extern "C" {
 #endif
+int  tn_build_netx3(const tnerf_mlp_desc* d, NetX3* n);        // 0 or TNERF_E*
 // host_plan.cpp
 int  tn_build_layout(const tnerf_mlp_desc* d, MlpLayout* L);   // 0 or TNERF_E*
 int  tn_build_net16(const tnerf_mlp_desc* d, Net16* n);        // 0 or TNERF_E*

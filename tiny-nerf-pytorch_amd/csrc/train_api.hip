@@ -105,11 +105,15 @@ static int tn_train_fwd_impl(const char* who, const tnerf_mlp_desc* d, const flo
 
 // forward (+ loss gradient per ray) -> dgrad -> wgrad: the step up to the slabs.  Shared by the per-call entry points below
 // and by tnerf_train_step_dataset (step_api.hip).
-int tn_step32_core(const char* who, const tnerf_mlp_desc* d, const float* packed, const RaySource& rs, const TnStepRef& sr,
+int tn_step32_core(const char* who, const tnerf_mlp_desc* d, const float* packed, const void* packed3, const RaySource& rs, const TnStepRef& sr,
                    const LossArgs& loss, int64_t R, int32_t S, const float* ztab, int32_t randomized, const float* t_rand,
                    uint64_t seed, uint64_t offset, int32_t white, float* comp_rgb, float* stash, int64_t Mp,
                    const int32_t* job_table, int64_t n_jobs, float* slabs, hipStream_t stream) {
-    int rc = tn_train_fwd_impl(who, d, packed, rs, sr, loss, R, S, ztab, randomized, t_rand, seed, offset, white, comp_rgb, stash, Mp, stream);
+    int rc;
+    if (packed3 && !(d->flags & TNERF_FLAG_FP32_MFMA))
+        rc = tnx3_train_fwd(who, d, packed3, rs, sr, loss, R, S, ztab, randomized, t_rand, seed, offset, white, comp_rgb, stash, Mp, stream);
+    else
+        rc = tn_train_fwd_impl(who, d, packed, rs, sr, loss, R, S, ztab, randomized, t_rand, seed, offset, white, comp_rgb, stash, Mp, stream);
     if (rc) return rc;
     return train_bwd_impl(who, d, packed, rs, sr, R, S, ztab, randomized, t_rand, seed, offset, white, loss.ray_ws, 4, stash, Mp,
                           job_table, n_jobs, slabs, nullptr, nullptr, stream);
@@ -120,7 +124,7 @@ static int train_step_impl(const char* who, const tnerf_mlp_desc* d, const float
                            const float* t_rand, uint64_t seed, uint64_t offset, int32_t white, double loss_denominator,
                            float* comp_rgb, float* g_comp_ws, float* loss_out, float* stash, int64_t Mp,
                            const int32_t* job_table, int64_t n_jobs, float* slabs, const int32_t* reduce_table,
-                           float* grads, hipStream_t stream) {
+                           float* grads, const void* packed_x3, hipStream_t stream) {
     if (!target || !comp_rgb || !g_comp_ws || !loss_out || !(loss_denominator > 0.0) || R < 1) {
         tn_set_error("%s: target=%p comp=%p g_ws=%p loss=%p denom=%g R=%lld", who, (const void*)target, (void*)comp_rgb,
                      (void*)g_comp_ws, (void*)loss_out, loss_denominator, (long long)R);
@@ -128,7 +132,7 @@ static int train_step_impl(const char* who, const tnerf_mlp_desc* d, const float
     }
     if (!reduce_table || !grads) { tn_set_error("%s: reduce_table=%p grads=%p", who, (const void*)reduce_table, (void*)grads); return TNERF_EINVAL; }
     const LossArgs loss{target, target_index, (float)(1.0 / loss_denominator), g_comp_ws, nullptr};
-    int rc = tn_step32_core(who, d, packed, rs, TnStepRef{}, loss, R, S, ztab, randomized, t_rand, seed, offset, white, comp_rgb, stash, Mp,
+    int rc = tn_step32_core(who, d, packed, packed_x3, rs, TnStepRef{}, loss, R, S, ztab, randomized, t_rand, seed, offset, white, comp_rgb, stash, Mp,
                             job_table, n_jobs, slabs, stream);
     if (rc) return rc;
     FinishArgs f{};
@@ -142,10 +146,10 @@ extern "C" int tnerf_train_step_fused(const tnerf_mlp_desc* d, const float* pack
                                       const float* t_rand, uint64_t seed, uint64_t offset, int32_t white, double loss_denominator,
                                       float* comp_rgb, float* g_comp_ws, float* loss_out, float* stash, int64_t Mp,
                                       const int32_t* job_table, int64_t n_jobs, float* slabs, const int32_t* reduce_table,
-                                      float* grads, tnerf_stream_t stream) {
+                                      float* grads, const void* packed_x3, tnerf_stream_t stream) {
     return train_step_impl("tnerf_train_step_fused", d, packed, tn_table_source(rays_o, rays_d), target, nullptr, R, S, ztab, randomized,
                            t_rand, seed, offset, white, loss_denominator, comp_rgb, g_comp_ws, loss_out, stash, Mp, job_table, n_jobs,
-                           slabs, reduce_table, grads, (hipStream_t)stream);
+                           slabs, reduce_table, grads, packed_x3, (hipStream_t)stream);
 }
 
 extern "C" int tnerf_train_step_fused_cam(const tnerf_mlp_desc* d, const float* packed, const tnerf_camera* cam, const float* pixels,
@@ -153,13 +157,13 @@ extern "C" int tnerf_train_step_fused_cam(const tnerf_mlp_desc* d, const float* 
                                           uint64_t seed, uint64_t offset, int32_t white, double loss_denominator, float* comp_rgb,
                                           float* g_comp_ws, float* loss_out, float* stash, int64_t Mp, const int32_t* job_table,
                                           int64_t n_jobs, float* slabs, const int32_t* reduce_table, float* grads,
-                                          tnerf_stream_t stream) {
+                                          const void* packed_x3, tnerf_stream_t stream) {
     RaySource rs;
     int rc = tn_camera_source("tnerf_train_step_fused_cam", cam, R, &rs); if (rc) return rc;
     if (!cam->pix_index) { tn_set_error("tnerf_train_step_fused_cam: pix_index is required (it also selects the target pixels)"); return TNERF_EINVAL; }
     return train_step_impl("tnerf_train_step_fused_cam", d, packed, rs, pixels, cam->pix_index, R, S, ztab, randomized, t_rand, seed,
                            offset, white, loss_denominator, comp_rgb, g_comp_ws, loss_out, stash, Mp, job_table, n_jobs, slabs,
-                           reduce_table, grads, (hipStream_t)stream);
+                           reduce_table, grads, packed_x3, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------ RCCL

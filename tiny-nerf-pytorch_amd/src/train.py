@@ -100,7 +100,7 @@ def render_one(model: nn.Module, encoder: nn.Module, H: int, W: int, focal: floa
         render = ops.render_camera_fused_bf16 if precision == "bf16" else ops.render_camera_fused
         key = tuple(p._version for p in model._param_list())
         for i in range(0, H * W, chunk):
-            kw = dict(key=key) if precision == "bf16" else {}
+            kw = dict(key=key) if precision == "bf16" else dict(x3_key=key)
             comp, _, _ = render(st, pose_d, H, W, focal, i, min(chunk, H * W - i), near, far, n_samples, **kw)
             parts.append(comp)
         return torch.cat(parts, dim=0).reshape(H, W, 3).clamp(0.0, 1.0)
@@ -130,7 +130,8 @@ def render_one_sharded(model: nn.Module, encoder: nn.Module, H: int, W: int, foc
     lo, hi = _dist.shard_bounds(H * W, rank, world)
     st, pose_d = model._ensure_packed(), pose.to(device)
     render = ops.render_camera_fused_bf16 if precision == "bf16" else ops.render_camera_fused
-    kw = dict(key=tuple(p._version for p in model._param_list())) if precision == "bf16" else {}
+    vkey = tuple(p._version for p in model._param_list())
+    kw = dict(key=vkey) if precision == "bf16" else dict(x3_key=vkey)
     parts = [render(st, pose_d, H, W, focal, i, min(chunk, hi - i), near, far, n_samples, **kw)[0]
              for i in range(lo, hi, chunk)]
     local = torch.cat(parts, dim=0) if parts else torch.zeros(0, 3, device=device)

@@ -48,7 +48,8 @@ class StepArgs(C.Structure):
                 ("job_table", C.c_void_p), ("n_jobs", C.c_int64), ("slabs", C.c_void_p), ("reduce_table", C.c_void_p), ("grads", C.c_void_p),
                 ("params", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
                 ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
-                ("scatter_table", C.c_void_p), ("scatter_width", C.c_int32)]
+                ("scatter_table", C.c_void_p), ("scatter_width", C.c_int32),
+                ("packed_x3", C.c_void_p), ("scatter_x3", C.c_void_p), ("scatter_x3_width", C.c_int32)]
 
 
 PHASE_GRADIENT, PHASE_REDUCE, PHASE_UPDATE = 1, 2, 4
@@ -85,10 +86,10 @@ SIGNATURES = {
     "tnerf_wgrad": (C.c_int, [_DESC, _P, _I64, _I64, _P, _I64, _P, _P]),
     "tnerf_wgrad_reduce": (C.c_int, [_P, _P, _I64, _P, _P]),
     "tnerf_train_step_fused": (C.c_int, [_DESC, _P, _P, _P, _P, _I64, _I32, _P, _I32, _P, _U64, _U64, _I32, _D,
-                                         _P, _P, _P, _P, _I64, _P, _I64, _P, _P, _P, _P]),
+                                         _P, _P, _P, _P, _I64, _P, _I64, _P, _P, _P, _P, _P]),
     "tnerf_render_fused_cam": (C.c_int, [_DESC, _P, C.POINTER(Camera), _I64, _I32, _P, _I32, _P, _U64, _U64, _I32, _P, _P, _P, _P]),
     "tnerf_train_step_fused_cam": (C.c_int, [_DESC, _P, C.POINTER(Camera), _P, _I64, _I32, _P, _I32, _P, _U64, _U64, _I32, _D,
-                                             _P, _P, _P, _P, _I64, _P, _I64, _P, _P, _P, _P]),
+                                             _P, _P, _P, _P, _I64, _P, _I64, _P, _P, _P, _P, _P]),
     "tnerf_bf16_plan_sizes": (C.c_int, [_DESC, C.POINTER(Bf16Sizes)]),
     "tnerf_bf16_pack_table": (C.c_int, [_DESC, _P]),
     "tnerf_mlp_pack_bf16": (C.c_int, [_DESC, _P, _P, _P, _P]),
@@ -104,6 +105,12 @@ SIGNATURES = {
     "tnerf_train_step_fused_cam_bf16": (C.c_int, [_DESC, _P, C.POINTER(Camera), _P, _I64, _I32, _P, _I32, _P, _U64, _U64, _I32, _D,
                                                   _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P]),
     "tnerf_adam_step": (C.c_int, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _I64, _F, _P]),
+    "tnerf_x3_plan_sizes": (C.c_int, [_DESC, C.POINTER(Bf16Sizes)]),
+    "tnerf_x3_pack_table": (C.c_int, [_DESC, _P]),
+    "tnerf_mlp_pack_x3": (C.c_int, [_DESC, _P, _P, _P, _P]),
+    "tnerf_render_fused_x3": (C.c_int, [_DESC, _P, _P, _P, _I64, _I32, _P, _I32, _P, _U64, _U64, _I32, _P, _P, _P, _P]),
+    "tnerf_render_fused_cam_x3": (C.c_int, [_DESC, _P, C.POINTER(Camera), _I64, _I32, _P, _I32, _P, _U64, _U64, _I32, _P, _P, _P, _P]),
+    "tnerf_train_fwd_fused_x3": (C.c_int, [_DESC, _P, _P, _P, _I64, _I32, _P, _I32, _P, _U64, _U64, _I32, _P, _P, _I64, _P]),
     "tnerf_train_step_dataset": (C.c_int, [C.POINTER(StepArgs), _P]),
     "tnerf_graph_begin": (C.c_int, [_P]),
     "tnerf_graph_end": (C.c_int, [_P, C.POINTER(C.c_void_p)]),

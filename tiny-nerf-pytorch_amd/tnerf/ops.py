@@ -256,6 +256,8 @@ class ModelState:
             _l.check(_l.EUNSUPPORTED, "TinyNeRF (HIP)")
         self.n_params = int(n)
         self.n_cu = torch.cuda.get_device_properties(device).multi_processor_count
+        # the x3 chain kernels (fp32 products on the bf16 matrix pipe, exact) cover the fused paths: in_dim = 6L+3
+        self.x3_capable = in_dim >= 9 and (in_dim - 3) % 6 == 0
         k = 2 * depth + 4
         off = np.zeros(k, np.int64); rows = np.zeros(k, np.int64); cols = np.zeros(k, np.int64)
         _l.call("tnerf_param_layout", C.byref(self.desc), off.ctypes.data_as(C.c_void_p), rows.ctypes.data_as(C.c_void_p),
@@ -274,6 +276,7 @@ class ModelState:
         self.plans: Dict[int, _Plan] = {}
         self.adopted_ptrs: Tuple[int, ...] = ()
         self.bf16: Optional[_Bf16State] = None          # built on first use of the bf16 mode
+        self.x3: Optional["_X3State"] = None            # built on first use of the x3 chain kernels
 
     def plan(self, M: int) -> _Plan:
         p = self.plans.get(M)
@@ -296,6 +299,8 @@ class ModelState:
         self.packed_key = None
         if self.bf16 is not None:
             self.bf16.key = None
+        if self.x3 is not None:
+            self.x3.key = None
 
     def owns(self, params) -> bool:
         """True while EVERY parameter is still the view into the flat buffer that adopt() made (2*depth+4 pointer
@@ -316,6 +321,17 @@ class ModelState:
         b = self.bf16
         if key is None or key != b.key:
             _l.call("tnerf_mlp_pack_bf16", C.byref(self.desc), self.flat.data_ptr(), b.table.data_ptr(), b.packed.data_ptr(),
+                    _stream(self.device))
+            b.key = key
+        return b
+
+    def repack_x3(self, key=None) -> "_X3State":
+        """x3 chain (fp32 products on the bf16 matrix pipe, exact): (re)build the three-piece record stream + fp32 biases."""
+        if self.x3 is None:
+            self.x3 = _X3State(self)
+        b = self.x3
+        if key is None or key != b.key:
+            _l.call("tnerf_mlp_pack_x3", C.byref(self.desc), self.flat.data_ptr(), b.table.data_ptr(), b.packed.data_ptr(),
                     _stream(self.device))
             b.key = key
         return b
@@ -346,6 +362,20 @@ class _Bf16State:
                 self.plans.pop(next(iter(self.plans)))
             p = self.plans[(R, S)] = _Bf16TrainPlan(self.st, R, S)
         return p
+
+
+class _X3State:
+    """Pack table and packed record stream of the x3 chain kernels for one model (include/tnerf.h, "x3")."""
+
+    def __init__(self, st: ModelState):
+        sz = _l.Bf16Sizes()
+        _l.call("tnerf_x3_plan_sizes", C.byref(st.desc), C.byref(sz))
+        tab = np.empty(int(sz.pack_entries), np.int32)
+        _l.call("tnerf_x3_pack_table", C.byref(st.desc), tab.ctypes.data_as(C.c_void_p))
+        self.table = torch.from_numpy(tab).to(st.device)
+        self.packed = torch.empty(int(sz.packed_bytes), dtype=torch.uint8, device=st.device)
+        self.n_fragments = int(sz.n_fragments)
+        self.key = None
 
 
 class _Bf16TrainPlan:
@@ -493,9 +523,10 @@ def camera_struct(c2w: torch.Tensor, H: int, W: int, focal: float, pix_index: Op
 
 @torch.no_grad()
 def render_camera_fused(st: ModelState, c2w, H, W, focal, pix_first, n_rays, near, far, n_samples, white_bkgd=True,
-                        randomized=False, t_rand=None, philox=None):
+                        randomized=False, t_rand=None, philox=None, x3_key=None):
     """Inference render of pixels pix_first .. pix_first+n_rays-1 of one pose: rays are generated in the kernel
-    (no get_rays launch, no ray tables).  Returns (comp_rgb, depth, acc)."""
+    (no get_rays launch, no ray tables).  Returns (comp_rgb, depth, acc).  x3_key (the parameters' version tuple): run the
+    x3 chain kernel — same fp32 results, the matrix work on the bf16 pipe; None: the fp32-MFMA kernel on st.packed."""
     dev = st.device
     S = int(n_samples)
     ztab = depth_table(near, far, S, dev)
@@ -504,6 +535,11 @@ def render_camera_fused(st: ModelState, c2w, H, W, focal, pix_first, n_rays, nea
     comp = torch.empty(n_rays, 3, dtype=torch.float32, device=dev)
     depth = torch.empty(n_rays, 1, dtype=torch.float32, device=dev)
     acc = torch.empty(n_rays, 1, dtype=torch.float32, device=dev)
+    if x3_key is not None and st.x3_capable and not (st.desc.flags & _l.FLAG_FP32_MFMA):
+        b = st.repack_x3(x3_key)              # fp32 results, products formed exactly on the bf16 matrix pipe
+        _l.call("tnerf_render_fused_cam_x3", C.byref(st.desc), b.packed.data_ptr(), C.byref(cam), int(n_rays), S, ztab.data_ptr(), rnd,
+                _ptr(tr), seed, off, int(bool(white_bkgd)), comp.data_ptr(), depth.data_ptr(), acc.data_ptr(), _stream(dev))
+        return comp, depth, acc
     _l.call("tnerf_render_fused_cam", C.byref(st.desc), st.packed.data_ptr(), C.byref(cam), int(n_rays), S, ztab.data_ptr(), rnd,
             _ptr(tr), seed, off, int(bool(white_bkgd)), comp.data_ptr(), depth.data_ptr(), acc.data_ptr(), _stream(dev))
     return comp, depth, acc
@@ -546,5 +582,46 @@ def render_camera_fused_bf16(st: ModelState, c2w, H, W, focal, pix_first, n_rays
     depth = torch.empty(n_rays, 1, dtype=torch.float32, device=dev)
     acc = torch.empty(n_rays, 1, dtype=torch.float32, device=dev)
     _l.call("tnerf_render_fused_cam_bf16", C.byref(st.desc), b.packed.data_ptr(), C.byref(cam), int(n_rays), S, ztab.data_ptr(), rnd,
+            _ptr(tr), seed, off, int(bool(white_bkgd)), comp.data_ptr(), depth.data_ptr(), acc.data_ptr(), _stream(dev))
+    return comp, depth, acc
+
+
+# ------------------------------------------------------------------------------------- x3 chain
+@torch.no_grad()
+def render_rays_fused_x3(st: ModelState, rays_o, rays_d, near, far, n_samples, randomized=False, white_bkgd=True,
+                         t_rand=None, philox=None, key=None):
+    """render_rays_fused (inference) with the MLP's fp32 products formed exactly on the bf16 matrix pipe (three-way operand
+    split): fp32 results.  Returns (comp_rgb [R,3], depth [R,1], acc [R,1])."""
+    dev = _need_cuda(rays_o, rays_d, t_rand)
+    rays_o, rays_d = _f32c(rays_o), _f32c(rays_d)
+    R, S = rays_o.shape[0], int(n_samples)
+    ztab = depth_table(near, far, S, dev)
+    rnd, tr, seed, off = _rng_args(randomized, t_rand, philox)
+    if tr is not None:
+        tr = _f32c(tr)
+    b = st.repack_x3(key)
+    comp = torch.empty(R, 3, dtype=torch.float32, device=dev)
+    depth = torch.empty(R, 1, dtype=torch.float32, device=dev)
+    acc = torch.empty(R, 1, dtype=torch.float32, device=dev)
+    _l.call("tnerf_render_fused_x3", C.byref(st.desc), b.packed.data_ptr(), rays_o.data_ptr(), rays_d.data_ptr(), R, S,
+            ztab.data_ptr(), rnd, _ptr(tr), seed, off, int(bool(white_bkgd)), comp.data_ptr(), depth.data_ptr(), acc.data_ptr(),
+            _stream(dev))
+    return comp, depth, acc
+
+
+@torch.no_grad()
+def render_camera_fused_x3(st: ModelState, c2w, H, W, focal, pix_first, n_rays, near, far, n_samples, white_bkgd=True,
+                           randomized=False, t_rand=None, philox=None, key=None):
+    """render_camera_fused on the x3 chain kernels."""
+    dev = st.device
+    S = int(n_samples)
+    ztab = depth_table(near, far, S, dev)
+    rnd, tr, seed, off = _rng_args(randomized, t_rand, philox)
+    cam, keep = camera_struct(c2w, H, W, focal, None, pix_first)
+    b = st.repack_x3(key)
+    comp = torch.empty(n_rays, 3, dtype=torch.float32, device=dev)
+    depth = torch.empty(n_rays, 1, dtype=torch.float32, device=dev)
+    acc = torch.empty(n_rays, 1, dtype=torch.float32, device=dev)
+    _l.call("tnerf_render_fused_cam_x3", C.byref(st.desc), b.packed.data_ptr(), C.byref(cam), int(n_rays), S, ztab.data_ptr(), rnd,
             _ptr(tr), seed, off, int(bool(white_bkgd)), comp.data_ptr(), depth.data_ptr(), acc.data_ptr(), _stream(dev))
     return comp, depth, acc

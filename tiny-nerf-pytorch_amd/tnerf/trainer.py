@@ -73,9 +73,11 @@ class FlatAdam(torch.optim.Optimizer):
         _l.call("tnerf_adam_step", st.flat.data_ptr(), st.grad.data_ptr(), self._m.data_ptr(), self._v.data_ptr(), st.n_params,
                 float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), self._t, float(grad_scale),
                 torch.cuda.current_stream(st.device).cuda_stream)
-        st.packed_key = None                     # the packed copies (fp32 fragments, bf16 stream) are stale now
+        st.packed_key = None                     # the packed copies (fp32 fragments, bf16 stream, x3 records) are stale now
         if st.bf16 is not None:
             st.bf16.key = None
+        if st.x3 is not None:
+            st.x3.key = None
         return None          # the per-parameter "step" scalars are refreshed lazily (state_dict), not 2*depth+4 times per step
 
     def _refresh_steps(self):
@@ -140,10 +142,18 @@ class FusedTrainer:
                     target.data_ptr(), R, self.S, ztab.data_ptr(), rnd, _ops._ptr(tr), seed, off, self.white, denom,
                     self._comp.data_ptr(), self._gws.data_ptr(), self.loss.data_ptr(), stash.data_ptr(), plan.Mp,
                     plan.jobs.data_ptr(), plan.n_jobs, plan.slabs.data_ptr(), plan.reduce.data_ptr(), st.grad.data_ptr(),
-                    torch.cuda.current_stream(dev).cuda_stream)
+                    self._x3_ptr(), torch.cuda.current_stream(dev).cuda_stream)
         _dist.all_reduce_sum_(st.grad)
         self.opt.step(grads_in_flat=True)
         return self.loss, self._comp
+
+    def _x3_ptr(self):
+        """The x3 record stream of the current weights (the forward runs on the bf16 matrix pipe with exact fp32 products), or
+        None for models the x3 kernels do not cover / when the fp32-MFMA kernels were asked for."""
+        st = self.st
+        if (st.desc.flags & _l.FLAG_FP32_MFMA) or not st.x3_capable:
+            return None
+        return st.repack_x3(tuple(p._version for p in self.model._param_list())).packed.data_ptr()
 
     @torch.no_grad()
     def step_camera(self, pose, H: int, W: int, focal: float, inds, pixels, t_rand: Optional[torch.Tensor] = None, philox=None,
@@ -179,7 +189,7 @@ class FusedTrainer:
             _l.call("tnerf_train_step_fused_cam", C.byref(st.desc), st.packed.data_ptr(), C.byref(cam), pixels.data_ptr(), R, self.S,
                     ztab.data_ptr(), rnd, _ops._ptr(tr), seed, off, self.white, denom, self._comp.data_ptr(), self._gws.data_ptr(),
                     self.loss.data_ptr(), stash.data_ptr(), plan.Mp, plan.jobs.data_ptr(), plan.n_jobs, plan.slabs.data_ptr(),
-                    plan.reduce.data_ptr(), st.grad.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+                    plan.reduce.data_ptr(), st.grad.data_ptr(), self._x3_ptr(), torch.cuda.current_stream(dev).cuda_stream)
         _dist.all_reduce_sum_(st.grad)
         self.opt.step(grads_in_flat=True)
         return self.loss, self._comp
@@ -248,6 +258,7 @@ class DatasetTrainer:
         self.pix = torch.empty(self.R, dtype=torch.int32, device=dev) if record_pixels else None
         self._graph = None
         self._graph_key = None
+        self._x3_packed = self._x3_scatter = None
         self._want_graph = bool(graph) and world == 1
         self._calls = 0
         self._own_stream = None
@@ -260,6 +271,10 @@ class DatasetTrainer:
             self._lease = self._plan.lease()                                  # this trainer's stash for as long as it lives
             self._stash, self._stride = self._lease.buf, self._plan.Mp
             tab = st.pack_table.cpu().numpy()
+            if st.x3_capable and not (st.desc.flags & _l.FLAG_FP32_MFMA):    # forward on the x3 chain kernel; the finishing kernel keeps its stream current
+                x3 = st.repack_x3(tuple(p._version for p in model._param_list()))
+                self._x3_packed = x3.packed
+                self._x3_scatter = torch.from_numpy(_scatter_table(x3.table.cpu().numpy(), st.n_params)).to(dev)
         else:
             b = st.repack_bf16(tuple(p._version for p in model._param_list()))
             self._packed = b.packed
@@ -289,6 +304,8 @@ class DatasetTrainer:
         a.params, a.exp_avg, a.exp_avg_sq = st.flat.data_ptr(), self.opt._m.data_ptr(), self.opt._v.data_ptr()
         a.lr, a.beta1, a.beta2, a.eps = float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"])
         a.scatter_table, a.scatter_width = self._scatter.data_ptr(), int(self._scatter.shape[1])
+        if self._x3_packed is not None:
+            a.packed_x3, a.scatter_x3, a.scatter_x3_width = self._x3_packed.data_ptr(), self._x3_scatter.data_ptr(), int(self._x3_scatter.shape[1])
         return a
 
     def _hyper_key(self):
@@ -342,12 +359,16 @@ class DatasetTrainer:
                 torch.cuda.current_stream(st.device).wait_stream(stream)
         self._calls += 1
         self.opt._t += 1
-        # the finishing kernel re-packed THIS precision's copy of the weights; the other one is stale now
+        # the finishing kernel re-packed THIS precision's copies of the weights; the others are stale now
         if self.precision == "fp32":
             if st.bf16 is not None:
                 st.bf16.key = None
+            if st.x3 is not None and self._x3_packed is None:
+                st.x3.key = None
         else:
             st.packed_key = None
+            if st.x3 is not None:
+                st.x3.key = None
         return self.loss, self.comp
 
     @torch.no_grad()
@@ -367,8 +388,12 @@ class DatasetTrainer:
         if self.precision == "fp32":
             if self.st.bf16 is not None:
                 self.st.bf16.key = None
+            if self.st.x3 is not None and self._x3_packed is None:
+                self.st.x3.key = None
         else:
             self.st.packed_key = None
+            if self.st.x3 is not None:
+                self.st.x3.key = None
         return self.loss, self.comp
 
     @property
