@@ -441,6 +441,14 @@ int tnerf_train_fwd_fused_x3(const tnerf_mlp_desc* d, const void* packed3,
                              uint64_t seed, uint64_t offset, int32_t white_bkgd,
                              float* comp_rgb, float* stash, int64_t stash_row_stride, tnerf_stream_t stream);
 
+/* tnerf_train_dgrad_fused on the split-bf16 chain: reads the backward record stream of `packed_x3` (heads^T and the
+ * transposed hidden layers, which tnerf_mlp_pack_x3 writes behind the forward stream) and fills the same dZ rows. */
+int tnerf_train_dgrad_fused_x3(const tnerf_mlp_desc* d, const void* packed_x3,
+                               const float* rays_o, const float* rays_d, int64_t n_rays, int32_t n_samples,
+                               const float* ztab, int32_t randomized, const float* t_rand,
+                               uint64_t seed, uint64_t offset, int32_t white_bkgd,
+                               const float* g_comp, float* stash, int64_t stash_row_stride, tnerf_stream_t stream);
+
 /* torch.optim.Adam(lr, betas, eps, weight_decay=0) on the flat buffers   [src/train.py:80,127]
  * step = 1-based step count t used for the bias corrections; grad_scale multiplies the gradient
  * first (1/world_size after an all-reduce SUM of already globally-normalised shards = 1). */

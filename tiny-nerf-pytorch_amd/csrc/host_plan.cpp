@@ -689,10 +689,14 @@ extern "C" int tn_build_netx3(const tnerf_mlp_desc* d, NetX3* n) {
     rec += n->KH;                                                           // heads
     if ((rec * n->rec_frags) % TX_STAGE != 0) { tn_set_error("x3 chain: the record stream is not a whole number of stages"); return TNERF_EUNSUPPORTED; }
     n->n_rec = rec; n->n_stage = rec * n->rec_frags / TX_STAGE;
-    n->bias_off = rec * n->rec_frags * 1024;
+    const int rps = TX_STAGE / n->rec_frags;                               // records per stage
+    n->n_bw_rec = rps + (d->depth - 1) * n->KH;                             // heads^T (padded to a stage) + transposed hidden layers
+    if ((n->n_bw_rec * n->rec_frags) % TX_STAGE != 0) { tn_set_error("x3 chain: the backward record stream is not a whole number of stages"); return TNERF_EUNSUPPORTED; }
+    n->n_bw_stage = n->n_bw_rec * n->rec_frags / TX_STAGE;
+    n->bias_off = (rec + n->n_bw_rec) * n->rec_frags * 1024;
     n->n_bias = d->depth * H + 4;
     n->packed_bytes = (int64_t)n->bias_off + (int64_t)n->n_bias * 4;
-    n->pack_entries = (int64_t)rec * n->rec_frags * 512 + n->n_bias;
+    n->pack_entries = (int64_t)(rec + n->n_bw_rec) * n->rec_frags * 512 + n->n_bias;
     return TNERF_OK;
 }
 
@@ -700,8 +704,8 @@ extern "C" int tnerf_x3_plan_sizes(const tnerf_mlp_desc* d, tnerf_bf16_sizes* ou
     NetX3 n; int rc = tn_build_netx3(d, &n); if (rc) return rc;
     if (!out) { tn_set_error("tnerf_x3_plan_sizes: NULL output"); return TNERF_EINVAL; }
     out->packed_bytes = n.packed_bytes; out->pack_entries = n.pack_entries;
-    out->n_fragments = (int64_t)n.n_rec * n.rec_frags; out->bias_offset_bytes = n.bias_off;
-    out->n_fwd_fragments = out->n_fragments;
+    out->n_fragments = (int64_t)(n.n_rec + n.n_bw_rec) * n.rec_frags; out->bias_offset_bytes = n.bias_off;
+    out->n_fwd_fragments = (int64_t)n.n_rec * n.rec_frags;
     return TNERF_OK;
 }
 
@@ -737,7 +741,18 @@ extern "C" int tnerf_x3_pack_table(const tnerf_mlp_desc* d, int32_t* T) {
             const int64_t src = head_w(lane & 31, hid_feature16(s, lane >> 5, e));
             if (src >= 0) put(0, lane, e, src);
         }
-    int32_t* B = T + (int64_t)n.n_rec * n.rec_frags * 512;
+    // ---- backward stream
+    rec = n.n_rec;
+    for (int t = 0; t < NT; ++t)                                            // heads^T: dH[k] = sum_{row<4} W_head[row][k] dZh[row]
+        for (int lane = 0; lane < 32; ++lane) for (int e = 0; e < 4; ++e) put(t, lane, e, head_w(e, 32 * t + lane));
+    rec = n.n_rec + TX_STAGE / n.rec_frags;
+    for (int l = L.depth - 1; l >= 1; --l) {
+        const int fan = L.fan_in[l];
+        for (int s = 0; s < KH; ++s, ++rec)
+            for (int t = 0; t < NT; ++t) for (int lane = 0; lane < 64; ++lane) for (int e = 0; e < 8; ++e)
+                put(t, lane, e, L.p_w[l] + (int64_t)hid_feature16(s, lane >> 5, e) * fan + (32 * t + (lane & 31)));
+    }
+    int32_t* B = T + (int64_t)(n.n_rec + n.n_bw_rec) * n.rec_frags * 512;
     for (int l = 0; l < L.depth; ++l) for (int j = 0; j < H; ++j) B[l * H + j] = (int32_t)(L.p_b[l] + j);
     for (int j = 0; j < 3; ++j) B[L.depth * H + j] = (int32_t)(L.p_bc + j);
     B[L.depth * H + 3] = (int32_t)L.p_bs;

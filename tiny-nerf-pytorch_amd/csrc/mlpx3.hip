@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256, 1) void k_renderx3(FwdX3Args a) {
     if (TRAIN) tn_resolve_step(rs, sa);                            // dataset mode: this step's image and Philox counters
     const int S = sa.S, Lf = a.n.Lf;
     PipeX p;
-    tx_prologue(p, lds, a.packed3, a.n, lane, wave);
+    tx_prologue(p, lds, a.packed3, a.n, a.packed3, a.n.n_stage, lane, wave);
 
     // Every wave of the workgroup runs the same number of network passes (the stage barriers are workgroup-wide): rays beyond
     // R are computed on a clamped index and stored nowhere (training: into the dump block).
@@ -147,6 +147,171 @@ __global__ __launch_bounds__(256, 1) void k_renderx3(FwdX3Args a) {
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // no DMA may still be writing this workgroup's LDS at exit
+}
+
+// ------------------------------------------------------------------------------------------------ dgrad
+// What autograd derives from volume.py:18-42 and nerf.py:34-40 (as mlp_bwd.hip), with the chain dH_{l-1} = W_l^T dZ_l on the
+// bf16 matrix pipe: the backward record stream (heads^T, then the transposed hidden layers), dZ_l as three exact pieces, the
+// same k-step-major layer walk.  Reads the forward's sign bits and head outputs from the stash and writes every dZ_l (fp32)
+// next to them, exactly where the weight-gradient kernel expects them.
+struct BwdX3Args {
+    BwdArgs b;                      // layout, stash, ray source, sampling, g_comp (+ stride) — as the fp32 kernel
+    NetX3 n;
+    const unsigned char* packed3;
+};
+
+// dzh[4]: this lane's head gradients (r,g,b,sigma pre-activation) for sample m.
+template <int HID>
+__device__ __forceinline__ void tx_bwd_tile(PipeX& p, const unsigned char* lds, const BwdX3Args& a, const float (&dzh)[4], int64_t m, bool valid,
+                                            int lane) {
+    constexpr int NT = HID / 32;
+    constexpr int ST = 0;
+    const MlpLayout& L = a.b.L;
+    const int h = lane >> 5, depth = a.n.depth;
+    float* __restrict__ stash = a.b.stash;
+    const int64_t Mp = a.b.Mp;
+    const int64_t ms = valid ? m : Mp + (lane & 31);               // padding lanes use the dump block
+    float* __restrict__ pl = tn_stash_at(stash, L.stash_rows, ms) + 4 * h * 32;
+    if (h == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pl[(L.dzh_row0 + i) * 32] = dzh[i];
+    }
+    const uint32_t* __restrict__ mrow = reinterpret_cast<const uint32_t*>(stash + TN_STASH_BODY_FLOATS(L, Mp)) + (2 * ms + h) * (NT / 2);
+    ActX<HID> X;
+    EncX Z;                                                        // the head gradient as the B operand of the heads^T k-step (slot (h=0, e<4) = row e)
+    {
+        unsigned a0, b0, c0, a1, b1, c1;
+        tx_split2(h ? 0.0f : dzh[0], h ? 0.0f : dzh[1], a0, b0, c0);
+        tx_split2(h ? 0.0f : dzh[2], h ? 0.0f : dzh[3], a1, b1, c1);
+        const u32x4 w1 = {a0, a1, 0u, 0u}, w2 = {b0, b1, 0u, 0u}, w3 = {c0, c1, 0u, 0u};
+        Z.p1[0] = __builtin_bit_cast(bf16x8, w1); Z.p2[0] = __builtin_bit_cast(bf16x8, w2); Z.p3[0] = __builtin_bit_cast(bf16x8, w3);
+    }
+    f32x16 acc[NT];
+    uint32_t mw[NT / 2];
+    auto fin_layer = [&](int l) TN_INLINE_LAMBDA {                 // acc = dH_l  ->  dZ_l (masked, stashed, split into X)
+#pragma unroll
+        for (int w = 0; w < NT / 2; ++w) mw[w] = mrow[(int64_t)l * (Mp + 32) * NT + w];
+        float* __restrict__ zrow = pl + L.dz_row0[l] * 32;
+        tx_layer_epilogue_bwd<HID>(acc, mw, X, [&](auto tc, const float (&v)[16]) TN_INLINE_LAMBDA {
+            constexpr int t = decltype(tc)::value;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) TN_STASH_STORE(&zrow[(32 * t + (r & 3) + 8 * (r >> 2)) * 32], v[r]);
+        });
+    };
+    tx_layer_mfma<HID, 4, ST>(p, lds, X, Z, acc);                  // heads^T
+    fin_layer(depth - 1);
+    for (int l = depth - 1; l >= 1; --l) {
+        tx_layer_mfma<HID, 1, ST>(p, lds, X, Z, acc);              // dH_{l-1} = W_l^T dZ_l
+        fin_layer(l - 1);
+    }
+}
+
+template <int HID>
+__global__ __launch_bounds__(256, 1) void k_dgradx3(BwdX3Args a) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    const int lane = tn_lane();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    RaySource rs = a.b.rs; SampleArgs sa = a.b.sa;
+    tn_resolve_step(rs, sa);
+    const int S = sa.S;
+    const int nseg = (S + 63) / 64;
+    PipeX p;
+    tx_prologue(p, lds, a.packed3, a.n, a.packed3 + (int64_t)a.n.n_rec * a.n.rec_frags * 1024, a.n.n_bw_stage, lane, wave);
+    const int64_t R = a.b.R;
+    const int64_t n_groups = (R + 3) / 4;
+    const int orow = a.b.L.out_row0 * 32; const int64_t SR = a.b.L.stash_rows;
+    for (int64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
+        const int64_t ray = g * 4 + wave;
+        const bool rvalid = ray < R;
+        const int64_t rayc = rvalid ? ray : R - 1;
+        float ro_[3], rd_[3];
+        tn_fetch_ray(rs, rayc, ro_, rd_);
+        const float dn = tn_norm3(rd_[0], rd_[1], rd_[2]);
+        const int64_t gi = (int64_t)a.b.g_stride * rayc;
+        const float gr = rvalid ? a.b.g_comp[gi] : 0.f, gg = rvalid ? a.b.g_comp[gi + 1] : 0.f, gb = rvalid ? a.b.g_comp[gi + 2] : 0.f;
+        const float gbg = a.b.white ? (gr + gg + gb) : 0.0f;
+        const int64_t mray = rayc * S;
+        auto outv = [&](int i, int sc) TN_INLINE_LAMBDA { return tn_stash_at(a.b.stash, SR, mray + sc)[orow + 32 * i]; };
+
+        float segprod = 1.0f;
+        if (nseg > 1) {
+            for (int sg_ = 0; sg_ < nseg; ++sg_) {
+                const int s = sg_ * 64 + lane; const bool ok = s < S; const int sc = ok ? s : S - 1;
+                const float z = tn_depth(sa, rayc, sc);
+                const float zn = (s + 1 < S) ? tn_depth(sa, rayc, s + 1) : z;
+                const CompTerms t = tn_comp_terms(ok ? outv(3, sc) : 0.f, z, zn, s == S - 1, dn);
+                const float pr = tn_wave_prod(ok ? t.om : 1.0f);
+                if (lane == sg_) segprod = pr;
+            }
+        }
+        const float seg_incl = tn_wave_scan_mul(segprod, lane);
+        float seg_T = __shfl_up(seg_incl, 1, 64);
+        if (lane == 0) seg_T = 1.0f;
+        float tail = 0.0f;
+        for (int sg_ = nseg - 1; sg_ >= 0; --sg_) {
+            const int s = sg_ * 64 + lane; const bool ok = s < S; const int sc = ok ? s : S - 1;
+            const float c0 = outv(0, sc), c1 = outv(1, sc), c2 = outv(2, sc);
+            const float sg = ok ? outv(3, sc) : 0.f;
+            const float z = tn_depth(sa, rayc, sc);
+            const float zn = (s + 1 < S) ? tn_depth(sa, rayc, s + 1) : z;
+            const CompTerms t = tn_comp_terms(sg, z, zn, s == S - 1, dn);
+            const float om = ok ? t.om : 1.0f;
+            const float incl = tn_wave_scan_mul(om, lane);
+            float excl = __shfl_up(incl, 1, 64);
+            if (lane == 0) excl = 1.0f;
+            const float T = __shfl(seg_T, sg_, 64) * excl;
+            const float w = ok ? t.alpha * T : 0.f;
+            const float dw = gr * c0 + gg * c1 + gb * c2 - gbg;
+            const float v = ok ? w * dw : 0.f;
+            const float suf = tn_wave_suffix_sum(v, lane);
+            const float after = (suf - v) + tail;
+            const float da = T * dw - after / om;
+            float d4[4];
+            d4[0] = ok ? (w * gr) * (c0 * (1.0f - c0)) : 0.f;                          // sigmoid backward of dL/dc = w g
+            d4[1] = ok ? (w * gg) * (c1 * (1.0f - c1)) : 0.f;
+            d4[2] = ok ? (w * gb) * (c2 * (1.0f - c2)) : 0.f;
+            d4[3] = (ok && sg > 0.0f) ? (da * t.e) * t.delta : 0.f;                    // ReLU backward of dL/dsigma
+            tail += __shfl(suf, 0, 64);
+#pragma unroll 1
+            for (int half = 0; half < 2; ++half) {
+                const int sb = sg_ * 64 + 32 * half;
+                if (sb >= S) break;                                                    // wave-uniform
+                float dzh[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dzh[i] = __shfl(d4[i], 32 * half + (lane & 31), 64);
+                const int st = sb + (lane & 31);
+                const bool valid = rvalid && st < S;
+                tx_bwd_tile<HID>(p, lds, a, dzh, rayc * S + (st < S ? st : S - 1), valid, lane);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+int tnx3_launch_dgrad(const BwdX3Args& a, hipStream_t stream, const char* who) {
+    const int dev = tn_stream_device(stream), n_cu = tn_device_cus(dev);
+    const int64_t groups = (a.b.R + 3) / 4;
+    const dim3 grid((unsigned)(groups < n_cu ? groups : n_cu)), block(256);
+    const size_t lds_bytes = TX_RING + (size_t)((a.n.n_bias + 3) / 4 * 4) * 4;
+    if (a.n.hidden == 256) {
+        static std::atomic<uint32_t> seen_[TN_MAX_DEVICES];
+        if (int rc = tn_grant_dyn_lds(reinterpret_cast<const void*>(&k_dgradx3<256>), lds_bytes, dev, seen_, who)) return rc;
+        hipLaunchKernelGGL((k_dgradx3<256>), grid, block, lds_bytes, stream, a);
+    } else {
+        static std::atomic<uint32_t> seen_[TN_MAX_DEVICES];
+        if (int rc = tn_grant_dyn_lds(reinterpret_cast<const void*>(&k_dgradx3<128>), lds_bytes, dev, seen_, who)) return rc;
+        hipLaunchKernelGGL((k_dgradx3<128>), grid, block, lds_bytes, stream, a);
+    }
+    TN_HIP_CHECK_LAUNCH(who);
+    return TNERF_OK;
+}
+
+// dgrad of a train step on the x3 kernel (train_api.hip calls this instead of the fp32-MFMA dgrad when packed3 is given).
+int tnx3_train_dgrad(const char* who, const BwdArgs& b, const tnerf_mlp_desc* d, const void* packed3, hipStream_t stream) {
+    BwdX3Args a{};
+    int rc = tn_build_netx3(d, &a.n); if (rc) return rc;
+    a.b = b; a.packed3 = static_cast<const unsigned char*>(packed3);
+    return tnx3_launch_dgrad(a, stream, who);
 }
 
 int tnx3_launch_fwd(const FwdX3Args& a, bool train, hipStream_t stream, const char* who) {
@@ -251,7 +416,7 @@ extern "C" int tnerf_mlp_pack_x3(const tnerf_mlp_desc* d, const float* params, c
         tn_set_error("tnerf_mlp_pack_x3: params=%p table=%p packed3=%p", (const void*)params, (const void*)table, packed3);
         return TNERF_EINVAL;
     }
-    const int64_t n_w = (int64_t)n.n_rec * n.rec_frags * 512;
+    const int64_t n_w = (int64_t)(n.n_rec + n.n_bw_rec) * n.rec_frags * 512;
     hipLaunchKernelGGL(k_packx3, dim3((unsigned)((n.pack_entries + 255) / 256)), dim3(256), 0, (hipStream_t)stream, params, table, n_w,
                        n.pack_entries, static_cast<unsigned short*>(packed3),
                        reinterpret_cast<float*>(static_cast<unsigned char*>(packed3) + n.bias_off));

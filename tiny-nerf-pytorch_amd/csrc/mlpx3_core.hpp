@@ -66,14 +66,16 @@ __device__ __forceinline__ void tx_boundary(PipeX& p) {
 }
 
 // Workgroup prologue: biases -> LDS, LEAD stages in flight, the first one landed; the first tx_boundary publishes stage 0.
-__device__ __forceinline__ void tx_prologue(PipeX& p, unsigned char* lds, const unsigned char* packed, const NetX3& n, int lane, int wave) {
+// `src` / `n_stage`: the stream this kernel walks (forward: packed, n.n_stage; dgrad: the backward stream behind it).
+__device__ __forceinline__ void tx_prologue(PipeX& p, unsigned char* lds, const unsigned char* packed, const NetX3& n,
+                                            const unsigned char* src, int n_stage, int lane, int wave) {
     {
         float* bl = reinterpret_cast<float*>(lds + TX_RING);
         const float* bg = reinterpret_cast<const float*>(packed + n.bias_off);
         for (int i = threadIdx.x; i < n.n_bias; i += 256) bl[i] = bg[i];
     }
     p.lane16 = lane * 16;
-    p.src = packed; p.src_off = 0; p.stream_bytes = (uint32_t)n.n_stage * TX_SLOT;
+    p.src = src; p.src_off = 0; p.stream_bytes = (uint32_t)n_stage * TX_SLOT;
     p.dst_off = 0;
     p.lds_dst0 = (uint32_t)(uintptr_t)lds + wave * (TX_DPW * 1024);
 #pragma unroll
@@ -102,22 +104,23 @@ __device__ __forceinline__ void tx_mfma6(f32x16& acc, const bf16x8& a1, const bf
     acc = TN16_MFMA(a1, b1, acc);
 }
 
-// The records of one layer: KIND 0: input k-steps only   1: hidden   2: hidden, then input (skip layer)   3: heads (tile 0 only).
+// The records of one layer: KIND 0: input k-steps only   1: hidden   2: hidden, then input (skip layer)   3: heads (tile 0 only)
+// 4: heads^T of the backward stream (ONE k-step whose B operand is E.p*[0]; the stage is padded with empty records).
 // RPS = records per stage (1 for 256-wide, 2 for 128-wide nets); every layer is a whole number of stages (4, 8, 12, 16, 20
 // records), so the stage phase of record k of a layer is k % RPS.
 template <int HID, int KIND, int STORES>
 __device__ __forceinline__ void tx_layer_mfma(PipeX& p, const unsigned char* lds, const ActX<HID>& X, const EncX& E,
                                               f32x16 (&acc)[HID / 32]) {
     constexpr int NT = HID / 32, KH = HID / 16, RPS = TX_STAGE / (NT * 3);
-    constexpr int NK = KIND == 0 ? TN16_KE : (KIND == 2 ? KH + TN16_KE : KH);
+    constexpr int NK = KIND == 0 ? TN16_KE : (KIND == 2 ? KH + TN16_KE : (KIND == 4 ? 1 : KH));
     constexpr int NTU = KIND == 3 ? 1 : NT;                        // tiles with MFMAs
-    static_assert(NK % RPS == 0, "a layer must be a whole number of stages");
+    static_assert(NK % RPS == 0 || KIND == 4, "a layer must be a whole number of stages");
     tn_static_for<NK>([&](auto kc) TN_INLINE_LAMBDA {
         constexpr int k = decltype(kc)::value;
         if constexpr (k % RPS == 0) tx_boundary<STORES>(p);
         const unsigned char* base = lds + p.cur + (k % RPS) * (NT * 3 * 1024) + p.lane16;
         bf16x8 b1, b2, b3;
-        if constexpr (KIND == 0 || (KIND == 2 && k >= KH)) { constexpr int u = KIND == 0 ? k : k - KH; b1 = E.p1[u]; b2 = E.p2[u]; b3 = E.p3[u]; }
+        if constexpr (KIND == 0 || KIND == 4 || (KIND == 2 && k >= KH)) { constexpr int u = (KIND == 0 || KIND == 4) ? k : k - KH; b1 = E.p1[u]; b2 = E.p2[u]; b3 = E.p3[u]; }
         else { b1 = X.p1[k]; b2 = X.p2[k]; b3 = X.p3[k]; }
         tn_static_for<NTU>([&](auto tc) TN_INLINE_LAMBDA {
             constexpr int t = decltype(tc)::value;
@@ -143,6 +146,36 @@ __device__ __forceinline__ void tx_layer_epilogue(const unsigned char* lds, uint
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[4 * q + i] = fmaxf(acc[t][4 * q + i] + b[i], 0.0f);
         }
+        fin(tc, v);
+        u32x4 w1[2], w2[2], w3[2];
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                unsigned a_, b_, c_;
+                tx_split2(v[8 * half + 2 * q], v[8 * half + 2 * q + 1], a_, b_, c_);
+                w1[half][q] = a_; w2[half][q] = b_; w3[half][q] = c_;
+            }
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            X.p1[2 * t + half] = __builtin_bit_cast(bf16x8, w1[half]);
+            X.p2[2 * t + half] = __builtin_bit_cast(bf16x8, w2[half]);
+            X.p3[2 * t + half] = __builtin_bit_cast(bf16x8, w3[half]);
+        }
+    });
+}
+
+// Epilogue of a backward layer: ReLU backward with the forward's sign bits (mw: the words of the layer whose activation gradient
+// this is), exact split back into the activation registers.  `fin(t, v)` sees the 16 fp32 values dZ of tile t (stash).
+template <int HID, typename Fin>
+__device__ __forceinline__ void tx_layer_epilogue_bwd(const f32x16 (&acc)[HID / 32], const uint32_t (&mw)[HID / 64], ActX<HID>& X, Fin&& fin) {
+    constexpr int NT = HID / 32;
+    tn_static_for<NT>([&](auto tc) TN_INLINE_LAMBDA {
+        constexpr int t = decltype(tc)::value;
+        float v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            v[r] = __int_as_float(__float_as_int(acc[t][r]) & __builtin_amdgcn_sbfe((int)mw[t / 2], (t & 1) * 16 + r, 1));
         fin(tc, v);
         u32x4 w1[2], w2[2], w3[2];
 #pragma unroll

@@ -71,7 +71,7 @@ extern "C" int tnerf_train_step_dataset(const tnerf_step_args* a, tnerf_stream_t
         if (a->precision == 0 && a->packed_x3 && a->scatter_x3) {
             NetX3 n; if ((rc = tn_build_netx3(&a->desc, &n))) return rc;
             f.scatter3 = a->scatter_x3; f.width3 = a->scatter_x3_width; f.packed3 = const_cast<void*>(a->packed_x3);
-            f.x3_elems = (int64_t)n.n_rec * n.rec_frags * 512; f.x3_bias_off_bytes = n.bias_off;
+            f.x3_elems = (int64_t)(n.n_rec + n.n_bw_rec) * n.rec_frags * 512; f.x3_bias_off_bytes = n.bias_off;
         }
     }
     return tn_launch_finish(f, stream);

@@ -91,9 +91,13 @@ struct NetX3 {
     int32_t NT, KH;               // n-tiles (hidden/32), hidden k-steps (hidden/16)
     int32_t rec_frags;            // NT * 3
     int32_t n_rec, n_stage;       // forward stream, per pass
+    int32_t n_bw_rec, n_bw_stage; // backward (dgrad) stream, per pass: starts at byte n_rec * rec_frags * 1024
     int32_t bias_off, n_bias;     // byte offset / count of the fp32 biases (depth*hidden + 4)
-    int64_t packed_bytes, pack_entries;     // pack_entries = n_rec * rec_frags * 512 + n_bias
+    int64_t packed_bytes, pack_entries;     // pack_entries = (n_rec + n_bw_rec) * rec_frags * 512 + n_bias
 };
+// Backward stream: heads^T (one record: fragment row 32t+i <-> feature, k-slot (h=0, e<4) <-> head row e = r,g,b,sigma; padded
+// to a whole stage), then for l = depth-1 .. 1 the hidden part of W_l transposed: hidden/16 records, fragment row 32t+i <->
+// input feature, k-slot (s,h,e) <-> output feature.
 
 #ifdef __cplusplus
 extern "C" {

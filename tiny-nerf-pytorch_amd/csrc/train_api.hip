@@ -37,7 +37,7 @@ extern "C" int tnerf_mlp_bwd(const tnerf_mlp_desc* d, const float* packed, int64
 }
 
 // dgrad + wgrad (+ slab reduction when reduce_table != NULL).  g_comp: dL/dcomp_rgb with row stride g_stride.
-static int train_bwd_impl(const char* who, const tnerf_mlp_desc* d, const float* packed, const RaySource& rs, const TnStepRef& sr,
+static int train_bwd_impl(const char* who, const tnerf_mlp_desc* d, const float* packed, const void* packed3, const RaySource& rs, const TnStepRef& sr,
                           int64_t R, int32_t S, const float* ztab, int32_t randomized, const float* t_rand, uint64_t seed,
                           uint64_t offset, int32_t white, const float* g_comp, int32_t g_stride, float* stash, int64_t Mp,
                           const int32_t* job_table, int64_t n_jobs, float* slabs, const int32_t* reduce_table, float* grads, hipStream_t s) {
@@ -50,7 +50,9 @@ static int train_bwd_impl(const char* who, const tnerf_mlp_desc* d, const float*
     a.L = f.L; a.packed = packed; a.stash = stash; a.Mp = Mp; a.rs = f.rs; a.R = R; a.sa = f.sa;
     a.sa.step = sr.step; a.sa.per_step = sr.per_step;
     a.white = white; a.g_comp = g_comp; a.g_stride = g_stride;
-    if ((rc = tn_launch_train_bwd(a, s))) return rc;
+    if (packed3 && !(d->flags & TNERF_FLAG_FP32_MFMA)) rc = tnx3_train_dgrad(who, a, d, packed3, s);
+    else                                                rc = tn_launch_train_bwd(a, s);
+    if (rc) return rc;
     if ((rc = tn_launch_wgrad(stash, a.L.stash_rows, R * S, job_table, n_jobs, slabs, sr.step, s, !(a.L.flags & TNERF_FLAG_FP32_MFMA)))) return rc;
     if (!reduce_table) return TNERF_OK;
     return tn_launch_reduce(slabs, reduce_table, a.L.n_params, grads, s);
@@ -61,7 +63,7 @@ extern "C" int tnerf_train_bwd_fused(const tnerf_mlp_desc* d, const float* packe
                                      uint64_t seed, uint64_t offset, int32_t white, const float* g_comp, float* stash, int64_t Mp,
                                      const int32_t* job_table, int64_t n_jobs, float* slabs, const int32_t* reduce_table,
                                      float* grads, tnerf_stream_t stream) {
-    return train_bwd_impl("tnerf_train_bwd_fused", d, packed, tn_table_source(rays_o, rays_d), TnStepRef{}, R, S, ztab, randomized, t_rand, seed, offset, white,
+    return train_bwd_impl("tnerf_train_bwd_fused", d, packed, nullptr, tn_table_source(rays_o, rays_d), TnStepRef{}, R, S, ztab, randomized, t_rand, seed, offset, white,
                           g_comp, 3, stash, Mp, job_table, n_jobs, slabs, reduce_table, grads, (hipStream_t)stream);
 }
 
@@ -77,6 +79,21 @@ extern "C" int tnerf_train_dgrad_fused(const tnerf_mlp_desc* d, const float* pac
     a.L = f.L; a.packed = packed; a.stash = stash; a.Mp = Mp; a.rs = f.rs; a.R = R; a.sa = f.sa;
     a.white = white; a.g_comp = g_comp; a.g_stride = 3;
     return tn_launch_train_bwd(a, (hipStream_t)stream);
+}
+
+extern "C" int tnerf_train_dgrad_fused_x3(const tnerf_mlp_desc* d, const void* packed_x3, const float* rays_o, const float* rays_d,
+                                          int64_t R, int32_t S, const float* ztab, int32_t randomized, const float* t_rand,
+                                          uint64_t seed, uint64_t offset, int32_t white, const float* g_comp, float* stash, int64_t Mp,
+                                          tnerf_stream_t stream) {
+    const char* who = "tnerf_train_dgrad_fused_x3";
+    FwdArgs f{};
+    int rc = tn_fused_args(who, f, d, reinterpret_cast<const float*>(packed_x3), tn_table_source(rays_o, rays_d), R, S, ztab, randomized, t_rand, seed, offset, white);
+    if (rc) return rc;
+    if (R < 1 || !g_comp || !stash || Mp < R * S) { tn_set_error("%s: R=%lld g_comp=%p stash=%p Mp=%lld", who, (long long)R, (const void*)g_comp, (void*)stash, (long long)Mp); return TNERF_EINVAL; }
+    BwdArgs a{};
+    a.L = f.L; a.packed = nullptr; a.stash = stash; a.Mp = Mp; a.rs = f.rs; a.R = R; a.sa = f.sa;
+    a.white = white; a.g_comp = g_comp; a.g_stride = 3;
+    return tnx3_train_dgrad(who, a, d, packed_x3, (hipStream_t)stream);
 }
 
 extern "C" int tnerf_wgrad(const tnerf_mlp_desc* d, const float* stash, int64_t Mp, int64_t M, const int32_t* job_table, int64_t n_jobs,
@@ -115,7 +132,7 @@ int tn_step32_core(const char* who, const tnerf_mlp_desc* d, const float* packed
     else
         rc = tn_train_fwd_impl(who, d, packed, rs, sr, loss, R, S, ztab, randomized, t_rand, seed, offset, white, comp_rgb, stash, Mp, stream);
     if (rc) return rc;
-    return train_bwd_impl(who, d, packed, rs, sr, R, S, ztab, randomized, t_rand, seed, offset, white, loss.ray_ws, 4, stash, Mp,
+    return train_bwd_impl(who, d, packed, packed3, rs, sr, R, S, ztab, randomized, t_rand, seed, offset, white, loss.ray_ws, 4, stash, Mp,
                           job_table, n_jobs, slabs, nullptr, nullptr, stream);
 }
 

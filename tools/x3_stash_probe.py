@@ -44,3 +44,16 @@ for tag in ("4x128", "8x256"):
         a = mA[l * (Mp + 32) * NT: l * (Mp + 32) * NT + M * NT]; b = mB[l * (Mp + 32) * NT: l * (Mp + 32) * NT + M * NT]
         x = (a ^ b)
         print(f"  mask[{l}] words differing {int((x != 0).sum())} of {a.numel()}, bits {int(sum(bin(int(v) & 0xffffffff).count('1') for v in x[x != 0][:2000]))}")
+    # ---- dgrad: both kernels on the fp32 forward's stash (same inputs), dZ rows compared
+    gc = torch.randn(R, 3, generator=g).to(dev) / (3 * R)
+    sC = sA.clone()
+    lib.call("tnerf_train_dgrad_fused", C.byref(st.desc), st.packed.data_ptr(), *common, gc.data_ptr(), sA.data_ptr(), plan.Mp, sp)
+    lib.call("tnerf_train_dgrad_fused_x3", C.byref(st.desc), x3.packed.data_ptr(), *common, gc.data_ptr(), sC.data_ptr(), plan.Mp, sp)
+    torch.cuda.synchronize()
+    A = sA[: (Mp // 32 + 1) * rows * 32].view(-1, rows, 32).cpu(); B = sC[: (Mp // 32 + 1) * rows * 32].view(-1, rows, 32).cpu()
+    r0 = 2 * NE + depth * H + 4
+    for l in range(depth):
+        da = A[:nb, r0:r0 + H].double(); db = B[:nb, r0:r0 + H].double()
+        print(f"  dZ[{l}]      max diff {float((da - db).abs().max()):.3e}  rel L2 {float((da - db).norm() / da.norm()):.3e}  max {float(da.abs().max()):.3e}")
+        r0 += H
+    print("  dzh rows   ", float((A[:nb, r0:r0 + 4] - B[:nb, r0:r0 + 4]).abs().max()), "max", float(A[:nb, r0:r0 + 4].abs().max()))
