@@ -46,7 +46,10 @@ L_FREQS, HIDDEN, DEPTH, SKIP = 6, 256, 8, 4
 RAYS, SAMPLES, NEAR, FAR, LR = 4096, 64, 2.0, 6.0, 5e-4
 PEAK_F32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: 256 CU x 2.4 GHz x 256 FLOP/clk/CU
 PEAK_BF16_MFMA_TFLOPS = 2516.6      # 16x the fp32 MFMA rate (v_mfma_f32_32x32x16_bf16: 32 cycles per 32768 FLOP per SIMD)
+PEAK_X3_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6      # an exact fp32 product = 6 bf16 MFMA partial products
 PEAK_HBM_GBS = 8000.0
+# what the fp32 fused paths are priced against: the split-bf16 chain unless TNERF_FP32_PIPE selects the plain fp32 MFMA kernels
+FP32_PATH_PEAK = PEAK_F32_MFMA_TFLOPS if os.environ.get("TNERF_FP32_PIPE", "").lower() in ("mfma32", "fp32", "mfma") else PEAK_X3_TFLOPS
 
 
 def mlp_macs(in_dim, hidden, depth, skip):
@@ -354,6 +357,15 @@ def run(args):
                 "wgrad": lambda: lib.call("tnerf_wgrad", C.byref(st.desc), plan.stash.data_ptr(), plan.Mp, R * S, plan.jobs.data_ptr(), plan.n_jobs, plan.slabs.data_ptr(), sp),
                 "reduce": lambda: lib.call("tnerf_wgrad_reduce", plan.slabs.data_ptr(), plan.reduce.data_ptr(), st.n_params, st.grad.data_ptr(), sp),
             }
+            if st.x3_capable and not (st.desc.flags & lib.FLAG_FP32_MFMA):
+                # the chain kernels the step actually launches: fp32 products formed exactly on the bf16 matrix pipe
+                for k_ in ("render_fwd", "train_fwd", "dgrad"):
+                    calls[k_ + "_fp32_mfma"] = calls[k_]
+                x3 = st.repack_x3(("bench", id(st)))
+                cx = (C.byref(st.desc), x3.packed.data_ptr()) + common[2:]
+                calls["render_fwd"] = lambda: lib.call("tnerf_render_fused_x3", *cx, comp.data_ptr(), dep.data_ptr(), acc_.data_ptr(), sp)
+                calls["train_fwd"] = lambda: lib.call("tnerf_train_fwd_fused_x3", *cx, comp.data_ptr(), plan.stash.data_ptr(), plan.Mp, sp)
+                calls["dgrad"] = lambda: lib.call("tnerf_train_dgrad_fused_x3", *cx, gws.data_ptr(), plan.stash.data_ptr(), plan.Mp, sp)
             d32 = lib.MlpDesc(st.desc.in_dim, st.desc.hidden, st.desc.depth, st.desc.skip_at, lib.FLAG_FP32_MFMA)
             calls["wgrad_fp32_mfma"] = lambda: lib.call("tnerf_wgrad", C.byref(d32), plan.stash.data_ptr(), plan.Mp, R * S, plan.jobs.data_ptr(), plan.n_jobs, plan.slabs.data_ptr(), sp)
         else:
@@ -373,17 +385,28 @@ def run(args):
         kern = kernel_section(model.hip_state(), RAYS, SAMPLES, "fp32")
         fl = algorithmic_flops()
         step_kernels = ("train_fwd", "dgrad", "wgrad")
-        dom = max(step_kernels, key=lambda k: kern[k])
+        x3 = "train_fwd_fp32_mfma" in kern
+        chain = ("train_fwd", "dgrad")
+        dom = max(chain, key=lambda k: kern[k])                      # the MFMA-bound kernels of the step (wgrad is HBM-bound, below)
         ach = fl[dom] / (kern[dom] * 1e-3) / 1e12
+        peak = PEAK_X3_TFLOPS if x3 else PEAK_F32_MFMA_TFLOPS
         cap = measured_traffic("r02_traffic.json")
-        out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                           "frac": ach / PEAK_F32_MFMA_TFLOPS,
+        out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                           "frac": ach / peak,
                            "traffic": cap[dom]["hbm_bytes"] if cap and dom in cap else None,
                            "traffic_source": f"profiles/r02_traffic.json (PMC passes on kernel sources {cap['kernel_source_sha']})" if cap and dom in cap else None,
-                           "flops_per_launch": fl[dom], "ms_per_launch": kern[dom]}
-        fl["wgrad_fp32_mfma"] = fl["wgrad"]
+                           "flops_per_launch": fl[dom], "ms_per_launch": kern[dom],
+                           "note": ("algorithmic fp32 FLOP per launch; each product runs as 6 bf16 MFMA partial products (exact 3-way split), "
+                                    "so the ceiling is the dense bf16 MFMA peak / 6 = %.1f TFLOP/s; executed bf16 rate = 6 x achieved" % PEAK_X3_TFLOPS)
+                                   if x3 else "fp32 MFMA"}
+        for k_ in list(kern):
+            if k_.endswith("_fp32_mfma"):
+                fl[k_] = fl[k_[:-len("_fp32_mfma")]]
+        def _peak(k_):
+            return PEAK_F32_MFMA_TFLOPS if (k_.endswith("_fp32_mfma") or not x3) else PEAK_X3_TFLOPS
         out["kernels"] = {k: {"ms": kern[k], "tflops": (fl[k] / (kern[k] * 1e-3) / 1e12) if k in fl else None,
-                              "mfma_frac": (fl[k] / (kern[k] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS) if k in fl else None} for k in kern}
+                              "mfma_frac": (fl[k] / (kern[k] * 1e-3) / 1e12 / _peak(k)) if k in fl else None,
+                              "mfma_peak": _peak(k) if k in fl else None} for k in kern}
         # the weight-gradient kernel runs its products on the bf16 matrix pipe (exact 3-way split): it is HBM-bound — its own roofline
         m_ = RAYS * SAMPLES
         wg_bytes = m_ * 4 * ((HIDDEN + 64) * 2 + (DEPTH - 1) * 2 * HIDDEN + 32 + HIDDEN)        # every job class reads its A and B rows of the stash once
@@ -395,7 +418,7 @@ def run(args):
         out["kernels"]["wgrad_fp32_mfma"]["matrix_pipe"] = "fp32 MFMA (TNERF_FLAG_FP32_MFMA)"
         if args.scaling == "weak" or world == 1:
             step_flops = sum(fl[k] for k in step_kernels)
-            out["step_mfma_frac"] = step_flops / (ms_per_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS
+            out["step_mfma_frac"] = step_flops / (ms_per_step * 1e-3) / 1e12 / peak
             out["step_minus_big3_us"] = (ms_per_step - sum(kern[k] for k in step_kernels)) * 1e3
 
     def psnr_block(mdl, extra=None):
@@ -489,7 +512,7 @@ def run(args):
                 d_ = timed(warm, steps)
                 f, dg, wg = mlp_macs(6 * L + 3, hidden, depth, skip)
                 flops = 2 * (f + dg + wg) * (h0 - l0) * samples
-                peak = PEAK_F32_MFMA_TFLOPS if prec == "fp32" else PEAK_BF16_MFMA_TFLOPS
+                peak = FP32_PATH_PEAK if prec == "fp32" else PEAK_BF16_MFMA_TFLOPS
                 res[prec] = {"ms_per_step": d_ / steps * 1e3, "rays_per_s": Rg * steps / d_,
                              "mfma_frac": flops / (d_ / steps) / 1e12 / peak}
                 del mdl, op, t_
@@ -511,7 +534,7 @@ def run(args):
                 d_ = float(t.item())
             rays_s = h * w * len(pose_list) / d_
             f, _, _ = mlp_macs(enc.out_dim, mdl.hidden, mdl.depth, mdl.skip_at)
-            peak = PEAK_F32_MFMA_TFLOPS if prec == "fp32" else PEAK_BF16_MFMA_TFLOPS
+            peak = FP32_PATH_PEAK if prec == "fp32" else PEAK_BF16_MFMA_TFLOPS
             return {"ms_per_image": d_ / len(pose_list) * 1e3, "rays_per_s": rays_s, "images": len(pose_list),
                     "mfma_frac": 2 * f * samples * rays_s / world / 1e12 / peak,
                     "hbm_frac": 12.0 * rays_s / world / 1e9 / PEAK_HBM_GBS, "finite": bool(torch.isfinite(img_).all())}

@@ -194,14 +194,16 @@ int tnerf_train_fwd_fused(const tnerf_mlp_desc* d, const float* packed,
                           tnerf_stream_t stream);
 
 /* Training backward: given g_comp = dL/dcomp_rgb [R,3], overwrite grads [n_params]
- * (what loss.backward() accumulates, train.py:126).  Same sampling arguments as the forward. */
+ * (what loss.backward() accumulates, train.py:126).  Same sampling arguments as the forward.
+ * packed_x3: NULL, or the tnerf_mlp_pack_x3 stream of the same parameters — the dgrad chain then runs on the bf16 matrix
+ * pipe (exact split) unless desc.flags has TNERF_FLAG_FP32_MFMA. */
 int tnerf_train_bwd_fused(const tnerf_mlp_desc* d, const float* packed,
                           const float* rays_o, const float* rays_d, int64_t n_rays, int32_t n_samples,
                           const float* ztab, int32_t randomized, const float* t_rand,
                           uint64_t seed, uint64_t offset, int32_t white_bkgd,
                           const float* g_comp, float* stash, int64_t stash_row_stride,
                           const int32_t* job_table, int64_t n_jobs, float* slabs,
-                          const int32_t* reduce_table, float* grads, tnerf_stream_t stream);
+                          const int32_t* reduce_table, float* grads, const void* packed_x3, tnerf_stream_t stream);
 
 /* The three stages of tnerf_train_bwd_fused as separate calls (same arguments; used to time each kernel):
  *   dgrad : composite backward + register-resident dgrad chain, fills the dZ rows of the stash

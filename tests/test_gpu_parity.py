@@ -276,8 +276,13 @@ def test_train_gradients_match_oracle(mods, dev, tag):
     c2, _, _, _ = mods["volume"].volume_render(rgb.reshape(-1, S, 3), sig.reshape(-1, S, 1), z, rd.to(dev))
     assert float((c2 - comp).abs().max()) <= 2e-5
     torch.mean((c2 - tgt.to(dev)) ** 2).backward()
+    # (the fused op runs the split-bf16 chain, the per-function ops the fp32 MFMA: two fp32 evaluations, each judged against fp64)
+    g_unf = flat([q.grad.cpu() for q in m2.parameters()])
+    l2_unf = float((g_unf - g_ref).norm() / g_ref.norm())
+    assert l2_unf <= 2.0 * l2_cpu + 1e-6, (l2_unf, l2_cpu)
+    assert float((g_unf - g_hip).norm() / g_ref.norm()) <= 2.0 * l2_cpu + 1e-6
     for p, q in zip(plist, m2.parameters()):
-        assert relmax(q.grad, p.grad) <= 2e-4
+        assert relmax(q.grad, p.grad) <= 1e-2
 
 
 @pytest.mark.parametrize("tag", ["4x128", "8x256"])

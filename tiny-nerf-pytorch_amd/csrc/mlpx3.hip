@@ -160,6 +160,22 @@ struct BwdX3Args {
     const unsigned char* packed3;
 };
 
+// The sign words of one layer for this lane: fetched with an asm load so that the wait can be COUNTED (a compiler-placed
+// vmcnt(0) would drain the weight ring).  The wait takes the load's own destination registers: nothing may read (or copy)
+// them before it.
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+template <int NW> struct TxMask;
+template <> struct TxMask<4> {
+    u32x4 v;
+    __device__ __forceinline__ void fetch(const uint32_t* q) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(q) : "memory"); }
+    template <int N> __device__ __forceinline__ void wait() { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(v) : "n"(N) : "memory"); }
+};
+template <> struct TxMask<2> {
+    u32x2 v;
+    __device__ __forceinline__ void fetch(const uint32_t* q) { asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(v) : "v"(q) : "memory"); }
+    template <int N> __device__ __forceinline__ void wait() { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(v) : "n"(N) : "memory"); }
+};
+
 // dzh[4]: this lane's head gradients (r,g,b,sigma pre-activation) for sample m.
 template <int HID>
 __device__ __forceinline__ void tx_bwd_tile(PipeX& p, const unsigned char* lds, const BwdX3Args& a, const float (&dzh)[4], int64_t m, bool valid,
@@ -188,20 +204,28 @@ __device__ __forceinline__ void tx_bwd_tile(PipeX& p, const unsigned char* lds, 
     }
     f32x16 acc[NT];
     uint32_t mw[NT / 2];
+    // The sign words of a layer are fetched before the layer walk that produces its dH and waited for with a COUNTED wait
+    // after it (the walk's last boundaries issued `after` younger DMAs; a compiler-placed vmcnt(0) would drain the weight ring).
+    TxMask<NT / 2> mk;
+    auto mask_fetch = [&](int l) TN_INLINE_LAMBDA { mk.fetch(mrow + (int64_t)l * (Mp + 32) * NT); };
     auto fin_layer = [&](int l) TN_INLINE_LAMBDA {                 // acc = dH_l  ->  dZ_l (masked, stashed, split into X)
-#pragma unroll
-        for (int w = 0; w < NT / 2; ++w) mw[w] = mrow[(int64_t)l * (Mp + 32) * NT + w];
         float* __restrict__ zrow = pl + L.dz_row0[l] * 32;
+#pragma unroll
+        for (int w = 0; w < NT / 2; ++w) mw[w] = mk.v[w];
         tx_layer_epilogue_bwd<HID>(acc, mw, X, [&](auto tc, const float (&v)[16]) TN_INLINE_LAMBDA {
             constexpr int t = decltype(tc)::value;
 #pragma unroll
             for (int r = 0; r < 16; ++r) TN_STASH_STORE(&zrow[(32 * t + (r & 3) + 8 * (r >> 2)) * 32], v[r]);
         });
     };
-    tx_layer_mfma<HID, 4, ST>(p, lds, X, Z, acc);                  // heads^T
+    mask_fetch(depth - 1);
+    tx_layer_mfma<HID, 4, ST>(p, lds, X, Z, acc);                  // heads^T (one boundary)
+    mk.template wait<TX_DPW>();
     fin_layer(depth - 1);
     for (int l = depth - 1; l >= 1; --l) {
-        tx_layer_mfma<HID, 1, ST>(p, lds, X, Z, acc);              // dH_{l-1} = W_l^T dZ_l
+        mask_fetch(l - 1);
+        tx_layer_mfma<HID, 1, ST>(p, lds, X, Z, acc);              // dH_{l-1} = W_l^T dZ_l (>= TX_LEAD boundaries)
+        mk.template wait<TX_DPW * TX_LEAD>();
         fin_layer(l - 1);
     }
 }

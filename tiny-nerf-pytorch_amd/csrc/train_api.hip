@@ -62,8 +62,8 @@ extern "C" int tnerf_train_bwd_fused(const tnerf_mlp_desc* d, const float* packe
                                      int64_t R, int32_t S, const float* ztab, int32_t randomized, const float* t_rand,
                                      uint64_t seed, uint64_t offset, int32_t white, const float* g_comp, float* stash, int64_t Mp,
                                      const int32_t* job_table, int64_t n_jobs, float* slabs, const int32_t* reduce_table,
-                                     float* grads, tnerf_stream_t stream) {
-    return train_bwd_impl("tnerf_train_bwd_fused", d, packed, nullptr, tn_table_source(rays_o, rays_d), TnStepRef{}, R, S, ztab, randomized, t_rand, seed, offset, white,
+                                     float* grads, const void* packed_x3, tnerf_stream_t stream) {
+    return train_bwd_impl("tnerf_train_bwd_fused", d, packed, packed_x3, tn_table_source(rays_o, rays_d), TnStepRef{}, R, S, ztab, randomized, t_rand, seed, offset, white,
                           g_comp, 3, stash, Mp, job_table, n_jobs, slabs, reduce_table, grads, (hipStream_t)stream);
 }
 

@@ -81,7 +81,7 @@ SIGNATURES = {
     "tnerf_render_fused": (C.c_int, [_DESC, _P, _P, _P, _I64, _I32, _P, _I32, _P, _U64, _U64, _I32, _P, _P, _P, _P]),
     "tnerf_train_fwd_fused": (C.c_int, [_DESC, _P, _P, _P, _I64, _I32, _P, _I32, _P, _U64, _U64, _I32, _P, _P, _I64, _P]),
     "tnerf_train_bwd_fused": (C.c_int, [_DESC, _P, _P, _P, _I64, _I32, _P, _I32, _P, _U64, _U64, _I32, _P, _P, _I64,
-                                        _P, _I64, _P, _P, _P, _P]),
+                                        _P, _I64, _P, _P, _P, _P, _P]),
     "tnerf_train_dgrad_fused": (C.c_int, [_DESC, _P, _P, _P, _I64, _I32, _P, _I32, _P, _U64, _U64, _I32, _P, _P, _I64, _P]),
     "tnerf_wgrad": (C.c_int, [_DESC, _P, _I64, _I64, _P, _I64, _P, _P]),
     "tnerf_wgrad_reduce": (C.c_int, [_P, _P, _I64, _P, _P]),

@@ -453,20 +453,32 @@ class _FusedRaysFn(torch.autograd.Function):
         dev = st.device
         R = rays_o.shape[0]
         comp = torch.empty(R, 3, dtype=torch.float32, device=dev)
+        # the x3 chain (same fp32 results, products on the bf16 matrix pipe) whenever the model allows it; its record stream
+        # follows the fp32 pack's key (the caller packed for the current parameter versions)
+        x3 = None
+        if st.x3_capable and not (st.desc.flags & _l.FLAG_FP32_MFMA):
+            x3 = st.repack_x3(("pack", st.packed_key) if st.packed_key is not None else None)
         if train:
             plan = st.plan(R * S)
             lease = plan.lease()
-            _l.call("tnerf_train_fwd_fused", C.byref(st.desc), st.packed.data_ptr(), rays_o.data_ptr(), rays_d.data_ptr(), R, S,
-                    ztab.data_ptr(), rnd, _ptr(t_rand), seed, off, white, comp.data_ptr(), lease.buf.data_ptr(), plan.Mp,
-                    _stream(dev))
+            if x3 is not None:
+                _l.call("tnerf_train_fwd_fused_x3", C.byref(st.desc), x3.packed.data_ptr(), rays_o.data_ptr(), rays_d.data_ptr(), R, S,
+                        ztab.data_ptr(), rnd, _ptr(t_rand), seed, off, white, comp.data_ptr(), lease.buf.data_ptr(), plan.Mp,
+                        _stream(dev))
+            else:
+                _l.call("tnerf_train_fwd_fused", C.byref(st.desc), st.packed.data_ptr(), rays_o.data_ptr(), rays_d.data_ptr(), R, S,
+                        ztab.data_ptr(), rnd, _ptr(t_rand), seed, off, white, comp.data_ptr(), lease.buf.data_ptr(), plan.Mp,
+                        _stream(dev))
             ctx.save_for_backward(rays_o, rays_d, ztab, t_rand if t_rand is not None else ztab)
             ctx.args = (st, plan, R, S, rnd, t_rand is not None, seed, off, white)
+            ctx.x3 = x3
             ctx.lease = lease
             ctx.shapes = [p.shape for p in params]
             return comp, None, None
         depth = torch.empty(R, 1, dtype=torch.float32, device=dev)
         acc = torch.empty(R, 1, dtype=torch.float32, device=dev)
-        _l.call("tnerf_render_fused", C.byref(st.desc), st.packed.data_ptr(), rays_o.data_ptr(), rays_d.data_ptr(), R, S,
+        _l.call("tnerf_render_fused_x3" if x3 is not None else "tnerf_render_fused", C.byref(st.desc),
+                (x3 if x3 is not None else st).packed.data_ptr(), rays_o.data_ptr(), rays_d.data_ptr(), R, S,
                 ztab.data_ptr(), rnd, _ptr(t_rand), seed, off, white, comp.data_ptr(), depth.data_ptr(), acc.data_ptr(), _stream(dev))
         ctx.args = None
         return comp, depth, acc
@@ -485,7 +497,7 @@ class _FusedRaysFn(torch.autograd.Function):
         _l.call("tnerf_train_bwd_fused", C.byref(st.desc), st.packed.data_ptr(), rays_o.data_ptr(), rays_d.data_ptr(), R, S,
                 ztab.data_ptr(), rnd, t_rand.data_ptr() if has_tr else None, seed, off, white, g_comp.data_ptr(),
                 lease.buf.data_ptr(), plan.Mp, plan.jobs.data_ptr(), plan.n_jobs, plan.slabs.data_ptr(), plan.reduce.data_ptr(),
-                st.grad.data_ptr(), _stream(dev))
+                st.grad.data_ptr(), ctx.x3.packed.data_ptr() if ctx.x3 is not None else None, _stream(dev))
         grads = [st.grad[o:o + int(np.prod(s))].view(s).clone() for s, o in zip(ctx.shapes, st.offsets)]
         lease.release()
         return (None,) * 11 + tuple(grads)
@@ -525,8 +537,9 @@ def camera_struct(c2w: torch.Tensor, H: int, W: int, focal: float, pix_index: Op
 def render_camera_fused(st: ModelState, c2w, H, W, focal, pix_first, n_rays, near, far, n_samples, white_bkgd=True,
                         randomized=False, t_rand=None, philox=None, x3_key=None):
     """Inference render of pixels pix_first .. pix_first+n_rays-1 of one pose: rays are generated in the kernel
-    (no get_rays launch, no ray tables).  Returns (comp_rgb, depth, acc).  x3_key (the parameters' version tuple): run the
-    x3 chain kernel — same fp32 results, the matrix work on the bf16 pipe; None: the fp32-MFMA kernel on st.packed."""
+    (no get_rays launch, no ray tables).  Returns (comp_rgb, depth, acc).  Runs the x3 chain kernel (fp32 results,
+    the matrix work on the bf16 pipe) unless the model's flags select the fp32-MFMA kernels; x3_key names the parameter
+    versions its record stream was packed for (None: the key st.packed was packed with)."""
     dev = st.device
     S = int(n_samples)
     ztab = depth_table(near, far, S, dev)
@@ -535,7 +548,9 @@ def render_camera_fused(st: ModelState, c2w, H, W, focal, pix_first, n_rays, nea
     comp = torch.empty(n_rays, 3, dtype=torch.float32, device=dev)
     depth = torch.empty(n_rays, 1, dtype=torch.float32, device=dev)
     acc = torch.empty(n_rays, 1, dtype=torch.float32, device=dev)
-    if x3_key is not None and st.x3_capable and not (st.desc.flags & _l.FLAG_FP32_MFMA):
+    if st.x3_capable and not (st.desc.flags & _l.FLAG_FP32_MFMA):
+        if x3_key is None and st.packed_key is not None:
+            x3_key = ("pack", st.packed_key)
         b = st.repack_x3(x3_key)              # fp32 results, products formed exactly on the bf16 matrix pipe
         _l.call("tnerf_render_fused_cam_x3", C.byref(st.desc), b.packed.data_ptr(), C.byref(cam), int(n_rays), S, ztab.data_ptr(), rnd,
                 _ptr(tr), seed, off, int(bool(white_bkgd)), comp.data_ptr(), depth.data_ptr(), acc.data_ptr(), _stream(dev))
