@@ -377,12 +377,27 @@ def run(args):
                 "dgrad": lambda: lib.call("tnerf_train_dgrad_fused_bf16", *common, gws.data_ptr(), bp.stash.data_ptr(), sp),
                 "wgrad": lambda: lib.call("tnerf_wgrad_bf16", C.byref(st.desc), bp.stash.data_ptr(), bp.n_tiles, bp.jobs.data_ptr(), bp.n_jobs, bp.slabs.data_ptr(), sp),
             }
-        return {name: event_ms(fn, reps) for name, fn in calls.items()}
+        iso = {name: event_ms(fn, reps) for name, fn in calls.items()}
+        # the step's kernels in step order, back to back (what they cost INSIDE a step: the chip's clock depends on what ran just
+        # before); events between the launches.  These are the durations the roofline uses; rocprofv3's per-kernel
+        # averages of a bench run mix both situations.
+        order = [k for k in ("train_fwd", "dgrad", "wgrad", "reduce") if k in calls]
+        for k in order:
+            calls[k]()
+        torch.cuda.synchronize()
+        marks = [[torch.cuda.Event(enable_timing=True) for _ in range(len(order) + 1)] for _ in range(reps)]
+        for row in marks:
+            row[0].record()
+            for i, k in enumerate(order):
+                calls[k](); row[i + 1].record()
+        torch.cuda.synchronize()
+        seq = {k: float(np.mean([row[i].elapsed_time(row[i + 1]) for row in marks])) for i, k in enumerate(order)}
+        return {name: seq.get(name, ms) for name, ms in iso.items()}, iso
 
     if rank == 0:
         # ---- per-kernel times, live, HIP events on the launch stream (torch's current stream)
         model._ensure_packed()
-        kern = kernel_section(model.hip_state(), RAYS, SAMPLES, "fp32")
+        kern, kern_iso = kernel_section(model.hip_state(), RAYS, SAMPLES, "fp32")
         fl = algorithmic_flops()
         step_kernels = ("train_fwd", "dgrad", "wgrad")
         x3 = "train_fwd_fp32_mfma" in kern
@@ -396,6 +411,7 @@ def run(args):
                            "traffic": cap[dom]["hbm_bytes"] if cap and dom in cap else None,
                            "traffic_source": f"profiles/r02_traffic.json (PMC passes on kernel sources {cap['kernel_source_sha']})" if cap and dom in cap else None,
                            "flops_per_launch": fl[dom], "ms_per_launch": kern[dom],
+                           "frac_of_fp32_mfma_peak": ach / PEAK_F32_MFMA_TFLOPS,      # north_star's yardstick (157.3 TFLOP/s): > 1 on the bf16 pipe
                            "note": ("algorithmic fp32 FLOP per launch; each product runs as 6 bf16 MFMA partial products (exact 3-way split), "
                                     "so the ceiling is the dense bf16 MFMA peak / 6 = %.1f TFLOP/s; executed bf16 rate = 6 x achieved" % PEAK_X3_TFLOPS)
                                    if x3 else "fp32 MFMA"}
@@ -406,7 +422,9 @@ def run(args):
             return PEAK_F32_MFMA_TFLOPS if (k_.endswith("_fp32_mfma") or not x3) else PEAK_X3_TFLOPS
         out["kernels"] = {k: {"ms": kern[k], "tflops": (fl[k] / (kern[k] * 1e-3) / 1e12) if k in fl else None,
                               "mfma_frac": (fl[k] / (kern[k] * 1e-3) / 1e12 / _peak(k)) if k in fl else None,
-                              "mfma_peak": _peak(k) if k in fl else None} for k in kern}
+                              "mfma_peak": _peak(k) if k in fl else None, "ms_alone": kern_iso[k]} for k in kern}
+        out["kernels"]["_timing"] = ("ms: HIP events between the launches of train_fwd -> dgrad -> wgrad -> reduce issued back to back in step "
+                                     "order (the other entries: alone); ms_alone: the same launch repeated on its own")
         # the weight-gradient kernel runs its products on the bf16 matrix pipe (exact 3-way split): it is HBM-bound — its own roofline
         m_ = RAYS * SAMPLES
         wg_bytes = m_ * 4 * ((HIDDEN + 64) * 2 + (DEPTH - 1) * 2 * HIDDEN + 32 + HIDDEN)        # every job class reads its A and B rows of the stash once
@@ -453,7 +471,7 @@ def run(args):
                "value": R_global * args.steps / dt16, "unit": "rays/s", "speedup_vs_fp32_step": dt / dt16}
         if rank == 0:
             st = model16.hip_state()
-            k16 = kernel_section(st, RAYS, SAMPLES, "bf16")
+            k16, k16_alone = kernel_section(st, RAYS, SAMPLES, "bf16")
             fl = algorithmic_flops()
             # algorithmic HBM bytes of the stash streams: 2 KB per (32-sample tile, 32-feature tile) of bf16
             # activations / activation gradients; the forward also writes the ReLU bits and the head outputs
@@ -466,7 +484,8 @@ def run(args):
             cap16 = measured_traffic("r02_traffic_bf16.json") or {}
             kern16 = {}
             for name, ms in k16.items():
-                kern16[name] = {"ms": ms, "tflops": fl[name] / (ms * 1e-3) / 1e12, "mfma_frac": fl[name] / (ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS}
+                kern16[name] = {"ms": ms, "ms_alone": k16_alone[name], "tflops": fl[name] / (ms * 1e-3) / 1e12,
+                                "mfma_frac": fl[name] / (ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS}
                 if name in hbm:
                     kern16[name].update(algorithmic_hbm_bytes=hbm[name], hbm_gbs=hbm[name] / (ms * 1e-3) / 1e9,
                                         hbm_frac=hbm[name] / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS,

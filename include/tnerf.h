@@ -49,13 +49,15 @@ typedef struct tnerf_mlp_desc {
     int32_t skip_at;
     int32_t flags;           /* TNERF_FLAG_* (ABI 2); 0 = defaults                                */
 } tnerf_mlp_desc;
-/* How the fp32 WEIGHT-GRADIENT kernel (tnerf_wgrad, inside tnerf_mlp_bwd / tnerf_train_*) forms its fp32 products.
+/* How the fp32 kernels of the fused paths form their fp32 products: the weight-gradient kernel (tnerf_wgrad, inside
+ * tnerf_mlp_bwd / tnerf_train_*) and, wherever a tnerf_mlp_pack_x3 stream is passed (the *_x3 entry points, the packed_x3
+ * arguments), the forward and dgrad chain kernels.
  * Default (0): on the bf16 matrix pipe by EXACT three-way splitting — an fp32 value is the sum of three bf16 numbers
  * (8+8+8 mantissa bits), a product of two bf16 numbers is exact in fp32, six v_mfma_f32_32x32x16_bf16 with fp32
  * accumulation carry a*b up to terms below 2^-24 |ab| — fp32-grade results (measured against fp64: at least as accurate
  * as an fp32 fma chain) at 6/16 of the fp32-MFMA time (CDNA4's bf16 matrix rate is 16x its fp32 rate).
- * TNERF_FLAG_FP32_MFMA selects v_mfma_f32_32x32x2_f32 (plain fp32 fma chains) instead.  The forward and dgrad chain
- * kernels always use fp32 MFMA. */
+ * TNERF_FLAG_FP32_MFMA selects v_mfma_f32_32x32x2_f32 (plain fp32 fma chains) for all of them instead; the entry points
+ * that take only the fp32 pack (tnerf_render_fused, tnerf_train_fwd_fused, tnerf_mlp_fwd, ...) always run those. */
 #define TNERF_FLAG_FP32_MFMA 1
 
 /* Sizes (in elements) of everything the caller must allocate for a model + sample count. */

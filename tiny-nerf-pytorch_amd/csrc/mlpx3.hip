@@ -7,6 +7,18 @@
 #include "mlpx3_core.hpp"
 #include "mlp_args.hpp"
 
+// Diagnostic builds (-DTN_STAMPS, tools/x3_stamp_probe.py): cycles a wave spends in the layer walks and in the epilogues, and the
+// shader clock (s_memtime / s_memrealtime).  The values go to a.f.stamps only; the product build has none of this.
+#ifdef TN_STAMPS
+struct TxProf { unsigned long long walk = 0, epi = 0, t = 0; };
+#define TX_PROF_BEGIN(pf) (pf).t = __builtin_amdgcn_s_memtime()
+#define TX_PROF_ADD(pf, field) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); (pf).field += n_ - (pf).t; (pf).t = n_; } while (0)
+#else
+struct TxProf {};
+#define TX_PROF_BEGIN(pf) do {} while (0)
+#define TX_PROF_ADD(pf, field) do {} while (0)
+#endif
+
 struct FwdX3Args {
     FwdArgs f;                      // layout (stash rows), ray source, sampling, outputs, stash, loss — as the fp32 kernels
     NetX3 n;
@@ -17,7 +29,7 @@ struct FwdX3Args {
 // sigmoid, sigma after ReLU (lane-half 0).
 template <int HID, bool TRAIN>
 __device__ __forceinline__ void tx_mlp_tile(PipeX& p, const unsigned char* lds, const FwdX3Args& a, int h, int lane, const EncX& E,
-                                            const float (&encf)[8 * TN16_KE], int64_t m, bool valid, float (&res)[4]) {
+                                            const float (&encf)[8 * TN16_KE], int64_t m, bool valid, float (&res)[4], TxProf& pf) {
     constexpr int NT = HID / 32;
     constexpr int ST = 0;                                          // stores allowed outstanding at a stage boundary
     const MlpLayout& L = a.f.L;
@@ -55,14 +67,20 @@ __device__ __forceinline__ void tx_mlp_tile(PipeX& p, const unsigned char* lds, 
             for (int w = 0; w < NT / 2; ++w) mrow[(int64_t)l * (Mp + 32) * NT + w] = mb[w];
         }
     };
+    TX_PROF_BEGIN(pf);
     tx_layer_mfma<HID, 0, ST>(p, lds, X, E, acc);
+    TX_PROF_ADD(pf, walk);
     fin_layer(0);
+    TX_PROF_ADD(pf, epi);
     for (int l = 1; l < depth; ++l) {
         if (l == skip_at) tx_layer_mfma<HID, 2, ST>(p, lds, X, E, acc);
         else              tx_layer_mfma<HID, 1, ST>(p, lds, X, E, acc);
+        TX_PROF_ADD(pf, walk);
         fin_layer(l);
+        TX_PROF_ADD(pf, epi);
     }
     tx_layer_mfma<HID, 3, ST>(p, lds, X, E, acc);
+    TX_PROF_ADD(pf, walk);
     // heads: rows 0..2 = rgb.0 (sigmoid), row 3 = sigma.0 (ReLU)                                   nerf.py:39-40
     const f32x4 hb = *reinterpret_cast<const f32x4*>(lds + TX_RING + depth * HID * 4);
 #pragma unroll
@@ -81,6 +99,10 @@ __global__ __launch_bounds__(256, 1) void k_renderx3(FwdX3Args a) {
     const int S = sa.S, Lf = a.n.Lf;
     PipeX p;
     tx_prologue(p, lds, a.packed3, a.n, a.packed3, a.n.n_stage, lane, wave);
+    TxProf pf;
+#ifdef TN_STAMPS
+    const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
     // Every wave of the workgroup runs the same number of network passes (the stage barriers are workgroup-wide): rays beyond
     // R are computed on a clamped index and stored nowhere (training: into the dump block).
@@ -108,7 +130,7 @@ __global__ __launch_bounds__(256, 1) void k_renderx3(FwdX3Args a) {
                 tx_encode(tn_point(ox, dx, z), tn_point(oy, dy, z), tn_point(oz, dz, z), Lf, h, E,
                           [&](auto stc, float val) TN_INLINE_LAMBDA { encf[decltype(stc)::value] = val; });
                 float res[4];
-                tx_mlp_tile<HID, TRAIN>(p, lds, a, h, lane, E, encf, rayc * S + sc, valid, res);
+                tx_mlp_tile<HID, TRAIN>(p, lds, a, h, lane, E, encf, rayc * S + sc, valid, res, pf);
                 const bool upper = (sb & 32) != 0;                            // wave-uniform
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -147,6 +169,12 @@ __global__ __launch_bounds__(256, 1) void k_renderx3(FwdX3Args a) {
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // no DMA may still be writing this workgroup's LDS at exit
+#ifdef TN_STAMPS
+    if (a.f.stamps && lane == 0) {
+        unsigned long long* o = a.f.stamps + (blockIdx.x * 4 + wave) * 8;
+        o[0] = __builtin_amdgcn_s_memtime() - st_c0; o[1] = __builtin_amdgcn_s_memrealtime() - st_r0; o[2] = pf.walk; o[3] = pf.epi;
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ dgrad
@@ -395,6 +423,17 @@ extern "C" int tnerf_render_fused_cam_x3(const tnerf_mlp_desc* d, const void* pa
     return renderx3_impl("tnerf_render_fused_cam_x3", d, packed3, rs, R, S, ztab, randomized, t_rand, seed, offset, white, comp, depth,
                          acc, stream);
 }
+
+#ifdef TN_STAMPS
+extern "C" int tnerf_debug_renderx3_stamps(const tnerf_mlp_desc* d, const void* packed3, const float* rays_o, const float* rays_d, int64_t R, int32_t S,
+                                           const float* ztab, float* comp, float* stash, int64_t Mp, long long* stamps, tnerf_stream_t stream) {
+    FwdX3Args a{};
+    int rc = x3_args("tnerf_debug_renderx3_stamps", a, d, packed3, tn_table_source(rays_o, rays_d), R, S, ztab, 0, nullptr, 0, 0, 1);
+    if (rc) return rc;
+    a.f.comp = comp; a.f.stash = stash; a.f.Mp = Mp; a.f.stamps = reinterpret_cast<unsigned long long*>(stamps);
+    return tnx3_launch_fwd(a, stash != nullptr, (hipStream_t)stream, "tnerf_debug_renderx3_stamps");
+}
+#endif
 
 // Training forward into the fp32 stash (tn_step32_core and tnerf_train_fwd_fused_x3 call this instead of the fp32-MFMA forward).
 int tnx3_train_fwd(const char* who, const tnerf_mlp_desc* d, const void* packed3, const RaySource& rs, const TnStepRef& sr,

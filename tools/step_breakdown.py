@@ -29,7 +29,7 @@ def ev(fn, reps=20):
     return float(np.mean([a.elapsed_time(b) for a, b in es]))
 
 
-for prec, peak in (("fp32", 157.3), ("bf16", 2516.6)):
+for prec, peak in (("fp32", 2516.6 / 6), ("bf16", 2516.6)):
     torch.manual_seed(0)
     m = nerf.TinyNeRF(in_dim, hidden, depth, skip).to(dev)
     with torch.no_grad(): m.sigma[0].bias += 0.5
@@ -52,6 +52,11 @@ for prec, peak in (("fp32", 157.3), ("bf16", 2516.6)):
                  "dgrad": lambda: lib.call("tnerf_train_dgrad_fused", *common, gws.data_ptr(), plan.stash.data_ptr(), plan.Mp, sp),
                  "wgrad": lambda: lib.call("tnerf_wgrad", C.byref(st.desc), plan.stash.data_ptr(), plan.Mp, R * S, plan.jobs.data_ptr(), plan.n_jobs, plan.slabs.data_ptr(), sp),
                  "reduce": lambda: lib.call("tnerf_wgrad_reduce", plan.slabs.data_ptr(), plan.reduce.data_ptr(), st.n_params, st.grad.data_ptr(), sp)}
+        if st.x3_capable and not (st.desc.flags & lib.FLAG_FP32_MFMA):          # what the step launches: the split-bf16 chain
+            x3 = st.repack_x3(("probe", 0)); cx = (C.byref(st.desc), x3.packed.data_ptr()) + common[2:]
+            calls.update({"render_fwd": lambda: lib.call("tnerf_render_fused_x3", *cx, comp.data_ptr(), dep.data_ptr(), acc.data_ptr(), sp),
+                          "train_fwd": lambda: lib.call("tnerf_train_fwd_fused_x3", *cx, comp.data_ptr(), plan.stash.data_ptr(), plan.Mp, sp),
+                          "dgrad": lambda: lib.call("tnerf_train_dgrad_fused_x3", *cx, gws.data_ptr(), plan.stash.data_ptr(), plan.Mp, sp)})
     else:
         b = st.repack_bf16(); bp = b.train_plan(R, S)
         common = (C.byref(st.desc), b.packed.data_ptr(), o.data_ptr(), d.data_ptr(), R, S, ztab.data_ptr(), 1, u.data_ptr(), 0, 0, 1)

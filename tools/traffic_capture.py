@@ -23,11 +23,14 @@ import bench  # noqa: E402  (kernel_source_sha, algorithmic sizes)
 
 # kernel-name prefix -> (json file, key, FETCH_SIZE correction factor: 2 = the loads are 16-B-per-lane coalesced streams)
 KERNELS = [
-    ("void k_render_fused<256, 20, true>", "fp32", "train_fwd", 1),
-    ("void k_train_bwd<256>", "fp32", "dgrad", 1),
+    ("void k_renderx3<256, true>", "fp32", "train_fwd", 1),
+    ("void k_dgradx3<256>", "fp32", "dgrad", 1),
+    ("void k_renderx3<256, false>", "fp32", "render_fwd", 1),
+    ("void k_render_fused<256, 20, true>", "fp32", "train_fwd_fp32_mfma", 1),
+    ("void k_train_bwd<256>", "fp32", "dgrad_fp32_mfma", 1),
     ("void k_wgrad<true>", "fp32", "wgrad", 2),
     ("void k_wgrad<false>", "fp32", "wgrad_fp32_mfma", 2),
-    ("void k_render_fused<256, 20, false>", "fp32", "render_fwd", 1),
+    ("void k_render_fused<256, 20, false>", "fp32", "render_fwd_fp32_mfma", 1),
     ("void k_finish<true, true>", "fp32", "finish", 1),
     ("void k_render16<256, true>", "bf16", "train_fwd", 1),
     ("void k_dgrad16<256>", "bf16", "dgrad", 1),
@@ -63,7 +66,8 @@ def main():
                      "wgrad": M * 4 * ((bench.HIDDEN + 64) * 2 + (bench.DEPTH - 1) * 2 * bench.HIDDEN + 32 + bench.HIDDEN),
                      "finish": 64 * 2 ** 20 + 8 * 4 * 481796, "render_fwd": bench.RAYS * 36},
             "bf16": {}}
-    algo["fp32"]["wgrad_fp32_mfma"] = algo["fp32"]["wgrad"]
+    for k_ in ("wgrad", "train_fwd", "dgrad", "render_fwd"):
+        algo["fp32"][k_ + "_fp32_mfma"] = algo["fp32"][k_]
     out = {"fp32": {}, "bf16": {}}
     for prefix, fam, key, corr in KERNELS:
         f = next((v for k, v in fetch.items() if k.startswith(prefix)), None)
