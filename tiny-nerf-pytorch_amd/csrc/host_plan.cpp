@@ -683,14 +683,14 @@ extern "C" int tn_build_netx3(const tnerf_mlp_desc* d, NetX3* n) {
     memset(n, 0, sizeof(*n));
     const int H = d->hidden <= 128 ? 128 : 256;                            // the kernel width (zero-padded weights, see check_desc)
     n->in_dim = d->in_dim; n->hidden = H; n->depth = d->depth; n->skip_at = d->skip_at; n->Lf = (d->in_dim - 3) / 6;
-    n->NT = H / 32; n->KH = H / 16; n->rec_frags = n->NT * 3;
-    int rec = TN16_KE;
-    for (int l = 1; l < d->depth; ++l) rec += n->KH + ((d->skip_at > 0 && l == d->skip_at) ? TN16_KE : 0);
+    n->NT = H / 32; n->KH = H / 16; n->rec_frags = n->NT / 2 * 3;           // a record covers HALF of the output tiles
+    int rec = 2 * TN16_KE;
+    for (int l = 1; l < d->depth; ++l) rec += 2 * (n->KH + ((d->skip_at > 0 && l == d->skip_at) ? TN16_KE : 0));
     rec += n->KH;                                                           // heads
     if ((rec * n->rec_frags) % TX_STAGE != 0) { tn_set_error("x3 chain: the record stream is not a whole number of stages"); return TNERF_EUNSUPPORTED; }
     n->n_rec = rec; n->n_stage = rec * n->rec_frags / TX_STAGE;
     const int rps = TX_STAGE / n->rec_frags;                               // records per stage
-    n->n_bw_rec = rps + (d->depth - 1) * n->KH;                             // heads^T (padded to a stage) + transposed hidden layers
+    n->n_bw_rec = rps + (d->depth - 1) * 2 * n->KH;                         // heads^T (two records, padded to a stage) + transposed hidden layers
     if ((n->n_bw_rec * n->rec_frags) % TX_STAGE != 0) { tn_set_error("x3 chain: the backward record stream is not a whole number of stages"); return TNERF_EUNSUPPORTED; }
     n->n_bw_stage = n->n_bw_rec * n->rec_frags / TX_STAGE;
     n->bias_off = (rec + n->n_bw_rec) * n->rec_frags * 1024;
@@ -714,43 +714,47 @@ extern "C" int tnerf_x3_pack_table(const tnerf_mlp_desc* d, int32_t* T) {
     MlpLayout L; rc = tn_build_layout(d, &L); if (rc) return rc;
     if (!T) { tn_set_error("tnerf_x3_pack_table: NULL table"); return TNERF_EINVAL; }
     for (int64_t i = 0; i < n.pack_entries; ++i) T[i] = -1;
-    const int H = L.hidden, NT = n.NT, KH = n.KH, Lf = n.Lf;
+    const int H = L.hidden, NH = n.NT / 2, KH = n.KH, Lf = n.Lf;
     int64_t rec = 0;                                                        // running record index
-    // all three piece fragments of (record, tile t) refer to the same parameters: the pack kernel derives the piece from the
-    // fragment's position (fragment index mod 3)
-    auto put = [&](int t, int lane, int e, int64_t src) {
-        for (int piece = 0; piece < 3; ++piece) T[(((rec * NT + t) * 3 + piece) * 64 + lane) * 8 + e] = (int32_t)src;
+    // all three piece fragments of (record, tile slot tl) refer to the same parameters: the pack kernel derives the piece from
+    // the fragment's position (fragment index mod 3).  Tile slot tl of a half-h record is output tile h*NH + tl.
+    auto put = [&](int tl, int lane, int e, int64_t src) {
+        for (int piece = 0; piece < 3; ++piece) T[(((rec * NH + tl) * 3 + piece) * 64 + lane) * 8 + e] = (int32_t)src;
     };
     auto head_w = [&](int row, int k) -> int64_t { return row < 3 ? L.p_wc + (int64_t)row * H + k : (row == 3 ? L.p_ws + k : -1); };
     for (int l = 0; l < L.depth; ++l) {
         const int fan = L.fan_in[l];
         const bool skip = L.skip_at > 0 && l == L.skip_at;
-        if (l > 0)
-            for (int s = 0; s < KH; ++s, ++rec)
-                for (int t = 0; t < NT; ++t) for (int lane = 0; lane < 64; ++lane) for (int e = 0; e < 8; ++e)
-                    put(t, lane, e, L.p_w[l] + (int64_t)(32 * t + (lane & 31)) * fan + hid_feature16(s, lane >> 5, e));
-        if (l == 0 || skip)
-            for (int u = 0; u < TN16_KE; ++u, ++rec)
-                for (int t = 0; t < NT; ++t) for (int lane = 0; lane < 64; ++lane) for (int e = 0; e < 8; ++e) {
-                    const int c = enc_column16(Lf, u, lane >> 5, e);
-                    if (c >= 0) put(t, lane, e, L.p_w[l] + (int64_t)(32 * t + (lane & 31)) * fan + (l == 0 ? 0 : H) + c);
-                }
+        for (int half = 0; half < 2; ++half) {                              // half-pass A (tiles 0..NH-1), then B
+            if (l > 0)
+                for (int s = 0; s < KH; ++s, ++rec)
+                    for (int tl = 0; tl < NH; ++tl) for (int lane = 0; lane < 64; ++lane) for (int e = 0; e < 8; ++e)
+                        put(tl, lane, e, L.p_w[l] + (int64_t)(32 * (half * NH + tl) + (lane & 31)) * fan + hid_feature16(s, lane >> 5, e));
+            if (l == 0 || skip)
+                for (int u = 0; u < TN16_KE; ++u, ++rec)
+                    for (int tl = 0; tl < NH; ++tl) for (int lane = 0; lane < 64; ++lane) for (int e = 0; e < 8; ++e) {
+                        const int c = enc_column16(Lf, u, lane >> 5, e);
+                        if (c >= 0) put(tl, lane, e, L.p_w[l] + (int64_t)(32 * (half * NH + tl) + (lane & 31)) * fan + (l == 0 ? 0 : H) + c);
+                    }
+        }
     }
-    for (int s = 0; s < KH; ++s, ++rec)                                     // heads: tile 0 rows r,g,b (rgb.0), sigma.0
+    for (int s = 0; s < KH; ++s, ++rec)                                     // heads: tile slot 0 rows r,g,b (rgb.0), sigma.0
         for (int lane = 0; lane < 64; ++lane) for (int e = 0; e < 8; ++e) {
             const int64_t src = head_w(lane & 31, hid_feature16(s, lane >> 5, e));
             if (src >= 0) put(0, lane, e, src);
         }
     // ---- backward stream
     rec = n.n_rec;
-    for (int t = 0; t < NT; ++t)                                            // heads^T: dH[k] = sum_{row<4} W_head[row][k] dZh[row]
-        for (int lane = 0; lane < 32; ++lane) for (int e = 0; e < 4; ++e) put(t, lane, e, head_w(e, 32 * t + lane));
+    for (int half = 0; half < 2; ++half, ++rec)                             // heads^T: dH[k] = sum_{row<4} W_head[row][k] dZh[row]
+        for (int tl = 0; tl < NH; ++tl)
+            for (int lane = 0; lane < 32; ++lane) for (int e = 0; e < 4; ++e) put(tl, lane, e, head_w(e, 32 * (half * NH + tl) + lane));
     rec = n.n_rec + TX_STAGE / n.rec_frags;
     for (int l = L.depth - 1; l >= 1; --l) {
         const int fan = L.fan_in[l];
-        for (int s = 0; s < KH; ++s, ++rec)
-            for (int t = 0; t < NT; ++t) for (int lane = 0; lane < 64; ++lane) for (int e = 0; e < 8; ++e)
-                put(t, lane, e, L.p_w[l] + (int64_t)hid_feature16(s, lane >> 5, e) * fan + (32 * t + (lane & 31)));
+        for (int half = 0; half < 2; ++half)
+            for (int s = 0; s < KH; ++s, ++rec)
+                for (int tl = 0; tl < NH; ++tl) for (int lane = 0; lane < 64; ++lane) for (int e = 0; e < 8; ++e)
+                    put(tl, lane, e, L.p_w[l] + (int64_t)hid_feature16(s, lane >> 5, e) * fan + (32 * (half * NH + tl) + (lane & 31)));
     }
     int32_t* B = T + (int64_t)(n.n_rec + n.n_bw_rec) * n.rec_frags * 512;
     for (int l = 0; l < L.depth; ++l) for (int j = 0; j < H; ++j) B[l * H + j] = (int32_t)(L.p_b[l] + j);

@@ -46,41 +46,37 @@ __device__ __forceinline__ void tx_mlp_tile(PipeX& p, const unsigned char* lds, 
             if (st < L.NE) TN_STASH_STORE(&pl[(L.enc_row0 + 2 * st - 3 * h) * 32], encf[st]);
         });
     }
+    constexpr int NH = NT / 2, KH = HID / 16, NP = NH * 8;
     ActX<HID> X;
-    f32x16 acc[NT];
-    uint32_t mb[NT / 2];
-    auto fin_layer = [&](int l) TN_INLINE_LAMBDA {
-        float* __restrict__ srow = TRAIN ? pl + L.h_row0[l] * 32 : nullptr;
-        tx_layer_epilogue<HID>(lds, vb0 + l * HID * 4, acc, X, [&](auto tc, const float (&v)[16]) TN_INLINE_LAMBDA {
-            constexpr int t = decltype(tc)::value;
-            if constexpr (TRAIN) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) TN_STASH_STORE(&srow[(32 * t + (r & 3) + 8 * (r >> 2)) * 32], v[r]);
-                uint32_t msk = 0u;
-#pragma unroll
-                for (int r = 15; r >= 0; --r) msk = __builtin_amdgcn_alignbit(msk, __float_as_uint(v[r]) + 0x7FFFFFFFu, 31);
-                if constexpr ((t & 1) == 0) mb[t / 2] = msk; else mb[t / 2] |= msk << 16;
-            }
-        });
-        if constexpr (TRAIN) {
-#pragma unroll
-            for (int w = 0; w < NT / 2; ++w) mrow[(int64_t)l * (Mp + 32) * NT + w] = mb[w];
-        }
+    f32x16 accA[NH], accB[NH];
+    TxEpi es;
+    // per-lane stash pointers of the layer whose epilogue is running (training)
+    float* __restrict__ srow = nullptr; uint32_t* __restrict__ mword = nullptr;
+    uint32_t vbe = vb0;                                            // LDS offset of that layer's biases
+    auto point_at = [&](int l) TN_INLINE_LAMBDA {
+        vbe = vb0 + l * HID * 4;
+        if constexpr (TRAIN) { srow = pl + L.h_row0[l] * 32; mword = mrow + (int64_t)l * (Mp + 32) * NT; }
     };
+    auto epiA = [&](auto ic, auto jc, auto pc) TN_INLINE_LAMBDA { tx_epi_fwd<HID, 0, decltype(ic)::value, decltype(jc)::value, TRAIN, decltype(pc)::value>(accA, X, es, lds, vbe, srow, mword); };
+    auto epiB = [&](auto ic, auto jc, auto pc) TN_INLINE_LAMBDA { tx_epi_fwd<HID, 1, decltype(ic)::value, decltype(jc)::value, TRAIN, decltype(pc)::value>(accB, X, es, lds, vbe, srow, mword); };
+    auto none = [](auto) TN_INLINE_LAMBDA {};
     TX_PROF_BEGIN(pf);
-    tx_layer_mfma<HID, 0, ST>(p, lds, X, E, acc);
-    TX_PROF_ADD(pf, walk);
-    fin_layer(0);
-    TX_PROF_ADD(pf, epi);
+    // layer 0: half A bare, half A's epilogue behind half B
+    tx_pass<HID, 0, true>(p, lds, X, E, accA, none);
+    point_at(0);
+    tx_pass<HID, 0, true>(p, lds, X, E, accB, tx_window<0, TN16_KE * NH, NP>(epiA));
+    // layer l: half B's epilogue of layer l-1 behind the first half of pass A, half A's of layer l behind the second half of pass B
     for (int l = 1; l < depth; ++l) {
-        if (l == skip_at) tx_layer_mfma<HID, 2, ST>(p, lds, X, E, acc);
-        else              tx_layer_mfma<HID, 1, ST>(p, lds, X, E, acc);
-        TX_PROF_ADD(pf, walk);
-        fin_layer(l);
-        TX_PROF_ADD(pf, epi);
+        tx_pass<HID, 1, true>(p, lds, X, E, accA, tx_window<0, KH / 2 * NH, NP>(epiB));
+        if (l == skip_at) tx_pass<HID, 0, false>(p, lds, X, E, accA, none);                    // + W_l[:, hidden:] . encoding
+        point_at(l);
+        tx_pass<HID, 1, true>(p, lds, X, E, accB, tx_window<KH / 2 * NH * 6, KH / 2 * NH, NP>(epiA));
+        if (l == skip_at) tx_pass<HID, 0, false>(p, lds, X, E, accB, none);
     }
-    tx_layer_mfma<HID, 3, ST>(p, lds, X, E, acc);
+    // heads (tile slot 0 of accA): the last layer's half B epilogue must be through before k-step KH/2
+    tx_pass<HID, 3, true>(p, lds, X, E, accA, tx_window<0, KH / 2, NP>(epiB));
     TX_PROF_ADD(pf, walk);
+    const f32x16 (&acc)[NH] = accA;
     // heads: rows 0..2 = rgb.0 (sigmoid), row 3 = sigma.0 (ReLU)                                   nerf.py:39-40
     const f32x4 hb = *reinterpret_cast<const f32x4*>(lds + TX_RING + depth * HID * 4);
 #pragma unroll
@@ -230,32 +226,40 @@ __device__ __forceinline__ void tx_bwd_tile(PipeX& p, const unsigned char* lds, 
         const u32x4 w1 = {a0, a1, 0u, 0u}, w2 = {b0, b1, 0u, 0u}, w3 = {c0, c1, 0u, 0u};
         Z.p1[0] = __builtin_bit_cast(bf16x8, w1); Z.p2[0] = __builtin_bit_cast(bf16x8, w2); Z.p3[0] = __builtin_bit_cast(bf16x8, w3);
     }
-    f32x16 acc[NT];
+    constexpr int NH = NT / 2, KH = HID / 16, NP = NH * 8;
+    f32x16 accA[NH], accB[NH];
     uint32_t mw[NT / 2];
-    // The sign words of a layer are fetched before the layer walk that produces its dH and waited for with a COUNTED wait
-    // after it (the walk's last boundaries issued `after` younger DMAs; a compiler-placed vmcnt(0) would drain the weight ring).
-    TxMask<NT / 2> mk;
-    auto mask_fetch = [&](int l) TN_INLINE_LAMBDA { mk.fetch(mrow + (int64_t)l * (Mp + 32) * NT); };
-    auto fin_layer = [&](int l) TN_INLINE_LAMBDA {                 // acc = dH_l  ->  dZ_l (masked, stashed, split into X)
-        float* __restrict__ zrow = pl + L.dz_row0[l] * 32;
+    TxEpi es;
+    TxMask<NT / 2> mk;                                             // asm load + counted wait (above)
+    float* __restrict__ zrow = nullptr;
+    auto epiA = [&](auto ic, auto jc, auto) TN_INLINE_LAMBDA { tx_epi_bwd<HID, 0, decltype(ic)::value, decltype(jc)::value>(accA, X, es, mw, zrow); };
+    auto epiB = [&](auto ic, auto jc, auto) TN_INLINE_LAMBDA { tx_epi_bwd<HID, 1, decltype(ic)::value, decltype(jc)::value>(accB, X, es, mw, zrow); };
+    // dH_{depth-1} = W_head^T dZ_head: both halves; half A's epilogue has nothing to hide behind
+    mk.fetch(mrow + (int64_t)(depth - 1) * (Mp + 32) * NT);
+    tx_pass_headsT<HID>(p, lds, Z, accA, accB);
+    mk.template wait<TX_DPW>();                                    // one boundary (TX_DPW DMAs) was issued behind the fetch
 #pragma unroll
-        for (int w = 0; w < NT / 2; ++w) mw[w] = mk.v[w];
-        tx_layer_epilogue_bwd<HID>(acc, mw, X, [&](auto tc, const float (&v)[16]) TN_INLINE_LAMBDA {
-            constexpr int t = decltype(tc)::value;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) TN_STASH_STORE(&zrow[(32 * t + (r & 3) + 8 * (r >> 2)) * 32], v[r]);
-        });
-    };
-    mask_fetch(depth - 1);
-    tx_layer_mfma<HID, 4, ST>(p, lds, X, Z, acc);                  // heads^T (one boundary)
-    mk.template wait<TX_DPW>();
-    fin_layer(depth - 1);
+    for (int w = 0; w < NT / 2; ++w) mw[w] = mk.v[w];
+    zrow = pl + L.dz_row0[depth - 1] * 32;
+    tx_drain<NP>(epiA);
+    // layer l (dH_{l-1} = W_l^T dZ_l): dZ_l's half B epilogue behind the first half of pass A; the sign words of layer l-1 are
+    // fetched before pass A and waited for (>= TX_LEAD boundaries later) at the start of dZ_{l-1}'s half A epilogue, which rides
+    // on the second half of pass B
     for (int l = depth - 1; l >= 1; --l) {
-        mask_fetch(l - 1);
-        tx_layer_mfma<HID, 1, ST>(p, lds, X, Z, acc);              // dH_{l-1} = W_l^T dZ_l (>= TX_LEAD boundaries)
-        mk.template wait<TX_DPW * TX_LEAD>();
-        fin_layer(l - 1);
+        mk.fetch(mrow + (int64_t)(l - 1) * (Mp + 32) * NT);
+        tx_pass<HID, 1, true>(p, lds, X, Z, accA, tx_window<0, KH / 2 * NH, NP>(epiB));
+        auto winA = tx_window<KH / 2 * NH * 6, KH / 2 * NH, NP>(epiA);
+        tx_pass<HID, 1, true>(p, lds, X, Z, accB, [&](auto sc) TN_INLINE_LAMBDA {
+            if constexpr (decltype(sc)::value == KH / 2 * NH * 6) {
+                mk.template wait<TX_DPW * TX_LEAD>();
+#pragma unroll
+                for (int w = 0; w < NT / 2; ++w) mw[w] = mk.v[w];
+                zrow = pl + L.dz_row0[l - 1] * 32;
+            }
+            winA(sc);
+        });
     }
+    tx_drain<NP>(epiB);                                            // dZ_0, half B
 }
 
 template <int HID>

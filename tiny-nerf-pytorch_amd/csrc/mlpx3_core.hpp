@@ -8,12 +8,16 @@
 // Orientation as everywhere in this library: weights = A operand, the wave's 32 samples on the lanes, the 32x32 fp32
 // accumulator of n-tile t = the next layer's B operand for k-steps 2t, 2t+1 — here after bias / ReLU in fp32 and ONE exact
 // split into three packed bf16 operand registers.  What differs from the bf16 mode (mlp16_core.hpp):
-//   * k-step-major order.  A layer is walked k-step by k-step with ALL n-tiles' accumulators live (HID/32 x 16 registers);
-//     the three pieces of the input activation X[s] are dead after k-step s, so the layer's output pieces are written back
-//     into the same registers: one activation array (3 x HID/16 x 4 registers) instead of an in / out pair.  8x256: 192 + 128
-//     registers — one wave per SIMD (512-register budget), four waves per workgroup.
-//   * the weight stream carries three pieces per fragment (tnerf_internal.h, NetX3): per k-step record NT x 3 KB through an LDS
-//     ring of 24 KB stages (LDS-DMA, counted vmcnt, one raw barrier per stage), shared by the four waves.
+//   * k-step-major order in two HALF-PASSES per layer (output tiles 0..NT/2-1 = half A, then half B), all of a half's
+//     accumulators live; the three pieces of the input activation X[s] are dead once half B has passed k-step s, so the layer's
+//     output pieces are written back into the same registers: one activation array (3 x HID/16 x 4 registers) instead of an
+//     in / out pair.  8x256: 192 + 128 registers — one wave per SIMD (512-register budget), four waves per workgroup.
+//   * with one wave per SIMD nothing else fills the matrix pipe while a wave runs an epilogue (bias, ReLU, sign bits, stash
+//     store, split: ~8 VALU per value), so the epilogue of one half is cut into per-pair MICRO-STEPS that are issued in the
+//     shadows of the other half's MFMAs (tx_pass's hook): half A's epilogue rides on the second half of pass B (X[0..KH/2)
+//     is dead there), half B's on the first half of the next layer's pass A.  The order is pinned with sched_barrier.
+//   * the weight stream carries three pieces per fragment (tnerf_internal.h, NetX3): per (half, k-step) record NT/2 x 3 KB
+//     through an LDS ring of 24 KB stages (LDS-DMA, counted vmcnt, one raw barrier per stage), shared by the four waves.
 #pragma once
 #include "mlp16_core.hpp"
 
@@ -88,7 +92,8 @@ __device__ __forceinline__ void tx_prologue(PipeX& p, unsigned char* lds, const 
 
 // The activation of a wave's 32-sample tile: three bf16 pieces of every k-step operand.
 template <int HID>
-struct ActX { bf16x8 p1[HID / 16], p2[HID / 16], p3[HID / 16]; };
+struct ActX { u32x4 p1[HID / 16], p2[HID / 16], p3[HID / 16]; };          // packed bf16 pairs; dword q = values 2q, 2q+1 of the k-step
+#define TX_BF(x) __builtin_bit_cast(bf16x8, (x))
 struct EncX { bf16x8 p1[TN16_KE], p2[TN16_KE], p3[TN16_KE]; };
 
 // Six exact partial products of one (n-tile, k-step): small terms first.  FIRST: the accumulator starts at zero.
@@ -104,94 +109,179 @@ __device__ __forceinline__ void tx_mfma6(f32x16& acc, const bf16x8& a1, const bf
     acc = TN16_MFMA(a1, b1, acc);
 }
 
-// The records of one layer: KIND 0: input k-steps only   1: hidden   2: hidden, then input (skip layer)   3: heads (tile 0 only)
-// 4: heads^T of the backward stream (ONE k-step whose B operand is E.p*[0]; the stage is padded with empty records).
-// RPS = records per stage (1 for 256-wide, 2 for 128-wide nets); every layer is a whole number of stages (4, 8, 12, 16, 20
-// records), so the stage phase of record k of a layer is k % RPS.
-template <int HID, int KIND, int STORES>
-__device__ __forceinline__ void tx_layer_mfma(PipeX& p, const unsigned char* lds, const ActX<HID>& X, const EncX& E,
-                                              f32x16 (&acc)[HID / 32]) {
-    constexpr int NT = HID / 32, KH = HID / 16, RPS = TX_STAGE / (NT * 3);
-    constexpr int NK = KIND == 0 ? TN16_KE : (KIND == 2 ? KH + TN16_KE : (KIND == 4 ? 1 : KH));
-    constexpr int NTU = KIND == 3 ? 1 : NT;                        // tiles with MFMAs
-    static_assert(NK % RPS == 0 || KIND == 4, "a layer must be a whole number of stages");
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+struct FragX { bf16x8 a1, a2, a3; };
+__device__ __forceinline__ FragX tx_frag_load(const unsigned char* base, int tl) {
+    FragX f;
+    f.a1 = *reinterpret_cast<const bf16x8*>(base + (tl * 3 + 0) * 1024);
+    f.a2 = *reinterpret_cast<const bf16x8*>(base + (tl * 3 + 1) * 1024);
+    f.a3 = *reinterpret_cast<const bf16x8*>(base + (tl * 3 + 2) * 1024);
+    return f;
+}
+#define TX_PIN() __builtin_amdgcn_sched_barrier(0)
+
+// One half-pass of a layer: NK k-step records, each NTU tiles x 6 MFMAs into acc[tile slot].
+// KIND 0: the TN16_KE input k-steps (B operand from E)   1: the hidden k-steps   3: heads (hidden k-steps, tile slot 0 only).
+// A skip layer's half is a KIND 1 pass followed by a KIND 0 pass that accumulates (ZERO = false) — one copy of the long pass
+// in the instruction cache instead of two.
+// RPS = records per stage (2 for 256-wide, 4 for 128-wide nets); every pass is a whole number of stages, so the stage
+// phase of record k is k % RPS.  ZERO: the accumulators start at zero.
+// hook(integral_constant<slot>) is called behind MFMA number slot = (k * NTU + tile) * 6 + j: work to issue in its shadow.
+// The next group's A fragments are read from LDS behind the first MFMA of a group (not across a stage boundary).
+template <int HID, int KIND, bool ZERO, typename Hook>
+__device__ __forceinline__ void tx_pass(PipeX& p, const unsigned char* lds, const ActX<HID>& X, const EncX& E,
+                                        f32x16 (&acc)[HID / 64], Hook&& hook) {
+    constexpr int NH = HID / 64, KH = HID / 16, RPS = TX_STAGE / (NH * 3);
+    constexpr int NK = KIND == 0 ? TN16_KE : KH;
+    constexpr int NTU = KIND == 3 ? 1 : NH;
+    static_assert(NK % RPS == 0, "a half-pass must be a whole number of stages");
+    FragX cur;
     tn_static_for<NK>([&](auto kc) TN_INLINE_LAMBDA {
         constexpr int k = decltype(kc)::value;
-        if constexpr (k % RPS == 0) tx_boundary<STORES>(p);
-        const unsigned char* base = lds + p.cur + (k % RPS) * (NT * 3 * 1024) + p.lane16;
+        if constexpr (k % RPS == 0) tx_boundary<0>(p);
+        const unsigned char* base = lds + p.cur + (k % RPS) * (NH * 3 * 1024) + p.lane16;
+        if constexpr (k % RPS == 0) cur = tx_frag_load(base, 0);
         bf16x8 b1, b2, b3;
-        if constexpr (KIND == 0 || KIND == 4 || (KIND == 2 && k >= KH)) { constexpr int u = (KIND == 0 || KIND == 4) ? k : k - KH; b1 = E.p1[u]; b2 = E.p2[u]; b3 = E.p3[u]; }
-        else { b1 = X.p1[k]; b2 = X.p2[k]; b3 = X.p3[k]; }
+        if constexpr (KIND == 0) { b1 = E.p1[k]; b2 = E.p2[k]; b3 = E.p3[k]; }
+        else { b1 = TX_BF(X.p1[k]); b2 = TX_BF(X.p2[k]); b3 = TX_BF(X.p3[k]); }
         tn_static_for<NTU>([&](auto tc) TN_INLINE_LAMBDA {
-            constexpr int t = decltype(tc)::value;
-            const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(base + (t * 3 + 0) * 1024);
-            const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(base + (t * 3 + 1) * 1024);
-            const bf16x8 a3 = *reinterpret_cast<const bf16x8*>(base + (t * 3 + 2) * 1024);
-            tx_mfma6<k == 0>(acc[t], a1, a2, a3, b1, b2, b3);
+            constexpr int tl = decltype(tc)::value;
+            constexpr bool more_tile = tl + 1 < NTU;
+            constexpr bool more_rec = !more_tile && (k + 1) % RPS != 0 && k + 1 < NK;
+            constexpr int s0 = (k * NTU + tl) * 6;
+            FragX nxt;
+            if constexpr (ZERO && k == 0) { const f32x16 z = {}; acc[tl] = TN16_MFMA(cur.a3, b1, z); }
+            else                  acc[tl] = TN16_MFMA(cur.a3, b1, acc[tl]);
+            if constexpr (more_tile)     nxt = tx_frag_load(base, tl + 1);
+            else if constexpr (more_rec) nxt = tx_frag_load(base + NH * 3 * 1024, 0);
+            hook(std::integral_constant<int, s0>{});     TX_PIN();
+            acc[tl] = TN16_MFMA(cur.a2, b2, acc[tl]); hook(std::integral_constant<int, s0 + 1>{}); TX_PIN();
+            acc[tl] = TN16_MFMA(cur.a1, b3, acc[tl]); hook(std::integral_constant<int, s0 + 2>{}); TX_PIN();
+            acc[tl] = TN16_MFMA(cur.a2, b1, acc[tl]); hook(std::integral_constant<int, s0 + 3>{}); TX_PIN();
+            acc[tl] = TN16_MFMA(cur.a1, b2, acc[tl]); hook(std::integral_constant<int, s0 + 4>{}); TX_PIN();
+            acc[tl] = TN16_MFMA(cur.a1, b1, acc[tl]); hook(std::integral_constant<int, s0 + 5>{}); TX_PIN();
+            if constexpr (more_tile || more_rec) cur = nxt;
         });
     });
 }
 
-// Epilogue of a hidden layer: bias (fp32, from LDS), ReLU, exact split back into the activation registers.
-// vb: per-lane LDS byte offset of this layer's biases (+ 16 h).  `fin(t, v)` sees the 16 fp32 outputs of tile t (training stash).
-template <int HID, typename Fin>
-__device__ __forceinline__ void tx_layer_epilogue(const unsigned char* lds, uint32_t vb, const f32x16 (&acc)[HID / 32], ActX<HID>& X, Fin&& fin) {
-    constexpr int NT = HID / 32;
-    tn_static_for<NT>([&](auto tc) TN_INLINE_LAMBDA {
+// heads^T of the backward stream: ONE k-step (B operand = Z.p*[0]) into both halves' accumulators; the stage holds record A,
+// record B and padding.
+template <int HID>
+__device__ __forceinline__ void tx_pass_headsT(PipeX& p, const unsigned char* lds, const EncX& Z, f32x16 (&accA)[HID / 64], f32x16 (&accB)[HID / 64]) {
+    constexpr int NH = HID / 64;
+    tx_boundary<0>(p);
+    const unsigned char* base = lds + p.cur + p.lane16;
+    const f32x16 z = {};
+    tn_static_for<2 * NH>([&](auto tc) TN_INLINE_LAMBDA {
         constexpr int t = decltype(tc)::value;
-        float v[16];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 b = *reinterpret_cast<const f32x4*>(lds + vb + (32 * t + 8 * q) * 4);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[4 * q + i] = fmaxf(acc[t][4 * q + i] + b[i], 0.0f);
-        }
-        fin(tc, v);
-        u32x4 w1[2], w2[2], w3[2];
-#pragma unroll
-        for (int half = 0; half < 2; ++half)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                unsigned a_, b_, c_;
-                tx_split2(v[8 * half + 2 * q], v[8 * half + 2 * q + 1], a_, b_, c_);
-                w1[half][q] = a_; w2[half][q] = b_; w3[half][q] = c_;
-            }
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            X.p1[2 * t + half] = __builtin_bit_cast(bf16x8, w1[half]);
-            X.p2[2 * t + half] = __builtin_bit_cast(bf16x8, w2[half]);
-            X.p3[2 * t + half] = __builtin_bit_cast(bf16x8, w3[half]);
-        }
+        const FragX f = tx_frag_load(base, t);                                    // record B follows record A: slot t = half * NH + tl
+        f32x16 a = TN16_MFMA(f.a3, Z.p1[0], z);
+        a = TN16_MFMA(f.a2, Z.p2[0], a); a = TN16_MFMA(f.a1, Z.p3[0], a);
+        a = TN16_MFMA(f.a2, Z.p1[0], a); a = TN16_MFMA(f.a1, Z.p2[0], a); a = TN16_MFMA(f.a1, Z.p1[0], a);
+        if constexpr (t < NH) accA[t] = a; else accB[t - NH] = a;
     });
 }
 
-// Epilogue of a backward layer: ReLU backward with the forward's sign bits (mw: the words of the layer whose activation gradient
-// this is), exact split back into the activation registers.  `fin(t, v)` sees the 16 fp32 values dZ of tile t (stash).
-template <int HID, typename Fin>
-__device__ __forceinline__ void tx_layer_epilogue_bwd(const f32x16 (&acc)[HID / 32], const uint32_t (&mw)[HID / 64], ActX<HID>& X, Fin&& fin) {
-    constexpr int NT = HID / 32;
-    tn_static_for<NT>([&](auto tc) TN_INLINE_LAMBDA {
-        constexpr int t = decltype(tc)::value;
-        float v[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            v[r] = __int_as_float(__float_as_int(acc[t][r]) & __builtin_amdgcn_sbfe((int)mw[t / 2], (t & 1) * 16 + r, 1));
-        fin(tc, v);
-        u32x4 w1[2], w2[2], w3[2];
-#pragma unroll
-        for (int half = 0; half < 2; ++half)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                unsigned a_, b_, c_;
-                tx_split2(v[8 * half + 2 * q], v[8 * half + 2 * q + 1], a_, b_, c_);
-                w1[half][q] = a_; w2[half][q] = b_; w3[half][q] = c_;
-            }
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            X.p1[2 * t + half] = __builtin_bit_cast(bf16x8, w1[half]);
-            X.p2[2 * t + half] = __builtin_bit_cast(bf16x8, w2[half]);
-            X.p3[2 * t + half] = __builtin_bit_cast(bf16x8, w3[half]);
+// ---- epilogues as micro-steps.  A half has NP = NH*8 register PAIRS (values 2pr, 2pr+1 of a tile); pair i of the order
+// below is tile 2(i/16) + 1 - (i%16)/8 of the half, pair 7 - i%8: the sign words of the training stash are built by shifting
+// (alignbit), i.e. bit 31 first = the odd tile of the word, register 15 downwards.
+template <int HID, int HALF, int I> struct TxPair {
+    static constexpr int NH = HID / 64;
+    static constexpr int tl = 2 * (I / 16) + (1 - (I % 16) / 8);      // accumulator slot in the half
+    static constexpr int t = HALF * NH + tl;                          // n-tile
+    static constexpr int pr = 7 - I % 8;
+    static constexpr int r0 = 2 * pr, r1 = 2 * pr + 1;
+    static constexpr int xs = 2 * t + pr / 4, xq = pr % 4;            // activation k-step and dword the pair lands in
+    static constexpr int row0 = 32 * t + (r0 & 3) + 8 * (r0 >> 2), row1 = 32 * t + (r1 & 3) + 8 * (r1 >> 2);   // feature rows (+ 4h) of the stash
+};
+struct TxEpi { float v0[4], v1[4], r0[4], r1[4], s0[4], s1[4]; f32x2 b[4]; uint32_t msk; };      // up to 4 pairs in flight
+
+// steps 3..5 of any epilogue: the exact split of the pair into the activation registers
+template <int HID, int HALF, int I, int J>
+__device__ __forceinline__ void tx_epi_split(ActX<HID>& X, TxEpi& e) {
+    using P = TxPair<HID, HALF, I>;
+    constexpr int u = I % 4;
+    if constexpr (J == 3) {
+        e.r0[u] = e.v0[u] - __uint_as_float(__float_as_uint(e.v0[u]) & 0xFFFF0000u);
+        e.r1[u] = e.v1[u] - __uint_as_float(__float_as_uint(e.v1[u]) & 0xFFFF0000u);
+    } else if constexpr (J == 4) {
+        e.s0[u] = e.r0[u] - __uint_as_float(__float_as_uint(e.r0[u]) & 0xFFFF0000u);
+        e.s1[u] = e.r1[u] - __uint_as_float(__float_as_uint(e.r1[u]) & 0xFFFF0000u);
+    } else if constexpr (J == 5) {
+        X.p1[P::xs][P::xq] = __builtin_amdgcn_perm(__float_as_uint(e.v1[u]), __float_as_uint(e.v0[u]), 0x07060302u);
+        X.p2[P::xs][P::xq] = __builtin_amdgcn_perm(__float_as_uint(e.r1[u]), __float_as_uint(e.r0[u]), 0x07060302u);
+        X.p3[P::xs][P::xq] = __builtin_amdgcn_perm(__float_as_uint(e.s1[u]), __float_as_uint(e.s0[u]), 0x07060302u);
+    }
+}
+
+// Forward: bias (fp32, LDS byte offset vb + 16 h: this layer's biases for rows 4h..), ReLU, [training: fp32 value to the stash,
+// sign bit], split.  The bias pair is READ one micro-step before it is used (step 0 of the pair; step 1 adds), so that the
+// compiler's lgkmcnt wait lands a whole MFMA later.
+// srow: per-lane stash pointer of the layer's activation rows (row 4h, this sample); mword: per-lane pointer of its sign words.
+template <int HID, int HALF, int I, int J, bool TRAIN, int PPG>
+__device__ __forceinline__ void tx_epi_fwd(const f32x16 (&acc)[HID / 64], ActX<HID>& X, TxEpi& e, const unsigned char* lds, uint32_t vb,
+                                           float* __restrict__ srow, uint32_t* __restrict__ mword) {
+    using P = TxPair<HID, HALF, I>;
+    constexpr int u = I % 4;
+    // PPG: pairs per MFMA group of the window this runs in; pair I + PPG is the one that takes this register slot next
+    if constexpr (J == 0) {
+        if constexpr (I < PPG) e.b[u] = *reinterpret_cast<const f32x2*>(lds + vb + P::row0 * 4);      // the window's first group
+        e.v0[u] = acc[P::tl][P::r0]; e.v1[u] = acc[P::tl][P::r1];
+    } else if constexpr (J == 1) {
+        e.v0[u] = fmaxf(e.v0[u] + e.b[u][0], 0.0f); e.v1[u] = fmaxf(e.v1[u] + e.b[u][1], 0.0f);
+    } else if constexpr (J == 5 && I + PPG < P::NH * 8) {          // (also runs the split's step 5 below)
+        e.b[(I + PPG) % 4] = *reinterpret_cast<const f32x2*>(lds + vb + TxPair<HID, HALF, I + PPG>::row0 * 4);
+        tx_epi_split<HID, HALF, I, J>(X, e);
+    } else if constexpr (J == 2) {
+        if constexpr (TRAIN) {
+            TN_STASH_STORE(&srow[P::row0 * 32], e.v0[u]); TN_STASH_STORE(&srow[P::row1 * 32], e.v1[u]);
+            if constexpr (I % 16 == 0) e.msk = 0u;
+            e.msk = __builtin_amdgcn_alignbit(e.msk, __float_as_uint(e.v1[u]) + 0x7FFFFFFFu, 31);
+            e.msk = __builtin_amdgcn_alignbit(e.msk, __float_as_uint(e.v0[u]) + 0x7FFFFFFFu, 31);
+            if constexpr (I % 16 == 15) mword[P::t / 2] = e.msk;
         }
+    } else tx_epi_split<HID, HALF, I, J>(X, e);
+}
+
+// Backward: ReLU backward with the forward's sign bits (mw: the words of the layer this activation gradient belongs to),
+// dZ to the stash, split.
+template <int HID, int HALF, int I, int J>
+__device__ __forceinline__ void tx_epi_bwd(const f32x16 (&acc)[HID / 64], ActX<HID>& X, TxEpi& e, const uint32_t (&mw)[HID / 64], float* __restrict__ zrow) {
+    using P = TxPair<HID, HALF, I>;
+    constexpr int u = I % 4;
+    if constexpr (J == 0) {
+        e.v0[u] = acc[P::tl][P::r0]; e.v1[u] = acc[P::tl][P::r1];
+    } else if constexpr (J == 1) {
+        e.v0[u] = __int_as_float(__float_as_int(e.v0[u]) & __builtin_amdgcn_sbfe((int)mw[P::t / 2], (P::t & 1) * 16 + P::r0, 1));
+        e.v1[u] = __int_as_float(__float_as_int(e.v1[u]) & __builtin_amdgcn_sbfe((int)mw[P::t / 2], (P::t & 1) * 16 + P::r1, 1));
+    } else if constexpr (J == 2) {
+        TN_STASH_STORE(&zrow[P::row0 * 32], e.v0[u]); TN_STASH_STORE(&zrow[P::row1 * 32], e.v1[u]);
+    } else tx_epi_split<HID, HALF, I, J>(X, e);
+}
+
+// The slots [W0, W0 + 6 G) of a pass as an epilogue window: group g = (slot - W0) / 6 carries micro-step (slot - W0) % 6 of the
+// pairs g*PPG .. g*PPG + PPG - 1 (PPG = ceil(NP / G) <= 4).  f(integral_constant<I>, integral_constant<J>, integral_constant<PPG>).
+template <int W0, int G, int NP, typename F>
+__device__ __forceinline__ auto tx_window(F&& f) {
+    return [&f](auto sc) TN_INLINE_LAMBDA {
+        constexpr int s = decltype(sc)::value;
+        constexpr int PPG = (NP + G - 1) / G;
+        static_assert(PPG <= 4, "epilogue window too short");
+        if constexpr (s >= W0 && s < W0 + 6 * G) {
+            constexpr int g = (s - W0) / 6, j = (s - W0) % 6;
+            tn_static_for<PPG>([&](auto uc) TN_INLINE_LAMBDA {
+                constexpr int i = g * PPG + decltype(uc)::value;
+                if constexpr (i < NP) f(std::integral_constant<int, i>{}, std::integral_constant<int, j>{}, std::integral_constant<int, PPG>{});
+            });
+        }
+    };
+}
+// A whole epilogue with nothing to hide behind.
+template <int NP, typename F>
+__device__ __forceinline__ void tx_drain(F&& f) {
+    tn_static_for<NP>([&](auto ic) TN_INLINE_LAMBDA {
+        tn_static_for<6>([&](auto jc) TN_INLINE_LAMBDA { f(ic, jc, std::integral_constant<int, 1>{}); });
     });
 }
 

@@ -78,26 +78,29 @@ struct Net16 {
 #define TN16_STASH_OUT_BYTES(n, tiles)  ((int64_t)((tiles) + 1) * 32 * 16)
 
 // "x3" chain kernels (mlpx3.hip): the fp32 MLP chain on the bf16 matrix pipe with exact three-way operand splitting
-// (DESIGN.md §13/§14).  The weights are a STREAM of k-step RECORDS in the order a wavefront consumes them; a record holds, for
-// every n-tile t, the three bf16 pieces W1, W2, W3 (W = W1 + W2 + W3 exactly) of the A fragment of (n-tile t, this k-step):
-//   record = [t = 0 .. NT-1][piece 0..2] x 1 KB,   fragment = lane (row l&31, half l>>5) x 8 bf16 (k-slots 8 (l>>5) + e)
-// Forward pass order: layer 0: TN16_KE input k-steps; layer l >= 1: hidden/16 hidden k-steps (+ TN16_KE input k-steps for the
-// skip layer); heads: hidden/16 k-steps whose records carry the head tile (rows r,g,b,sigma) at t = 0 and zeros elsewhere.
-// k-slot <-> feature maps as in the bf16 mode (above).  Records are cut into stages of TX_STAGE fragments (24 KB: one record of
-// a 256-wide net, two of a 128-wide one) for the LDS ring.  After the stream: the fp32 biases as in the bf16 mode.
+// (DESIGN.md §13/§14).  The weights are a STREAM of k-step RECORDS in the order a wavefront consumes them.  A layer is walked
+// as two HALF-PASSES (output tiles 0..NT/2-1, then NT/2..NT-1: the epilogue of one half hides behind the MFMAs of the other);
+// a record holds, for every tile slot tl of ONE half, the three bf16 pieces W1, W2, W3 (W = W1 + W2 + W3 exactly) of the A
+// fragment of (n-tile half*NT/2 + tl, this k-step):
+//   record = [tl = 0 .. NT/2-1][piece 0..2] x 1 KB,   fragment = lane (row l&31, half l>>5) x 8 bf16 (k-slots 8 (l>>5) + e)
+// Forward order: layer 0: half A: TN16_KE input k-steps, half B: the same; layer l >= 1: per half hidden/16 hidden k-steps
+// (+ TN16_KE input k-steps for the skip layer); heads: hidden/16 k-steps whose records carry the head tile (rows r,g,b,sigma)
+// at slot 0 and zeros elsewhere.  k-slot <-> feature maps as in the bf16 mode (above).  Records are cut into stages of
+// TX_STAGE fragments (24 KB: two records of a 256-wide net, four of a 128-wide one) for the LDS ring.  After the stream: the
+// fp32 biases as in the bf16 mode.
 #define TX_STAGE 24
 struct NetX3 {
     int32_t in_dim, hidden, depth, skip_at, Lf;
     int32_t NT, KH;               // n-tiles (hidden/32), hidden k-steps (hidden/16)
-    int32_t rec_frags;            // NT * 3
+    int32_t rec_frags;            // NT / 2 * 3
     int32_t n_rec, n_stage;       // forward stream, per pass
     int32_t n_bw_rec, n_bw_stage; // backward (dgrad) stream, per pass: starts at byte n_rec * rec_frags * 1024
     int32_t bias_off, n_bias;     // byte offset / count of the fp32 biases (depth*hidden + 4)
     int64_t packed_bytes, pack_entries;     // pack_entries = (n_rec + n_bw_rec) * rec_frags * 512 + n_bias
 };
-// Backward stream: heads^T (one record: fragment row 32t+i <-> feature, k-slot (h=0, e<4) <-> head row e = r,g,b,sigma; padded
-// to a whole stage), then for l = depth-1 .. 1 the hidden part of W_l transposed: hidden/16 records, fragment row 32t+i <->
-// input feature, k-slot (s,h,e) <-> output feature.
+// Backward stream: heads^T (two records, half A and half B: fragment row 32t+i <-> feature, k-slot (h=0, e<4) <-> head row
+// e = r,g,b,sigma; padded to a whole stage), then for l = depth-1 .. 1 the hidden part of W_l transposed: per half hidden/16
+// records, fragment row 32t+i <-> input feature, k-slot (s,h,e) <-> output feature.
 
 #ifdef __cplusplus
 extern "C" {
