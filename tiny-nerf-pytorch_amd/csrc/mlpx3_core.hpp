@@ -47,25 +47,43 @@ struct PipeX {
     uint32_t src_off, stream_bytes;
     uint32_t dst_off;            // ring offset of the slot the next DMA fills
     uint32_t lds_dst0;           // absolute LDS address of ring + wave * TX_DPW KB
-    uint32_t voff[TX_DPW];       // lane * 16 + (wave * TX_DPW + i) * 1024
+    uint32_t voff;               // lane * 16 + wave * TX_DPW * 1024: this wave's first piece of a stage
+    const unsigned char* pend_src; uint32_t pend_dst;      // the stage whose pieces are being issued behind MFMAs (tx_defer_stage)
 };
 
+// This wave's TX_DPW (= 6) pieces of a stage are 1 KB each, consecutive in the stream and in the slot: piece i is the pending
+// stage's base (+ 4 KB for i >= 4) with the instruction's immediate offset (i & 3) KB — the offset applies to the global AND
+// the LDS address.  M0 (the DMA's LDS base) is compiler-reserved: saved and restored around the load.
+template <int I>
+__device__ __forceinline__ void tx_issue_piece(const unsigned char* src, uint32_t voff, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%4\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(src + (I >> 2) * 4096), "s"(lds_dst + (I >> 2) * 4096), "n"((I & 3) * 1024) : "memory");
+}
+// the stage `dst_off` / `src_off` point at: all pieces now (prologue, heads^T) ...
 __device__ __forceinline__ void tx_issue_stage(PipeX& p) {
     const unsigned char* s = p.src + p.src_off;
-#pragma unroll
-    for (int i = 0; i < TX_DPW; ++i) tn_glds16(s, p.voff[i], p.lds_dst0 + p.dst_off + i * 1024);
+    tn_static_for<TX_DPW>([&](auto ic) TN_INLINE_LAMBDA { tx_issue_piece<decltype(ic)::value>(s, p.voff, p.lds_dst0 + p.dst_off); });
+    p.src_off += TX_SLOT; if (p.src_off == p.stream_bytes) p.src_off = 0;
+    p.dst_off += TX_SLOT; if (p.dst_off == TX_RING) p.dst_off = 0;
+}
+// ... or piece by piece behind the MFMAs of the stage that has just been published (tx_pass): back-to-back DMA instructions
+// cost the wave more issue time than the same six spread over as many MFMA groups.
+__device__ __forceinline__ void tx_defer_stage(PipeX& p) {
+    p.pend_src = p.src + p.src_off; p.pend_dst = p.lds_dst0 + p.dst_off;
     p.src_off += TX_SLOT; if (p.src_off == p.stream_bytes) p.src_off = 0;
     p.dst_off += TX_SLOT; if (p.dst_off == TX_RING) p.dst_off = 0;
 }
 
 // Start of a stage: wait for this wave's DMA of the stage (LEAD-1 younger ones may stay in flight; STORES more operations
 // are allowed to be outstanding — the training kernels interleave global stores with the stream, see mlp16_core.hpp),
-// barrier (the stage is readable by everyone, the slot of the previous one is free), issue stage + LEAD.
-template <int STORES>
+// barrier (the stage is readable by everyone, the slot of the previous one is free), issue stage + LEAD (DEFER: the caller
+// issues its pieces with tx_issue_piece before the next boundary).
+template <int STORES, bool DEFER = false>
 __device__ __forceinline__ void tx_boundary(PipeX& p) {
     TN16_WAIT_VM(TX_DPW * (TX_LEAD - 1) + STORES);
     __builtin_amdgcn_s_barrier();
-    tx_issue_stage(p);
+    if constexpr (DEFER) tx_defer_stage(p); else tx_issue_stage(p);
     p.cur += TX_SLOT; if (p.cur == TX_RING) p.cur = 0;
 }
 
@@ -82,8 +100,7 @@ __device__ __forceinline__ void tx_prologue(PipeX& p, unsigned char* lds, const 
     p.src = src; p.src_off = 0; p.stream_bytes = (uint32_t)n_stage * TX_SLOT;
     p.dst_off = 0;
     p.lds_dst0 = (uint32_t)(uintptr_t)lds + wave * (TX_DPW * 1024);
-#pragma unroll
-    for (int i = 0; i < TX_DPW; ++i) p.voff[i] = lane * 16 + (wave * TX_DPW + i) * 1024;
+    p.voff = lane * 16 + wave * TX_DPW * 1024;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #pragma unroll
     for (int i = 0; i < TX_LEAD; ++i) tx_issue_stage(p);
@@ -138,9 +155,13 @@ __device__ __forceinline__ void tx_pass(PipeX& p, const unsigned char* lds, cons
     FragX cur;
     tn_static_for<NK>([&](auto kc) TN_INLINE_LAMBDA {
         constexpr int k = decltype(kc)::value;
-        if constexpr (k % RPS == 0) tx_boundary<0>(p);
+        // The stage boundary (wait, barrier, next DMA stage named) of every stage but the pass's first is taken one MFMA group
+        // EARLY — in front of the last group of the stage before, whose A fragments are already in registers — so that the new
+        // stage's first fragments are read behind that group's MFMAs instead of in front of an idle matrix pipe.  (The ring has
+        // the spare slot this needs: TX_LEAD + 2 <= TX_NS.)
+        if constexpr (k == 0) tx_boundary<0, true>(p);
         const unsigned char* base = lds + p.cur + (k % RPS) * (NH * 3 * 1024) + p.lane16;
-        if constexpr (k % RPS == 0) cur = tx_frag_load(base, 0);
+        if constexpr (k == 0) cur = tx_frag_load(base, 0);
         bf16x8 b1, b2, b3;
         if constexpr (KIND == 0) { b1 = E.p1[k]; b2 = E.p2[k]; b3 = E.p3[k]; }
         else { b1 = TX_BF(X.p1[k]); b2 = TX_BF(X.p2[k]); b3 = TX_BF(X.p3[k]); }
@@ -148,19 +169,30 @@ __device__ __forceinline__ void tx_pass(PipeX& p, const unsigned char* lds, cons
             constexpr int tl = decltype(tc)::value;
             constexpr bool more_tile = tl + 1 < NTU;
             constexpr bool more_rec = !more_tile && (k + 1) % RPS != 0 && k + 1 < NK;
+            constexpr bool early = !more_tile && (k + 1) % RPS == 0 && k + 1 < NK;      // last group of a stage, another follows in this pass
             constexpr int s0 = (k * NTU + tl) * 6;
             FragX nxt;
+            if constexpr (early) tx_boundary<0, true>(p);
             if constexpr (ZERO && k == 0) { const f32x16 z = {}; acc[tl] = TN16_MFMA(cur.a3, b1, z); }
-            else                  acc[tl] = TN16_MFMA(cur.a3, b1, acc[tl]);
+            else                          acc[tl] = TN16_MFMA(cur.a3, b1, acc[tl]);
             if constexpr (more_tile)     nxt = tx_frag_load(base, tl + 1);
             else if constexpr (more_rec) nxt = tx_frag_load(base + NH * 3 * 1024, 0);
+            else if constexpr (early)    nxt = tx_frag_load(lds + p.cur + p.lane16, 0);
             hook(std::integral_constant<int, s0>{});     TX_PIN();
             acc[tl] = TN16_MFMA(cur.a2, b2, acc[tl]); hook(std::integral_constant<int, s0 + 1>{}); TX_PIN();
             acc[tl] = TN16_MFMA(cur.a1, b3, acc[tl]); hook(std::integral_constant<int, s0 + 2>{}); TX_PIN();
-            acc[tl] = TN16_MFMA(cur.a2, b1, acc[tl]); hook(std::integral_constant<int, s0 + 3>{}); TX_PIN();
+            acc[tl] = TN16_MFMA(cur.a2, b1, acc[tl]); hook(std::integral_constant<int, s0 + 3>{});
+            {   // this group's share of the pending stage's DMA pieces
+                constexpr int GPS = RPS * NTU, PPS = (TX_DPW + GPS - 2) / (GPS - 1), g = (k % RPS) * NTU + tl;
+                tn_static_for<PPS>([&](auto uc) TN_INLINE_LAMBDA {
+                    constexpr int i = g * PPS + decltype(uc)::value;
+                    if constexpr (i < TX_DPW && g < GPS - 1) tx_issue_piece<i>(p.pend_src, p.voff, p.pend_dst);
+                });
+            }
+            TX_PIN();
             acc[tl] = TN16_MFMA(cur.a1, b2, acc[tl]); hook(std::integral_constant<int, s0 + 4>{}); TX_PIN();
             acc[tl] = TN16_MFMA(cur.a1, b1, acc[tl]); hook(std::integral_constant<int, s0 + 5>{}); TX_PIN();
-            if constexpr (more_tile || more_rec) cur = nxt;
+            if constexpr (more_tile || more_rec || early) cur = nxt;
         });
     });
 }
