@@ -686,7 +686,7 @@ extern "C" int tn_build_netx3(const tnerf_mlp_desc* d, NetX3* n) {
     n->NT = H / 32; n->KH = H / 16; n->rec_frags = n->NT / 2 * 3;           // a record covers HALF of the output tiles
     int rec = 2 * TN16_KE;
     for (int l = 1; l < d->depth; ++l) rec += 2 * (n->KH + ((d->skip_at > 0 && l == d->skip_at) ? TN16_KE : 0));
-    rec += n->KH;                                                           // heads
+    rec += n->KH / (n->NT / 2);                                             // heads: NT/2 k-steps of the one head tile per record
     if ((rec * n->rec_frags) % TX_STAGE != 0) { tn_set_error("x3 chain: the record stream is not a whole number of stages"); return TNERF_EUNSUPPORTED; }
     n->n_rec = rec; n->n_stage = rec * n->rec_frags / TX_STAGE;
     const int rps = TX_STAGE / n->rec_frags;                               // records per stage
@@ -738,11 +738,13 @@ extern "C" int tnerf_x3_pack_table(const tnerf_mlp_desc* d, int32_t* T) {
                     }
         }
     }
-    for (int s = 0; s < KH; ++s, ++rec)                                     // heads: tile slot 0 rows r,g,b (rgb.0), sigma.0
+    for (int s = 0; s < KH; ++s) {                                          // heads: rows r,g,b (rgb.0), sigma.0; slot s % NH of record s / NH
         for (int lane = 0; lane < 64; ++lane) for (int e = 0; e < 8; ++e) {
             const int64_t src = head_w(lane & 31, hid_feature16(s, lane >> 5, e));
-            if (src >= 0) put(0, lane, e, src);
+            if (src >= 0) put(s % NH, lane, e, src);
         }
+        if (s % NH == NH - 1) ++rec;
+    }
     // ---- backward stream
     rec = n.n_rec;
     for (int half = 0; half < 2; ++half, ++rec)                             // heads^T: dH[k] = sum_{row<4} W_head[row][k] dZh[row]

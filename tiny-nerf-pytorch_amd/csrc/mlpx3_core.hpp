@@ -138,7 +138,8 @@ __device__ __forceinline__ FragX tx_frag_load(const unsigned char* base, int tl)
 #define TX_PIN() __builtin_amdgcn_sched_barrier(0)
 
 // One half-pass of a layer: NK k-step records, each NTU tiles x 6 MFMAs into acc[tile slot].
-// KIND 0: the TN16_KE input k-steps (B operand from E)   1: the hidden k-steps   3: heads (hidden k-steps, tile slot 0 only).
+// KIND 0: the TN16_KE input k-steps (B operand from E)   1: the hidden k-steps   3: heads — ONE output tile (acc[0]), so a
+// record's NH tile slots carry NH consecutive k-steps of it instead (KH / NH records).
 // A skip layer's half is a KIND 1 pass followed by a KIND 0 pass that accumulates (ZERO = false) — one copy of the long pass
 // in the instruction cache instead of two.
 // RPS = records per stage (2 for 256-wide, 4 for 128-wide nets); every pass is a whole number of stages, so the stage
@@ -149,8 +150,8 @@ template <int HID, int KIND, bool ZERO, typename Hook>
 __device__ __forceinline__ void tx_pass(PipeX& p, const unsigned char* lds, const ActX<HID>& X, const EncX& E,
                                         f32x16 (&acc)[HID / 64], Hook&& hook) {
     constexpr int NH = HID / 64, KH = HID / 16, RPS = TX_STAGE / (NH * 3);
-    constexpr int NK = KIND == 0 ? TN16_KE : KH;
-    constexpr int NTU = KIND == 3 ? 1 : NH;
+    constexpr int NK = KIND == 0 ? TN16_KE : (KIND == 3 ? KH / NH : KH);
+    constexpr int NTU = NH;
     static_assert(NK % RPS == 0, "a half-pass must be a whole number of stages");
     FragX cur;
     tn_static_for<NK>([&](auto kc) TN_INLINE_LAMBDA {
@@ -162,26 +163,28 @@ __device__ __forceinline__ void tx_pass(PipeX& p, const unsigned char* lds, cons
         if constexpr (k == 0) tx_boundary<0, true>(p);
         const unsigned char* base = lds + p.cur + (k % RPS) * (NH * 3 * 1024) + p.lane16;
         if constexpr (k == 0) cur = tx_frag_load(base, 0);
-        bf16x8 b1, b2, b3;
-        if constexpr (KIND == 0) { b1 = E.p1[k]; b2 = E.p2[k]; b3 = E.p3[k]; }
-        else { b1 = TX_BF(X.p1[k]); b2 = TX_BF(X.p2[k]); b3 = TX_BF(X.p3[k]); }
         tn_static_for<NTU>([&](auto tc) TN_INLINE_LAMBDA {
             constexpr int tl = decltype(tc)::value;
+            constexpr int ks = KIND == 3 ? k * NH + tl : k;          // the k-step of this group's B operand
+            constexpr int ta = KIND == 3 ? 0 : tl;                   // ... and its accumulator
+            bf16x8 b1, b2, b3;
+            if constexpr (KIND == 0) { b1 = E.p1[ks]; b2 = E.p2[ks]; b3 = E.p3[ks]; }
+            else { b1 = TX_BF(X.p1[ks]); b2 = TX_BF(X.p2[ks]); b3 = TX_BF(X.p3[ks]); }
             constexpr bool more_tile = tl + 1 < NTU;
             constexpr bool more_rec = !more_tile && (k + 1) % RPS != 0 && k + 1 < NK;
             constexpr bool early = !more_tile && (k + 1) % RPS == 0 && k + 1 < NK;      // last group of a stage, another follows in this pass
             constexpr int s0 = (k * NTU + tl) * 6;
             FragX nxt;
             if constexpr (early) tx_boundary<0, true>(p);
-            if constexpr (ZERO && k == 0) { const f32x16 z = {}; acc[tl] = TN16_MFMA(cur.a3, b1, z); }
-            else                          acc[tl] = TN16_MFMA(cur.a3, b1, acc[tl]);
+            if constexpr (ZERO && ks == 0) { const f32x16 z = {}; acc[ta] = TN16_MFMA(cur.a3, b1, z); }
+            else                          acc[ta] = TN16_MFMA(cur.a3, b1, acc[ta]);
             if constexpr (more_tile)     nxt = tx_frag_load(base, tl + 1);
             else if constexpr (more_rec) nxt = tx_frag_load(base + NH * 3 * 1024, 0);
             else if constexpr (early)    nxt = tx_frag_load(lds + p.cur + p.lane16, 0);
             hook(std::integral_constant<int, s0>{});     TX_PIN();
-            acc[tl] = TN16_MFMA(cur.a2, b2, acc[tl]); hook(std::integral_constant<int, s0 + 1>{}); TX_PIN();
-            acc[tl] = TN16_MFMA(cur.a1, b3, acc[tl]); hook(std::integral_constant<int, s0 + 2>{}); TX_PIN();
-            acc[tl] = TN16_MFMA(cur.a2, b1, acc[tl]); hook(std::integral_constant<int, s0 + 3>{});
+            acc[ta] = TN16_MFMA(cur.a2, b2, acc[ta]); hook(std::integral_constant<int, s0 + 1>{}); TX_PIN();
+            acc[ta] = TN16_MFMA(cur.a1, b3, acc[ta]); hook(std::integral_constant<int, s0 + 2>{}); TX_PIN();
+            acc[ta] = TN16_MFMA(cur.a2, b1, acc[ta]); hook(std::integral_constant<int, s0 + 3>{});
             {   // this group's share of the pending stage's DMA pieces
                 constexpr int GPS = RPS * NTU, PPS = (TX_DPW + GPS - 2) / (GPS - 1), g = (k % RPS) * NTU + tl;
                 tn_static_for<PPS>([&](auto uc) TN_INLINE_LAMBDA {
@@ -190,8 +193,8 @@ __device__ __forceinline__ void tx_pass(PipeX& p, const unsigned char* lds, cons
                 });
             }
             TX_PIN();
-            acc[tl] = TN16_MFMA(cur.a1, b2, acc[tl]); hook(std::integral_constant<int, s0 + 4>{}); TX_PIN();
-            acc[tl] = TN16_MFMA(cur.a1, b1, acc[tl]); hook(std::integral_constant<int, s0 + 5>{}); TX_PIN();
+            acc[ta] = TN16_MFMA(cur.a1, b2, acc[ta]); hook(std::integral_constant<int, s0 + 4>{}); TX_PIN();
+            acc[ta] = TN16_MFMA(cur.a1, b1, acc[ta]); hook(std::integral_constant<int, s0 + 5>{}); TX_PIN();
             if constexpr (more_tile || more_rec || early) cur = nxt;
         });
     });

@@ -84,8 +84,8 @@ struct Net16 {
 // fragment of (n-tile half*NT/2 + tl, this k-step):
 //   record = [tl = 0 .. NT/2-1][piece 0..2] x 1 KB,   fragment = lane (row l&31, half l>>5) x 8 bf16 (k-slots 8 (l>>5) + e)
 // Forward order: layer 0: half A: TN16_KE input k-steps, half B: the same; layer l >= 1: per half hidden/16 hidden k-steps
-// (+ TN16_KE input k-steps for the skip layer); heads: hidden/16 k-steps whose records carry the head tile (rows r,g,b,sigma)
-// at slot 0 and zeros elsewhere.  k-slot <-> feature maps as in the bf16 mode (above).  Records are cut into stages of
+// (+ TN16_KE input k-steps for the skip layer); heads: ONE output tile (rows r,g,b,sigma), so the NT/2 slots of a record carry
+// NT/2 consecutive k-steps of it: hidden/16 / (NT/2) records.  k-slot <-> feature maps as in the bf16 mode (above).  Records are cut into stages of
 // TX_STAGE fragments (24 KB: two records of a 256-wide net, four of a 128-wide one) for the LDS ring.  After the stream: the
 // fp32 biases as in the bf16 mode.
 #define TX_STAGE 24
