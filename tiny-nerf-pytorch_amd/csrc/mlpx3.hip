@@ -241,7 +241,7 @@ __device__ __forceinline__ void tx_bwd_tile(PipeX& p, const unsigned char* lds, 
 #pragma unroll
     for (int w = 0; w < NT / 2; ++w) mw[w] = mk.v[w];
     zrow = pl + L.dz_row0[depth - 1] * 32;
-    tx_drain<NP>(epiA);
+    tx_drain<NP, 6>(epiA);
     // layer l (dH_{l-1} = W_l^T dZ_l): dZ_l's half B epilogue behind the first half of pass A; the sign words of layer l-1 are
     // fetched before pass A and waited for (>= TX_LEAD boundaries later) at the start of dZ_{l-1}'s half A epilogue, which rides
     // on the second half of pass B
@@ -259,7 +259,7 @@ __device__ __forceinline__ void tx_bwd_tile(PipeX& p, const unsigned char* lds, 
             winA(sc);
         });
     }
-    tx_drain<NP>(epiB);                                            // dZ_0, half B
+    tx_drain<NP, 3>(epiB);                                         // dZ_0, half B: to the stash only
 }
 
 template <int HID>

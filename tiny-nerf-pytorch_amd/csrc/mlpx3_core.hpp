@@ -312,11 +312,11 @@ __device__ __forceinline__ auto tx_window(F&& f) {
         }
     };
 }
-// A whole epilogue with nothing to hide behind.
-template <int NP, typename F>
+// A whole epilogue with nothing to hide behind.  NJ = 6: all micro-steps; 3: without the split (nothing consumes the pieces).
+template <int NP, int NJ, typename F>
 __device__ __forceinline__ void tx_drain(F&& f) {
     tn_static_for<NP>([&](auto ic) TN_INLINE_LAMBDA {
-        tn_static_for<6>([&](auto jc) TN_INLINE_LAMBDA { f(ic, jc, std::integral_constant<int, 1>{}); });
+        tn_static_for<NJ>([&](auto jc) TN_INLINE_LAMBDA { f(ic, jc, std::integral_constant<int, 1>{}); });
     });
 }
 
