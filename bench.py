@@ -423,6 +423,9 @@ def run(args):
         out["kernels"] = {k: {"ms": kern[k], "tflops": (fl[k] / (kern[k] * 1e-3) / 1e12) if k in fl else None,
                               "mfma_frac": (fl[k] / (kern[k] * 1e-3) / 1e12 / _peak(k)) if k in fl else None,
                               "mfma_peak": _peak(k) if k in fl else None, "ms_alone": kern_iso[k]} for k in kern}
+        for k_ in out["kernels"]:
+            if cap and k_ in cap and isinstance(cap[k_], dict):
+                out["kernels"][k_]["traffic"] = cap[k_]["hbm_bytes"]
         out["kernels"]["_timing"] = ("ms: HIP events between the launches of train_fwd -> dgrad -> wgrad -> reduce issued back to back in step "
                                      "order (the other entries: alone); ms_alone: the same launch repeated on its own")
         # the weight-gradient kernel runs its products on the bf16 matrix pipe (exact 3-way split): it is HBM-bound — its own roofline
