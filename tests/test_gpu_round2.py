@@ -594,3 +594,67 @@ def test_hidden_widths_other_than_128_and_256(mods, dev, arch):
         # Adam's first steps move every weight by ~lr * g / (|g| + eps): units of these narrow random-init nets that are (almost)
         # dead have |g| ~ eps = 1e-8, where fp32 noise in g changes the update by a fraction of lr = 5e-4
         assert err <= (2.5e-4 if prec == "fp32" else 2e-3), (prec, err)
+
+
+# ------------------------------------------------- the split-bf16 chain kernels against the fp32-MFMA ones, region by region
+@pytest.mark.parametrize("tag,R,S", [("4x128", 101, 72), ("8x256", 64, 32), ("8x256", 37, 100)])
+def test_x3_chain_kernels_fill_the_stash_like_the_fp32_mfma_kernels(mods, dev, tag, R, S):
+    """tnerf_train_fwd_fused_x3 / tnerf_train_dgrad_fused_x3 (fp32 products formed exactly on the bf16 matrix pipe,
+    half-pass walk, epilogues in the MFMA shadows) write the SAME training stash as the round-1 fp32-MFMA kernels — encoder
+    rows bit-identical, activations / head outputs / every dZ to fp32 rounding, ReLU sign words identical except where an
+    activation is within rounding of zero — for ragged ray counts (R % 4 != 0) and sample counts (S % 32 != 0, two segments)."""
+    ops, lib = mods["ops"], mods["lib"]
+    cfg, params = golden_params(tag)
+    m = make_model(mods, cfg, params, dev)
+    st = m._ensure_packed(); x3 = st.repack_x3(("t", 0))
+    g = torch.Generator().manual_seed(11)
+    d = torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=-1).to(dev)
+    o = (-4.0 * d + 0.1).contiguous(); u = torch.rand(R, S, generator=g).to(dev)
+    gc = (torch.randn(R, 3, generator=g) / (3 * R)).to(dev)
+    plan = st.plan(R * S); ztab = ops.depth_table(2.0, 6.0, S, dev)
+    sA, sB = torch.zeros_like(plan.stash), torch.zeros_like(plan.stash)
+    cA, cB = torch.empty(R, 3, device=dev), torch.empty(R, 3, device=dev)
+    sp = torch.cuda.current_stream(dev).cuda_stream
+    common = (o.data_ptr(), d.data_ptr(), R, S, ztab.data_ptr(), 1, u.data_ptr(), 0, 0, 1)
+    lib.call("tnerf_train_fwd_fused", C.byref(st.desc), st.packed.data_ptr(), *common, cA.data_ptr(), sA.data_ptr(), plan.Mp, sp)
+    lib.call("tnerf_train_fwd_fused_x3", C.byref(st.desc), x3.packed.data_ptr(), *common, cB.data_ptr(), sB.data_ptr(), plan.Mp, sp)
+    torch.cuda.synchronize()
+    H = 128 if cfg["hidden"] <= 128 else 256
+    NE, depth, NT = (32 if cfg["L"] == 10 else 20), cfg["depth"], H // 32
+    rows = 2 * NE + depth * H + 4 + depth * H + 4
+    M, Mp = R * S, plan.Mp
+    nb = (M + 31) // 32
+
+    def blocks(s):
+        return s[: (Mp // 32 + 1) * rows * 32].view(-1, rows, 32)[:nb].cpu().double()
+
+    def valid(t):                                                   # [nb, rows, 32] -> only the samples < M of the last block
+        t = t.clone(); t.view(nb, -1, 32)[-1, :, M - 32 * (nb - 1):] = 0; return t
+    A, B = valid(blocks(sA)), valid(blocks(sB))
+    assert float((cA - cB).abs().max()) <= 1e-6
+    assert torch.equal(A[:, :2 * NE], B[:, :2 * NE])                # the network input: same encoder arithmetic
+    r0 = 2 * NE
+    for l in range(depth):
+        a, b = A[:, r0:r0 + H], B[:, r0:r0 + H]
+        assert float((a - b).norm() / a.norm()) <= 2e-6, (l, float((a - b).norm() / a.norm()))
+        assert float((a - b).abs().max()) <= 4e-6 * float(a.abs().max())
+        r0 += H
+    assert float((A[:, r0:r0 + 4] - B[:, r0:r0 + 4]).abs().max()) <= 4e-6 * max(1.0, float(A[:, r0:r0 + 4].abs().max()))
+    body = rows * (Mp + 32)
+    mA, mB = sA[body:].view(torch.int32).cpu(), sB[body:].view(torch.int32).cpu()
+    for l in range(depth):
+        a = mA[l * (Mp + 32) * NT: l * (Mp + 32) * NT + M * NT]; b = mB[l * (Mp + 32) * NT: l * (Mp + 32) * NT + M * NT]
+        flips = sum(bin(int(v) & 0xffffffff).count("1") for v in (a ^ b)[(a ^ b) != 0])
+        assert flips <= 1e-5 * M * H + 2, (l, flips)               # an activation within rounding of 0 may land on either side
+    # dgrad: both kernels on the SAME forward stash
+    sC = sA.clone()
+    lib.call("tnerf_train_dgrad_fused", C.byref(st.desc), st.packed.data_ptr(), *common, gc.data_ptr(), sA.data_ptr(), plan.Mp, sp)
+    lib.call("tnerf_train_dgrad_fused_x3", C.byref(st.desc), x3.packed.data_ptr(), *common, gc.data_ptr(), sC.data_ptr(), plan.Mp, sp)
+    torch.cuda.synchronize()
+    A, B = valid(blocks(sA)), valid(blocks(sC))
+    r0 = 2 * NE + depth * H + 4
+    for l in range(depth):
+        a, b = A[:, r0:r0 + H], B[:, r0:r0 + H]
+        assert float((a - b).norm() / a.norm()) <= 2e-6, (l, float((a - b).norm() / a.norm()))
+        r0 += H
+    assert torch.equal(A[:, r0:r0 + 4], B[:, r0:r0 + 4])            # the head gradients: same composite backward
