@@ -46,7 +46,7 @@ __device__ __forceinline__ void tx_mlp_tile(PipeX& p, const unsigned char* lds, 
             if (st < L.NE) TN_STASH_STORE(&pl[(L.enc_row0 + 2 * st - 3 * h) * 32], encf[st]);
         });
     }
-    constexpr int NH = NT / 2, KH = HID / 16, NP = NH * 8;
+    constexpr int NH = NT / 2, KH = HID / 16, NP = NH * 8, NW = TxCfg<HID, TRAIN>::NW;
     ActX<HID> X;
     f32x16 accA[NH], accB[NH];
     TxEpi es;
@@ -62,19 +62,19 @@ __device__ __forceinline__ void tx_mlp_tile(PipeX& p, const unsigned char* lds, 
     auto none = [](auto) TN_INLINE_LAMBDA {};
     TX_PROF_BEGIN(pf);
     // layer 0: half A bare, half A's epilogue behind half B
-    tx_pass<HID, 0, true>(p, lds, X, E, accA, none);
+    tx_pass<HID, 0, true, NW>(p, lds, X, E, accA, none);
     point_at(0);
-    tx_pass<HID, 0, true>(p, lds, X, E, accB, tx_window<0, TN16_KE * NH, NP>(epiA));
+    tx_pass<HID, 0, true, NW>(p, lds, X, E, accB, tx_window<0, TN16_KE * NH, NP>(epiA));
     // layer l: half B's epilogue of layer l-1 behind the first half of pass A, half A's of layer l behind the second half of pass B
     for (int l = 1; l < depth; ++l) {
-        tx_pass<HID, 1, true>(p, lds, X, E, accA, tx_window<0, KH / 2 * NH, NP>(epiB));
-        if (l == skip_at) tx_pass<HID, 0, false>(p, lds, X, E, accA, none);                    // + W_l[:, hidden:] . encoding
+        tx_pass<HID, 1, true, NW>(p, lds, X, E, accA, tx_window<0, KH / 2 * NH, NP>(epiB));
+        if (l == skip_at) tx_pass<HID, 0, false, NW>(p, lds, X, E, accA, none);                    // + W_l[:, hidden:] . encoding
         point_at(l);
-        tx_pass<HID, 1, true>(p, lds, X, E, accB, tx_window<KH / 2 * NH * 6, KH / 2 * NH, NP>(epiA));
-        if (l == skip_at) tx_pass<HID, 0, false>(p, lds, X, E, accB, none);
+        tx_pass<HID, 1, true, NW>(p, lds, X, E, accB, tx_window<KH / 2 * NH * 6, KH / 2 * NH, NP>(epiA));
+        if (l == skip_at) tx_pass<HID, 0, false, NW>(p, lds, X, E, accB, none);
     }
     // heads (tile slot 0 of accA): the last layer's half B epilogue must be through before k-step KH/2
-    tx_pass<HID, 3, true>(p, lds, X, E, accA, tx_window<0, KH / 2, NP>(epiB));
+    tx_pass<HID, 3, true, NW>(p, lds, X, E, accA, tx_window<0, KH / 2, NP>(epiB));
     TX_PROF_ADD(pf, walk);
     const f32x16 (&acc)[NH] = accA;
     // heads: rows 0..2 = rgb.0 (sigmoid), row 3 = sigma.0 (ReLU)                                   nerf.py:39-40
@@ -85,7 +85,8 @@ __device__ __forceinline__ void tx_mlp_tile(PipeX& p, const unsigned char* lds, 
 }
 
 template <int HID, bool TRAIN>
-__global__ __launch_bounds__(256, 1) void k_renderx3(FwdX3Args a) {
+__global__ __launch_bounds__((TxCfg<HID, TRAIN>::NW * 64), 1) void k_renderx3(FwdX3Args a) {
+    constexpr int NW = TxCfg<HID, TRAIN>::NW;
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
     const int lane = tn_lane();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(256, 1) void k_renderx3(FwdX3Args a) {
     if (TRAIN) tn_resolve_step(rs, sa);                            // dataset mode: this step's image and Philox counters
     const int S = sa.S, Lf = a.n.Lf;
     PipeX p;
-    tx_prologue(p, lds, a.packed3, a.n, a.packed3, a.n.n_stage, lane, wave);
+    tx_prologue<NW>(p, lds, a.packed3, a.n, a.packed3, a.n.n_stage, lane, wave);
     TxProf pf;
 #ifdef TN_STAMPS
     const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
@@ -103,9 +104,9 @@ __global__ __launch_bounds__(256, 1) void k_renderx3(FwdX3Args a) {
     // Every wave of the workgroup runs the same number of network passes (the stage barriers are workgroup-wide): rays beyond
     // R are computed on a clamped index and stored nowhere (training: into the dump block).
     const int64_t R = a.f.R;
-    const int64_t n_groups = (R + 3) / 4;
+    const int64_t n_groups = (R + NW - 1) / NW;
     for (int64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
-        const int64_t ray = g * 4 + wave;
+        const int64_t ray = g * NW + wave;
         const bool rvalid = ray < R;
         const int64_t rayc = rvalid ? ray : R - 1;
         float ro_[3], rd_[3];
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(256, 1) void k_renderx3(FwdX3Args a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // no DMA may still be writing this workgroup's LDS at exit
 #ifdef TN_STAMPS
     if (a.f.stamps && lane == 0) {
-        unsigned long long* o = a.f.stamps + (blockIdx.x * 4 + wave) * 8;
+        unsigned long long* o = a.f.stamps + (blockIdx.x * NW + wave) * 8;
         o[0] = __builtin_amdgcn_s_memtime() - st_c0; o[1] = __builtin_amdgcn_s_memrealtime() - st_r0; o[2] = pf.walk; o[3] = pf.epi;
     }
 #endif
@@ -226,7 +227,7 @@ __device__ __forceinline__ void tx_bwd_tile(PipeX& p, const unsigned char* lds, 
         const u32x4 w1 = {a0, a1, 0u, 0u}, w2 = {b0, b1, 0u, 0u}, w3 = {c0, c1, 0u, 0u};
         Z.p1[0] = __builtin_bit_cast(bf16x8, w1); Z.p2[0] = __builtin_bit_cast(bf16x8, w2); Z.p3[0] = __builtin_bit_cast(bf16x8, w3);
     }
-    constexpr int NH = NT / 2, KH = HID / 16, NP = NH * 8;
+    constexpr int NH = NT / 2, KH = HID / 16, NP = NH * 8, NW = TxCfg<HID>::NW;
     f32x16 accA[NH], accB[NH];
     uint32_t mw[NT / 2];
     TxEpi es;
@@ -236,8 +237,8 @@ __device__ __forceinline__ void tx_bwd_tile(PipeX& p, const unsigned char* lds, 
     auto epiB = [&](auto ic, auto jc, auto) TN_INLINE_LAMBDA { tx_epi_bwd<HID, 1, decltype(ic)::value, decltype(jc)::value>(accB, X, es, mw, zrow); };
     // dH_{depth-1} = W_head^T dZ_head: both halves; half A's epilogue has nothing to hide behind
     mk.fetch(mrow + (int64_t)(depth - 1) * (Mp + 32) * NT);
-    tx_pass_headsT<HID>(p, lds, Z, accA, accB);
-    mk.template wait<TX_DPW>();                                    // one boundary (TX_DPW DMAs) was issued behind the fetch
+    tx_pass_headsT<HID, NW>(p, lds, Z, accA, accB);
+    mk.template wait<TxCfg<HID>::DPW>();                           // one boundary (DPW DMAs) was issued behind the fetch
 #pragma unroll
     for (int w = 0; w < NT / 2; ++w) mw[w] = mk.v[w];
     zrow = pl + L.dz_row0[depth - 1] * 32;
@@ -247,11 +248,11 @@ __device__ __forceinline__ void tx_bwd_tile(PipeX& p, const unsigned char* lds, 
     // on the second half of pass B
     for (int l = depth - 1; l >= 1; --l) {
         mk.fetch(mrow + (int64_t)(l - 1) * (Mp + 32) * NT);
-        tx_pass<HID, 1, true>(p, lds, X, Z, accA, tx_window<0, KH / 2 * NH, NP>(epiB));
+        tx_pass<HID, 1, true, NW>(p, lds, X, Z, accA, tx_window<0, KH / 2 * NH, NP>(epiB));
         auto winA = tx_window<KH / 2 * NH * 6, KH / 2 * NH, NP>(epiA);
-        tx_pass<HID, 1, true>(p, lds, X, Z, accB, [&](auto sc) TN_INLINE_LAMBDA {
+        tx_pass<HID, 1, true, NW>(p, lds, X, Z, accB, [&](auto sc) TN_INLINE_LAMBDA {
             if constexpr (decltype(sc)::value == KH / 2 * NH * 6) {
-                mk.template wait<TX_DPW * TX_LEAD>();
+                mk.template wait<TxCfg<HID>::DPW * TX_LEAD>();
 #pragma unroll
                 for (int w = 0; w < NT / 2; ++w) mw[w] = mk.v[w];
                 zrow = pl + L.dz_row0[l - 1] * 32;
@@ -263,7 +264,8 @@ __device__ __forceinline__ void tx_bwd_tile(PipeX& p, const unsigned char* lds, 
 }
 
 template <int HID>
-__global__ __launch_bounds__(256, 1) void k_dgradx3(BwdX3Args a) {
+__global__ __launch_bounds__(TxCfg<HID>::NW * 64, 1) void k_dgradx3(BwdX3Args a) {
+    constexpr int NW = TxCfg<HID>::NW;
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
     const int lane = tn_lane();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -272,12 +274,12 @@ __global__ __launch_bounds__(256, 1) void k_dgradx3(BwdX3Args a) {
     const int S = sa.S;
     const int nseg = (S + 63) / 64;
     PipeX p;
-    tx_prologue(p, lds, a.packed3, a.n, a.packed3 + (int64_t)a.n.n_rec * a.n.rec_frags * 1024, a.n.n_bw_stage, lane, wave);
+    tx_prologue<NW>(p, lds, a.packed3, a.n, a.packed3 + (int64_t)a.n.n_rec * a.n.rec_frags * 1024, a.n.n_bw_stage, lane, wave);
     const int64_t R = a.b.R;
-    const int64_t n_groups = (R + 3) / 4;
+    const int64_t n_groups = (R + NW - 1) / NW;
     const int orow = a.b.L.out_row0 * 32; const int64_t SR = a.b.L.stash_rows;
     for (int64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
-        const int64_t ray = g * 4 + wave;
+        const int64_t ray = g * NW + wave;
         const bool rvalid = ray < R;
         const int64_t rayc = rvalid ? ray : R - 1;
         float ro_[3], rd_[3];
@@ -346,8 +348,9 @@ __global__ __launch_bounds__(256, 1) void k_dgradx3(BwdX3Args a) {
 
 int tnx3_launch_dgrad(const BwdX3Args& a, hipStream_t stream, const char* who) {
     const int dev = tn_stream_device(stream), n_cu = tn_device_cus(dev);
-    const int64_t groups = (a.b.R + 3) / 4;
-    const dim3 grid((unsigned)(groups < n_cu ? groups : n_cu)), block(256);
+    const int nw = a.n.hidden == 256 ? TxCfg<256>::NW : TxCfg<128>::NW;
+    const int64_t groups = (a.b.R + nw - 1) / nw;
+    const dim3 grid((unsigned)(groups < n_cu ? groups : n_cu)), block(nw * 64);
     const size_t lds_bytes = TX_RING + (size_t)((a.n.n_bias + 3) / 4 * 4) * 4;
     if (a.n.hidden == 256) {
         static std::atomic<uint32_t> seen_[TN_MAX_DEVICES];
@@ -372,8 +375,9 @@ int tnx3_train_dgrad(const char* who, const BwdArgs& b, const tnerf_mlp_desc* d,
 
 int tnx3_launch_fwd(const FwdX3Args& a, bool train, hipStream_t stream, const char* who) {
     const int dev = tn_stream_device(stream), n_cu = tn_device_cus(dev);
-    const int64_t groups = (a.f.R + 3) / 4;
-    const dim3 grid((unsigned)(groups < n_cu ? groups : n_cu)), block(256);
+    const int nw = a.n.hidden == 256 ? 4 : (train ? TxCfg<128, true>::NW : TxCfg<128, false>::NW);
+    const int64_t groups = (a.f.R + nw - 1) / nw;
+    const dim3 grid((unsigned)(groups < n_cu ? groups : n_cu)), block(nw * 64);
     const size_t lds_bytes = TX_RING + (size_t)((a.n.n_bias + 3) / 4 * 4) * 4;
 #define TX_CASE(H_, T_)                                                                                                      \
     if (a.n.hidden == H_ && train == T_) {                                                                                    \

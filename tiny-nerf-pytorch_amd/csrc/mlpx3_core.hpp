@@ -25,8 +25,18 @@
 #define TX_NS 5                                // ring slots
 #define TX_RING (TX_NS * TX_SLOT)              // 120 KB
 #define TX_LEAD 3                              // stages in flight behind the published one (LEAD + 2 <= NS)
-#define TX_DPW (TX_STAGE / 4)                  // DMA instructions per wave and stage (4 waves)
-static_assert(TX_LEAD + 2 <= TX_NS && TX_STAGE % 4 == 0, "ring budget");
+// Waves per workgroup: 256-wide nets need the 512-register budget of one wave per SIMD; a 128-wide wave fits 256 registers, so
+// two of them share a SIMD and fill each other's gaps (encoder, compositing, barriers).
+#ifndef TX_NW128
+#define TX_NW128 8
+#endif
+// (The 128-wide TRAINING forward keeps four: its stash pointers and sign words do not fit 256 registers — 91 spilled.)
+template <int HID, bool TRAIN_FWD = false> struct TxCfg {
+    static constexpr int NW = (HID == 128 && !TRAIN_FWD) ? TX_NW128 : 4;
+    static constexpr int DPW = TX_STAGE / NW;                     // DMA pieces per wave and stage
+    static_assert(TX_STAGE % NW == 0 && DPW <= 8, "ring budget");
+};
+static_assert(TX_LEAD + 2 <= TX_NS, "ring budget");
 
 // x (two fp32) -> the three packed bf16 pieces of the pair: dword = (hi16 of piece(x1)) : (hi16 of piece(x0))
 __device__ __forceinline__ void tx_split2(float x0, float x1, unsigned& p1, unsigned& p2, unsigned& p3) {
@@ -46,12 +56,12 @@ struct PipeX {
     const unsigned char* src;    // packed record stream
     uint32_t src_off, stream_bytes;
     uint32_t dst_off;            // ring offset of the slot the next DMA fills
-    uint32_t lds_dst0;           // absolute LDS address of ring + wave * TX_DPW KB
-    uint32_t voff;               // lane * 16 + wave * TX_DPW * 1024: this wave's first piece of a stage
+    uint32_t lds_dst0;           // absolute LDS address of ring + wave * DPW KB
+    uint32_t voff;               // lane * 16 + wave * DPW * 1024: this wave's first piece of a stage
     const unsigned char* pend_src; uint32_t pend_dst;      // the stage whose pieces are being issued behind MFMAs (tx_defer_stage)
 };
 
-// This wave's TX_DPW (= 6) pieces of a stage are 1 KB each, consecutive in the stream and in the slot: piece i is the pending
+// This wave's DPW pieces of a stage are 1 KB each, consecutive in the stream and in the slot: piece i is the pending
 // stage's base (+ 4 KB for i >= 4) with the instruction's immediate offset (i & 3) KB — the offset applies to the global AND
 // the LDS address.  M0 (the DMA's LDS base) is compiler-reserved: saved and restored around the load.
 template <int I>
@@ -61,9 +71,10 @@ __device__ __forceinline__ void tx_issue_piece(const unsigned char* src, uint32_
                  : "=&s"(keep) : "v"(voff), "s"(src + (I >> 2) * 4096), "s"(lds_dst + (I >> 2) * 4096), "n"((I & 3) * 1024) : "memory");
 }
 // the stage `dst_off` / `src_off` point at: all pieces now (prologue, heads^T) ...
+template <int DPW>
 __device__ __forceinline__ void tx_issue_stage(PipeX& p) {
     const unsigned char* s = p.src + p.src_off;
-    tn_static_for<TX_DPW>([&](auto ic) TN_INLINE_LAMBDA { tx_issue_piece<decltype(ic)::value>(s, p.voff, p.lds_dst0 + p.dst_off); });
+    tn_static_for<DPW>([&](auto ic) TN_INLINE_LAMBDA { tx_issue_piece<decltype(ic)::value>(s, p.voff, p.lds_dst0 + p.dst_off); });
     p.src_off += TX_SLOT; if (p.src_off == p.stream_bytes) p.src_off = 0;
     p.dst_off += TX_SLOT; if (p.dst_off == TX_RING) p.dst_off = 0;
 }
@@ -79,31 +90,33 @@ __device__ __forceinline__ void tx_defer_stage(PipeX& p) {
 // are allowed to be outstanding — the training kernels interleave global stores with the stream, see mlp16_core.hpp),
 // barrier (the stage is readable by everyone, the slot of the previous one is free), issue stage + LEAD (DEFER: the caller
 // issues its pieces with tx_issue_piece before the next boundary).
-template <int STORES, bool DEFER = false>
+template <int DPW, bool DEFER>
 __device__ __forceinline__ void tx_boundary(PipeX& p) {
-    TN16_WAIT_VM(TX_DPW * (TX_LEAD - 1) + STORES);
+    TN16_WAIT_VM(DPW * (TX_LEAD - 1));
     __builtin_amdgcn_s_barrier();
-    if constexpr (DEFER) tx_defer_stage(p); else tx_issue_stage(p);
+    if constexpr (DEFER) tx_defer_stage(p); else tx_issue_stage<DPW>(p);
     p.cur += TX_SLOT; if (p.cur == TX_RING) p.cur = 0;
 }
 
 // Workgroup prologue: biases -> LDS, LEAD stages in flight, the first one landed; the first tx_boundary publishes stage 0.
 // `src` / `n_stage`: the stream this kernel walks (forward: packed, n.n_stage; dgrad: the backward stream behind it).
+template <int NW>
 __device__ __forceinline__ void tx_prologue(PipeX& p, unsigned char* lds, const unsigned char* packed, const NetX3& n,
                                             const unsigned char* src, int n_stage, int lane, int wave) {
+    constexpr int DPW = TX_STAGE / NW;
     {
         float* bl = reinterpret_cast<float*>(lds + TX_RING);
         const float* bg = reinterpret_cast<const float*>(packed + n.bias_off);
-        for (int i = threadIdx.x; i < n.n_bias; i += 256) bl[i] = bg[i];
+        for (int i = threadIdx.x; i < n.n_bias; i += NW * 64) bl[i] = bg[i];
     }
     p.lane16 = lane * 16;
     p.src = src; p.src_off = 0; p.stream_bytes = (uint32_t)n_stage * TX_SLOT;
     p.dst_off = 0;
-    p.lds_dst0 = (uint32_t)(uintptr_t)lds + wave * (TX_DPW * 1024);
-    p.voff = lane * 16 + wave * TX_DPW * 1024;
+    p.lds_dst0 = (uint32_t)(uintptr_t)lds + wave * (DPW * 1024);
+    p.voff = lane * 16 + wave * DPW * 1024;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int i = 0; i < TX_LEAD; ++i) tx_issue_stage(p);
+    for (int i = 0; i < TX_LEAD; ++i) tx_issue_stage<DPW>(p);
     p.cur = TX_RING - TX_SLOT;                   // the first boundary moves it onto slot 0
 }
 
@@ -146,10 +159,10 @@ __device__ __forceinline__ FragX tx_frag_load(const unsigned char* base, int tl)
 // phase of record k is k % RPS.  ZERO: the accumulators start at zero.
 // hook(integral_constant<slot>) is called behind MFMA number slot = (k * NTU + tile) * 6 + j: work to issue in its shadow.
 // The next group's A fragments are read from LDS behind the first MFMA of a group (not across a stage boundary).
-template <int HID, int KIND, bool ZERO, typename Hook>
+template <int HID, int KIND, bool ZERO, int NW, typename Hook>
 __device__ __forceinline__ void tx_pass(PipeX& p, const unsigned char* lds, const ActX<HID>& X, const EncX& E,
                                         f32x16 (&acc)[HID / 64], Hook&& hook) {
-    constexpr int NH = HID / 64, KH = HID / 16, RPS = TX_STAGE / (NH * 3);
+    constexpr int NH = HID / 64, KH = HID / 16, RPS = TX_STAGE / (NH * 3), DPW = TX_STAGE / NW;
     constexpr int NK = KIND == 0 ? TN16_KE : (KIND == 3 ? KH / NH : KH);
     constexpr int NTU = NH;
     static_assert(NK % RPS == 0, "a half-pass must be a whole number of stages");
@@ -160,7 +173,7 @@ __device__ __forceinline__ void tx_pass(PipeX& p, const unsigned char* lds, cons
         // EARLY — in front of the last group of the stage before, whose A fragments are already in registers — so that the new
         // stage's first fragments are read behind that group's MFMAs instead of in front of an idle matrix pipe.  (The ring has
         // the spare slot this needs: TX_LEAD + 2 <= TX_NS.)
-        if constexpr (k == 0) tx_boundary<0, true>(p);
+        if constexpr (k == 0) tx_boundary<DPW, true>(p);
         const unsigned char* base = lds + p.cur + (k % RPS) * (NH * 3 * 1024) + p.lane16;
         if constexpr (k == 0) cur = tx_frag_load(base, 0);
         tn_static_for<NTU>([&](auto tc) TN_INLINE_LAMBDA {
@@ -175,7 +188,7 @@ __device__ __forceinline__ void tx_pass(PipeX& p, const unsigned char* lds, cons
             constexpr bool early = !more_tile && (k + 1) % RPS == 0 && k + 1 < NK;      // last group of a stage, another follows in this pass
             constexpr int s0 = (k * NTU + tl) * 6;
             FragX nxt;
-            if constexpr (early) tx_boundary<0, true>(p);
+            if constexpr (early) tx_boundary<DPW, true>(p);
             if constexpr (ZERO && ks == 0) { const f32x16 z = {}; acc[ta] = TN16_MFMA(cur.a3, b1, z); }
             else                          acc[ta] = TN16_MFMA(cur.a3, b1, acc[ta]);
             if constexpr (more_tile)     nxt = tx_frag_load(base, tl + 1);
@@ -186,10 +199,10 @@ __device__ __forceinline__ void tx_pass(PipeX& p, const unsigned char* lds, cons
             acc[ta] = TN16_MFMA(cur.a1, b3, acc[ta]); hook(std::integral_constant<int, s0 + 2>{}); TX_PIN();
             acc[ta] = TN16_MFMA(cur.a2, b1, acc[ta]); hook(std::integral_constant<int, s0 + 3>{});
             {   // this group's share of the pending stage's DMA pieces
-                constexpr int GPS = RPS * NTU, PPS = (TX_DPW + GPS - 2) / (GPS - 1), g = (k % RPS) * NTU + tl;
+                constexpr int GPS = RPS * NTU, PPS = (DPW + GPS - 2) / (GPS - 1), g = (k % RPS) * NTU + tl;
                 tn_static_for<PPS>([&](auto uc) TN_INLINE_LAMBDA {
                     constexpr int i = g * PPS + decltype(uc)::value;
-                    if constexpr (i < TX_DPW && g < GPS - 1) tx_issue_piece<i>(p.pend_src, p.voff, p.pend_dst);
+                    if constexpr (i < DPW && g < GPS - 1) tx_issue_piece<i>(p.pend_src, p.voff, p.pend_dst);
                 });
             }
             TX_PIN();
@@ -202,10 +215,10 @@ __device__ __forceinline__ void tx_pass(PipeX& p, const unsigned char* lds, cons
 
 // heads^T of the backward stream: ONE k-step (B operand = Z.p*[0]) into both halves' accumulators; the stage holds record A,
 // record B and padding.
-template <int HID>
+template <int HID, int NW>
 __device__ __forceinline__ void tx_pass_headsT(PipeX& p, const unsigned char* lds, const EncX& Z, f32x16 (&accA)[HID / 64], f32x16 (&accB)[HID / 64]) {
     constexpr int NH = HID / 64;
-    tx_boundary<0>(p);
+    tx_boundary<TX_STAGE / NW, false>(p);
     const unsigned char* base = lds + p.cur + p.lane16;
     const f32x16 z = {};
     tn_static_for<2 * NH>([&](auto tc) TN_INLINE_LAMBDA {
