@@ -235,8 +235,8 @@ int tnerf_train_step_fused(const tnerf_mlp_desc* d, const float* packed,
                            float* stash, int64_t stash_row_stride,
                            const int32_t* job_table, int64_t n_jobs, float* slabs,
                            const int32_t* reduce_table, float* grads,
-                           const void* packed_x3 /* NULL, or the record stream of tnerf_mlp_pack_x3: the forward then runs on the
-                                                    x3 chain kernel (unless TNERF_FLAG_FP32_MFMA) */,
+                           const void* packed_x3 /* NULL, or the record stream of tnerf_mlp_pack_x3: the forward and dgrad chains
+                                                    then run on the x3 kernels (unless TNERF_FLAG_FP32_MFMA) */,
                            tnerf_stream_t stream);
 
 /* Camera-sourced rays: instead of gathering from the (N,HW,3) tables that the reference
@@ -317,7 +317,7 @@ typedef struct tnerf_step_args {
     const int32_t* scatter_table; /* [n_params, scatter_width]: positions of parameter i in `packed` (-1 terminated),
                                      the inverse of the pack table; NULL = do not re-pack                            */
     int32_t scatter_width;
-    /* fp32 only: the x3 record stream (tnerf_mlp_pack_x3) — the forward then runs on the x3 chain kernel — and the inverse of
+    /* fp32 only: the x3 record stream (tnerf_mlp_pack_x3) — the forward and dgrad chains then run on the x3 kernels — and the inverse of
      * its pack table so that the finishing kernel keeps it current.  NULL = fp32-MFMA forward.                       */
     const void* packed_x3;
     const int32_t* scatter_x3;

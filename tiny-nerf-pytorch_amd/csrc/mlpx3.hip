@@ -2,8 +2,10 @@
 // with the MLP's fp32 products formed exactly on the bf16 matrix pipe (mlpx3_core.hpp).  Same inputs, outputs, sample bins,
 // encoder arithmetic (fp32-accurate sin/cos), compositing and — when training — the same block-major fp32 stash (activations,
 // ReLU sign bits, head outputs, loss gradient) as the fp32-MFMA kernels of mlp_fwd.hip, so the dgrad / weight-gradient kernels
-// and every caller are unchanged.  One persistent 256-thread workgroup per CU (4 waves = one per SIMD, 512-register budget);
-// a wave owns one ray at a time and marches it 32 samples per pass over the record stream.
+// and every caller are unchanged.  One persistent workgroup per CU — 4 waves (one per SIMD, 512-register budget) for 256-wide
+// networks and the 128-wide training forward, 8 waves (two per SIMD) for the 128-wide inference and dgrad kernels (TxCfg);
+// a wave owns one ray at a time and marches it 32 samples per pass over the record stream.  A layer is two half-passes whose
+// epilogues ride in each other's MFMA shadows (mlpx3_core.hpp).
 #include "mlpx3_core.hpp"
 #include "mlp_args.hpp"
 

@@ -86,8 +86,8 @@ __device__ __forceinline__ void tx_defer_stage(PipeX& p) {
     p.dst_off += TX_SLOT; if (p.dst_off == TX_RING) p.dst_off = 0;
 }
 
-// Start of a stage: wait for this wave's DMA of the stage (LEAD-1 younger ones may stay in flight; STORES more operations
-// are allowed to be outstanding — the training kernels interleave global stores with the stream, see mlp16_core.hpp),
+// Start of a stage: wait for this wave's DMA of the stage (LEAD-1 younger ones may stay in flight; the training kernels' stash
+// stores, which are younger still, make this wait stricter than it needs to be, never laxer: vmcnt retires in issue order),
 // barrier (the stage is readable by everyone, the slot of the previous one is free), issue stage + LEAD (DEFER: the caller
 // issues its pieces with tx_issue_piece before the next boundary).
 template <int DPW, bool DEFER>
@@ -125,19 +125,6 @@ template <int HID>
 struct ActX { u32x4 p1[HID / 16], p2[HID / 16], p3[HID / 16]; };          // packed bf16 pairs; dword q = values 2q, 2q+1 of the k-step
 #define TX_BF(x) __builtin_bit_cast(bf16x8, (x))
 struct EncX { bf16x8 p1[TN16_KE], p2[TN16_KE], p3[TN16_KE]; };
-
-// Six exact partial products of one (n-tile, k-step): small terms first.  FIRST: the accumulator starts at zero.
-template <bool FIRST>
-__device__ __forceinline__ void tx_mfma6(f32x16& acc, const bf16x8& a1, const bf16x8& a2, const bf16x8& a3,
-                                         const bf16x8& b1, const bf16x8& b2, const bf16x8& b3) {
-    if constexpr (FIRST) { const f32x16 z = {}; acc = TN16_MFMA(a3, b1, z); }
-    else                 acc = TN16_MFMA(a3, b1, acc);
-    acc = TN16_MFMA(a2, b2, acc);
-    acc = TN16_MFMA(a1, b3, acc);
-    acc = TN16_MFMA(a2, b1, acc);
-    acc = TN16_MFMA(a1, b2, acc);
-    acc = TN16_MFMA(a1, b1, acc);
-}
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 struct FragX { bf16x8 a1, a2, a3; };
