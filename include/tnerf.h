@@ -445,6 +445,16 @@ int tnerf_train_fwd_fused_x3(const tnerf_mlp_desc* d, const void* packed3,
                              uint64_t seed, uint64_t offset, int32_t white_bkgd,
                              float* comp_rgb, float* stash, int64_t stash_row_stride, tnerf_stream_t stream);
 
+/* tnerf_mlp_fwd / tnerf_mlp_bwd (TinyNeRF.forward and its backward on x[M, in_dim] in memory, src/nerf.py:29-41) on the
+ * split-bf16 chain; in_dim = 6L+3 as for every x3 entry point (other input widths: the fp32-MFMA entry points).  Same
+ * outputs, same stash, same gradients to fp32 rounding. */
+int tnerf_mlp_fwd_x3(const tnerf_mlp_desc* d, const void* packed_x3, const float* x, int64_t n_rows,
+                     float* rgb, float* sigma, float* stash, int64_t stash_row_stride, tnerf_stream_t stream);
+int tnerf_mlp_bwd_x3(const tnerf_mlp_desc* d, const void* packed_x3, int64_t n_rows,
+                     const float* d_rgb, const float* d_sigma, float* stash, int64_t stash_row_stride,
+                     const int32_t* job_table, int64_t n_jobs, float* slabs,
+                     const int32_t* reduce_table, float* grads, tnerf_stream_t stream);
+
 /* tnerf_train_dgrad_fused on the split-bf16 chain: reads the backward record stream of `packed_x3` (heads^T and the
  * transposed hidden layers, which tnerf_mlp_pack_x3 writes behind the forward stream) and fills the same dZ rows. */
 int tnerf_train_dgrad_fused_x3(const tnerf_mlp_desc* d, const void* packed_x3,

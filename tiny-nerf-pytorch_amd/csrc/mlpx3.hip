@@ -348,23 +348,116 @@ __global__ __launch_bounds__(TxCfg<HID>::NW * 64, 1) void k_dgradx3(BwdX3Args a)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-int tnx3_launch_dgrad(const BwdX3Args& a, hipStream_t stream, const char* who) {
+// ------------------------------------------------------------------------------------------------ MLP only
+// TinyNeRF.forward / its backward on x[M, in_dim] given in memory (reference src/nerf.py:29-41; the per-function call style of
+// src/train.py:117-118): the same tiles as the fused kernels with the network input READ instead of computed.  in_dim = 6L+3:
+// the k-slot (step a = 8u + e, lane half h) of the record stream carries column 3 + 6 (a/3) + 3h + a%3 of x for a < 3L (the
+// sin / cos of frequency a/3, coordinate a%3), columns h and 2 (h = 0) for the raw coordinates at a = 3L, 3L+1.
+template <typename Out>
+__device__ __forceinline__ void tx_load_input(const float* __restrict__ xrow, bool valid, int Lf, int h, EncX& E, Out&& out) {
+    tn_static_for<TN16_KE>([&](auto uc) TN_INLINE_LAMBDA {
+        constexpr int u = decltype(uc)::value;
+        float v[8];
+        tn_static_for<8>([&](auto ec) TN_INLINE_LAMBDA {
+            constexpr int e = decltype(ec)::value;
+            constexpr int a = 8 * u + e;
+            int col = -1;
+            if (a < 3 * Lf)           col = 3 + 6 * (a / 3) + 3 * h + a % 3;
+            else if (a == 3 * Lf)     col = h;
+            else if (a == 3 * Lf + 1) col = h ? -1 : 2;
+            const float r = (valid && col >= 0) ? xrow[col] : 0.0f;
+            v[e] = r;
+            out(std::integral_constant<int, a>{}, r);
+        });
+        u32x4 w1, w2, w3;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            unsigned a_, b_, c_;
+            tx_split2(v[2 * q], v[2 * q + 1], a_, b_, c_);
+            w1[q] = a_; w2[q] = b_; w3[q] = c_;
+        }
+        E.p1[u] = __builtin_bit_cast(bf16x8, w1); E.p2[u] = __builtin_bit_cast(bf16x8, w2); E.p3[u] = __builtin_bit_cast(bf16x8, w3);
+    });
+}
+
+template <int HID, bool TRAIN>
+__global__ __launch_bounds__((TxCfg<HID, TRAIN>::NW * 64), 1) void k_mlpx3_fwd(FwdX3Args a) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    constexpr int NW = TxCfg<HID, TRAIN>::NW;
+    const int lane = tn_lane();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int j = lane & 31, h = lane >> 5;
+    PipeX p;
+    tx_prologue<NW>(p, lds, a.packed3, a.n, a.packed3, a.n.n_stage, lane, wave);
+    TxProf pf;
+    const int64_t M = a.f.M, n_tiles = (M + 31) / 32, n_groups = (n_tiles + NW - 1) / NW;
+    const int in_dim = a.n.in_dim, Lf = a.n.Lf;
+    for (int64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {         // every wave of the workgroup runs every pass (stage barriers)
+        const int64_t m = (g * NW + wave) * 32 + j;
+        const bool valid = m < M;
+        const int64_t mc = valid ? m : M - 1;
+        EncX E;
+        float encf[8 * TN16_KE];
+        tx_load_input(a.f.x + mc * in_dim, valid, Lf, h, E, [&](auto stc, float val) TN_INLINE_LAMBDA { encf[decltype(stc)::value] = val; });
+        float res[4];
+        tx_mlp_tile<HID, TRAIN>(p, lds, a, h, lane, E, encf, mc, valid, res, pf);
+        if (valid && h == 0) {
+            a.f.rgb_out[3 * m + 0] = res[0]; a.f.rgb_out[3 * m + 1] = res[1]; a.f.rgb_out[3 * m + 2] = res[2];
+            a.f.sigma_out[m] = res[3];
+            if (TRAIN) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) tn_stash_at(a.f.stash, a.f.L.stash_rows, m)[(a.f.L.out_row0 + i) * 32] = res[i];
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int HID>
+__global__ __launch_bounds__(TxCfg<HID>::NW * 64, 1) void k_mlpx3_bwd(BwdX3Args a) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    constexpr int NW = TxCfg<HID>::NW;
+    const int lane = tn_lane();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    PipeX p;
+    tx_prologue<NW>(p, lds, a.packed3, a.n, a.packed3 + (int64_t)a.n.n_rec * a.n.rec_frags * 1024, a.n.n_bw_stage, lane, wave);
+    const int64_t M = a.b.M, n_tiles = (M + 31) / 32, n_groups = (n_tiles + NW - 1) / NW;
+    for (int64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
+        const int64_t m = (g * NW + wave) * 32 + (lane & 31);
+        const bool valid = m < M;
+        const int64_t mc = valid ? m : M - 1;
+        float dzh[4];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const float c = tn_stash_at(a.b.stash, a.b.L.stash_rows, mc)[(a.b.L.out_row0 + i) * 32];
+            dzh[i] = valid ? a.b.d_rgb[3 * mc + i] * (c * (1.0f - c)) : 0.0f;            // sigmoid backward
+        }
+        const float sg = tn_stash_at(a.b.stash, a.b.L.stash_rows, mc)[(a.b.L.out_row0 + 3) * 32];
+        dzh[3] = (valid && sg > 0.0f) ? a.b.d_sigma[mc] : 0.0f;                            // ReLU backward
+        tx_bwd_tile<HID>(p, lds, a, dzh, mc, valid, lane);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// units: rays (fused) or 32-sample tiles (mlp_only) — one per wave and pass
+int tnx3_launch_dgrad(const BwdX3Args& a, bool mlp_only, hipStream_t stream, const char* who) {
     const int dev = tn_stream_device(stream), n_cu = tn_device_cus(dev);
     const int nw = a.n.hidden == 256 ? TxCfg<256>::NW : TxCfg<128>::NW;
-    const int64_t groups = (a.b.R + nw - 1) / nw;
+    const int64_t units = mlp_only ? (a.b.M + 31) / 32 : a.b.R, groups = (units + nw - 1) / nw;
     const dim3 grid((unsigned)(groups < n_cu ? groups : n_cu)), block(nw * 64);
     const size_t lds_bytes = TX_RING + (size_t)((a.n.n_bias + 3) / 4 * 4) * 4;
-    if (a.n.hidden == 256) {
-        static std::atomic<uint32_t> seen_[TN_MAX_DEVICES];
-        if (int rc = tn_grant_dyn_lds(reinterpret_cast<const void*>(&k_dgradx3<256>), lds_bytes, dev, seen_, who)) return rc;
-        hipLaunchKernelGGL((k_dgradx3<256>), grid, block, lds_bytes, stream, a);
-    } else {
-        static std::atomic<uint32_t> seen_[TN_MAX_DEVICES];
-        if (int rc = tn_grant_dyn_lds(reinterpret_cast<const void*>(&k_dgradx3<128>), lds_bytes, dev, seen_, who)) return rc;
-        hipLaunchKernelGGL((k_dgradx3<128>), grid, block, lds_bytes, stream, a);
+#define TX_CASE(H_, K_, M_)                                                                                                  \
+    if (a.n.hidden == H_ && mlp_only == M_) {                                                                                 \
+        static std::atomic<uint32_t> seen_[TN_MAX_DEVICES];                                                                   \
+        if (int rc_ = tn_grant_dyn_lds(reinterpret_cast<const void*>(&K_<H_>), lds_bytes, dev, seen_, who)) return rc_;       \
+        hipLaunchKernelGGL((K_<H_>), grid, block, lds_bytes, stream, a);                                                      \
+        TN_HIP_CHECK_LAUNCH(who);                                                                                             \
+        return TNERF_OK;                                                                                                      \
     }
-    TN_HIP_CHECK_LAUNCH(who);
-    return TNERF_OK;
+    TX_CASE(256, k_dgradx3, false) TX_CASE(128, k_dgradx3, false) TX_CASE(256, k_mlpx3_bwd, true) TX_CASE(128, k_mlpx3_bwd, true)
+#undef TX_CASE
+    tn_set_error("%s: no x3 kernel for hidden=%d", who, a.n.hidden);
+    return TNERF_EUNSUPPORTED;
 }
 
 // dgrad of a train step on the x3 kernel (train_api.hip calls this instead of the fp32-MFMA dgrad when packed3 is given).
@@ -372,13 +465,13 @@ int tnx3_train_dgrad(const char* who, const BwdArgs& b, const tnerf_mlp_desc* d,
     BwdX3Args a{};
     int rc = tn_build_netx3(d, &a.n); if (rc) return rc;
     a.b = b; a.packed3 = static_cast<const unsigned char*>(packed3);
-    return tnx3_launch_dgrad(a, stream, who);
+    return tnx3_launch_dgrad(a, false, stream, who);
 }
 
-int tnx3_launch_fwd(const FwdX3Args& a, bool train, hipStream_t stream, const char* who) {
+int tnx3_launch_fwd(const FwdX3Args& a, bool train, hipStream_t stream, const char* who, bool mlp_only = false) {
     const int dev = tn_stream_device(stream), n_cu = tn_device_cus(dev);
     const int nw = a.n.hidden == 256 ? 4 : (train ? TxCfg<128, true>::NW : TxCfg<128, false>::NW);
-    const int64_t groups = (a.f.R + nw - 1) / nw;
+    const int64_t units = mlp_only ? (a.f.M + 31) / 32 : a.f.R, groups = (units + nw - 1) / nw;
     const dim3 grid((unsigned)(groups < n_cu ? groups : n_cu)), block(nw * 64);
     const size_t lds_bytes = TX_RING + (size_t)((a.n.n_bias + 3) / 4 * 4) * 4;
 #define TX_CASE(H_, T_)                                                                                                      \
@@ -389,10 +482,45 @@ int tnx3_launch_fwd(const FwdX3Args& a, bool train, hipStream_t stream, const ch
         TN_HIP_CHECK_LAUNCH(who);                                                                                             \
         return TNERF_OK;                                                                                                      \
     }
-    TX_CASE(256, false) TX_CASE(256, true) TX_CASE(128, false) TX_CASE(128, true)
+    if (!mlp_only) { TX_CASE(256, false) TX_CASE(256, true) TX_CASE(128, false) TX_CASE(128, true) }
+#undef TX_CASE
+#define TX_CASE(H_, T_)                                                                                                      \
+    if (a.n.hidden == H_ && train == T_) {                                                                                    \
+        static std::atomic<uint32_t> seen_[TN_MAX_DEVICES];                                                                   \
+        if (int rc_ = tn_grant_dyn_lds(reinterpret_cast<const void*>(&k_mlpx3_fwd<H_, T_>), lds_bytes, dev, seen_, who)) return rc_; \
+        hipLaunchKernelGGL((k_mlpx3_fwd<H_, T_>), grid, block, lds_bytes, stream, a);                                         \
+        TN_HIP_CHECK_LAUNCH(who);                                                                                             \
+        return TNERF_OK;                                                                                                      \
+    }
+    if (mlp_only) { TX_CASE(256, false) TX_CASE(256, true) TX_CASE(128, false) TX_CASE(128, true) }
 #undef TX_CASE
     tn_set_error("%s: no x3 kernel for hidden=%d", who, a.n.hidden);
     return TNERF_EUNSUPPORTED;
+}
+
+// TinyNeRF.forward on the x3 chain (in_dim = 6L+3; tnerf_mlp_fwd otherwise).  Same outputs and stash as tnerf_mlp_fwd.
+extern "C" int tnerf_mlp_fwd_x3(const tnerf_mlp_desc* d, const void* packed3, const float* x, int64_t M, float* rgb, float* sigma,
+                                float* stash, int64_t Mp, tnerf_stream_t stream) {
+    const char* who = "tnerf_mlp_fwd_x3";
+    FwdX3Args a{};
+    int rc = tn_build_netx3(d, &a.n); if (rc) return rc;
+    rc = tn_build_layout(d, &a.f.L); if (rc) return rc;
+    if (M == 0) return TNERF_OK;
+    if (M < 0 || !packed3 || !x || !rgb || !sigma || (stash && Mp < M)) {
+        tn_set_error("%s: M=%lld packed3=%p x=%p rgb=%p sigma=%p Mp=%lld", who, (long long)M, packed3, (const void*)x, (void*)rgb, (void*)sigma, (long long)Mp);
+        return TNERF_EINVAL;
+    }
+    a.packed3 = static_cast<const unsigned char*>(packed3);
+    a.f.x = x; a.f.M = M; a.f.rgb_out = rgb; a.f.sigma_out = sigma; a.f.stash = stash; a.f.Mp = Mp;
+    return tnx3_launch_fwd(a, stash != nullptr, (hipStream_t)stream, who, true);
+}
+
+// dgrad of tnerf_mlp_bwd on the x3 chain (train_api.hip adds the weight-gradient kernel and the slab reduction).
+int tnx3_mlp_dgrad(const char* who, const BwdArgs& b, const tnerf_mlp_desc* d, const void* packed3, hipStream_t stream) {
+    BwdX3Args a{};
+    int rc = tn_build_netx3(d, &a.n); if (rc) return rc;
+    a.b = b; a.packed3 = static_cast<const unsigned char*>(packed3);
+    return tnx3_launch_dgrad(a, true, stream, who);
 }
 
 // ----------------------------------------------------------------------------------- entry points

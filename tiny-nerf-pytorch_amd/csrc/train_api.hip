@@ -36,6 +36,21 @@ extern "C" int tnerf_mlp_bwd(const tnerf_mlp_desc* d, const float* packed, int64
     return tn_launch_reduce(slabs, reduce_table, a.L.n_params, grads, s);
 }
 
+extern "C" int tnerf_mlp_bwd_x3(const tnerf_mlp_desc* d, const void* packed_x3, int64_t M, const float* d_rgb, const float* d_sigma,
+                                float* stash, int64_t Mp, const int32_t* job_table, int64_t n_jobs, float* slabs,
+                                const int32_t* reduce_table, float* grads, tnerf_stream_t stream) {
+    const char* who = "tnerf_mlp_bwd_x3";
+    BwdArgs a{};
+    int rc = tn_build_layout(d, &a.L); if (rc) return rc;
+    if (M < 1 || !d_rgb || !d_sigma) { tn_set_error("%s: M=%lld d_rgb=%p d_sigma=%p", who, (long long)M, (const void*)d_rgb, (const void*)d_sigma); return TNERF_EINVAL; }
+    rc = bwd_common_check(who, reinterpret_cast<const float*>(packed_x3), stash, Mp, M, job_table, n_jobs, slabs, reduce_table, grads); if (rc) return rc;
+    a.packed = nullptr; a.stash = stash; a.Mp = Mp; a.M = M; a.d_rgb = d_rgb; a.d_sigma = d_sigma;
+    hipStream_t s = (hipStream_t)stream;
+    if ((rc = tnx3_mlp_dgrad(who, a, d, packed_x3, s))) return rc;
+    if ((rc = tn_launch_wgrad(stash, a.L.stash_rows, M, job_table, n_jobs, slabs, nullptr, s, !(a.L.flags & TNERF_FLAG_FP32_MFMA)))) return rc;
+    return tn_launch_reduce(slabs, reduce_table, a.L.n_params, grads, s);
+}
+
 // dgrad + wgrad (+ slab reduction when reduce_table != NULL).  g_comp: dL/dcomp_rgb with row stride g_stride.
 static int train_bwd_impl(const char* who, const tnerf_mlp_desc* d, const float* packed, const void* packed3, const RaySource& rs, const TnStepRef& sr,
                           int64_t R, int32_t S, const float* ztab, int32_t randomized, const float* t_rand, uint64_t seed,

@@ -111,6 +111,8 @@ SIGNATURES = {
     "tnerf_render_fused_x3": (C.c_int, [_DESC, _P, _P, _P, _I64, _I32, _P, _I32, _P, _U64, _U64, _I32, _P, _P, _P, _P]),
     "tnerf_render_fused_cam_x3": (C.c_int, [_DESC, _P, C.POINTER(Camera), _I64, _I32, _P, _I32, _P, _U64, _U64, _I32, _P, _P, _P, _P]),
     "tnerf_train_fwd_fused_x3": (C.c_int, [_DESC, _P, _P, _P, _I64, _I32, _P, _I32, _P, _U64, _U64, _I32, _P, _P, _I64, _P]),
+    "tnerf_mlp_fwd_x3": (C.c_int, [_DESC, _P, _P, _I64, _P, _P, _P, _I64, _P]),
+    "tnerf_mlp_bwd_x3": (C.c_int, [_DESC, _P, _I64, _P, _P, _P, _I64, _P, _I64, _P, _P, _P, _P]),
     "tnerf_train_dgrad_fused_x3": (C.c_int, [_DESC, _P, _P, _P, _I64, _I32, _P, _I32, _P, _U64, _U64, _I32, _P, _P, _I64, _P]),
     "tnerf_train_step_dataset": (C.c_int, [C.POINTER(StepArgs), _P]),
     "tnerf_graph_begin": (C.c_int, [_P]),

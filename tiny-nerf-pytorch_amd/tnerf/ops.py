@@ -408,9 +408,14 @@ class _MlpFn(torch.autograd.Function):
         sigma = torch.empty(M, 1, dtype=torch.float32, device=dev)
         plan = st.plan(M) if train else None
         lease = plan.lease() if train else None
-        _l.call("tnerf_mlp_fwd", C.byref(st.desc), st.packed.data_ptr(), x.data_ptr(), M, rgb.data_ptr(), sigma.data_ptr(),
+        # the x3 chain (same fp32 results, products on the bf16 matrix pipe) whenever the input is a 6L+3 encoding
+        x3 = None
+        if st.x3_capable and not (st.desc.flags & _l.FLAG_FP32_MFMA):
+            x3 = st.repack_x3(("pack", st.packed_key) if st.packed_key is not None else None)
+        _l.call("tnerf_mlp_fwd_x3" if x3 is not None else "tnerf_mlp_fwd", C.byref(st.desc),
+                (x3 if x3 is not None else st).packed.data_ptr(), x.data_ptr(), M, rgb.data_ptr(), sigma.data_ptr(),
                 lease.buf.data_ptr() if train else None, plan.Mp if train else 0, _stream(dev))
-        ctx.st, ctx.plan, ctx.M, ctx.lease = st, plan, M, lease
+        ctx.st, ctx.plan, ctx.M, ctx.lease, ctx.x3 = st, plan, M, lease, x3
         ctx.shapes = [p.shape for p in params]
         return rgb, sigma
 
@@ -425,7 +430,9 @@ class _MlpFn(torch.autograd.Function):
         dev = st.device
         g_rgb = torch.zeros(M, 3, dtype=torch.float32, device=dev) if g_rgb is None else _f32c(g_rgb)
         g_sigma = torch.zeros(M, 1, dtype=torch.float32, device=dev) if g_sigma is None else _f32c(g_sigma)
-        _l.call("tnerf_mlp_bwd", C.byref(st.desc), st.packed.data_ptr(), M, g_rgb.data_ptr(), g_sigma.data_ptr(),
+        x3 = ctx.x3
+        _l.call("tnerf_mlp_bwd_x3" if x3 is not None else "tnerf_mlp_bwd", C.byref(st.desc),
+                (x3 if x3 is not None else st).packed.data_ptr(), M, g_rgb.data_ptr(), g_sigma.data_ptr(),
                 lease.buf.data_ptr(), plan.Mp, plan.jobs.data_ptr(), plan.n_jobs, plan.slabs.data_ptr(), plan.reduce.data_ptr(),
                 st.grad.data_ptr(), _stream(dev))
         grads = [st.grad[o:o + int(np.prod(s))].view(s).clone() for s, o in zip(ctx.shapes, st.offsets)]
