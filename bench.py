@@ -310,8 +310,10 @@ def run(args):
            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling,
            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "dtype_note": ("fp32 values in, out and in every accumulator; the matrix products are formed EXACTLY from three bf16 pieces per "
-                          "fp32 operand (8+8+8 mantissa bits, 6 partial products on the bf16 MFMA pipe): measured at least as close to fp64 as an "
-                          "fp32 FMA chain (DESIGN.md 13/14); TNERF_FP32_PIPE=mfma32 runs the plain fp32-MFMA kernels instead")
+                          "fp32 operand (8+8+8 mantissa bits, 6 partial products on the bf16 MFMA pipe); measured against fp64: whole-gradient error equal "
+                          "to the reference's CPU fp32 path, activations within ~2x of the fp32-MFMA kernels' error after 8 layers, single "
+                          "hidden-layer gradient tensors up to 10x (the pipe drops addends below 1/8 ulp of its accumulator: DESIGN.md 14); "
+                          "TNERF_FP32_PIPE=mfma32 runs the plain fp32-MFMA kernels instead")
                          if FP32_PATH_PEAK == PEAK_X3_TFLOPS else "fp32 MFMA (v_mfma_f32_32x32x2_f32)",
            "config": {"workload": "train step: 100x100 synthetic Lego stand-in, 106 views, L=6 posenc, 8x256 ReLU MLP (skip 4), "
                                   f"64 samples/ray, {'4096 rays per GPU' if args.scaling == 'weak' else '4096 rays in total'} per step, "

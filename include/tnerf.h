@@ -54,8 +54,10 @@ typedef struct tnerf_mlp_desc {
  * arguments), the forward and dgrad chain kernels.
  * Default (0): on the bf16 matrix pipe by EXACT three-way splitting — an fp32 value is the sum of three bf16 numbers
  * (8+8+8 mantissa bits), a product of two bf16 numbers is exact in fp32, six v_mfma_f32_32x32x16_bf16 with fp32
- * accumulation carry a*b up to terms below 2^-24 |ab| — fp32-grade results (measured against fp64: at least as accurate
- * as an fp32 fma chain) at 6/16 of the fp32-MFMA time (CDNA4's bf16 matrix rate is 16x its fp32 rate).
+ * accumulation carry a*b up to terms below 2^-24 |ab| — fp32-grade results (measured against fp64: the weight-gradient
+ * GEMMs as accurate as an fp32 fma chain; the chain kernels within ~2x of the fp32-MFMA kernels' activation error after 8
+ * layers, because the matrix pipe drops addends below ~1/8 ulp of its accumulator: DESIGN.md 14) at 6/16 of the fp32-MFMA
+ * time (CDNA4's bf16 matrix rate is 16x its fp32 rate).
  * TNERF_FLAG_FP32_MFMA selects v_mfma_f32_32x32x2_f32 (plain fp32 fma chains) for all of them instead; the entry points
  * that take only the fp32 pack (tnerf_render_fused, tnerf_train_fwd_fused, tnerf_mlp_fwd, ...) always run those. */
 #define TNERF_FLAG_FP32_MFMA 1
