@@ -50,7 +50,7 @@ __device__ __forceinline__ void tx_mlp_tile(PipeX& p, const unsigned char* lds, 
     }
     constexpr int NH = NT / 2, KH = HID / 16, NP = NH * 8, NW = TxCfg<HID, TRAIN>::NW;
     ActX<HID> X;
-    f32x16 accA[NH], accB[NH];
+    f32x16 accA[TX_ACCN(HID)], accB[TX_ACCN(HID)];
     TxEpi es;
     // per-lane stash pointers of the layer whose epilogue is running (training)
     float* __restrict__ srow = nullptr; uint32_t* __restrict__ mword = nullptr;
@@ -78,12 +78,12 @@ __device__ __forceinline__ void tx_mlp_tile(PipeX& p, const unsigned char* lds, 
     // heads (tile slot 0 of accA): the last layer's half B epilogue must be through before k-step KH/2
     tx_pass<HID, 3, true, NW>(p, lds, X, E, accA, tx_window<0, KH / 2, NP>(epiB));
     TX_PROF_ADD(pf, walk);
-    const f32x16 (&acc)[NH] = accA;
+    const f32x16 (&acc)[TX_ACCN(HID)] = accA;
     // heads: rows 0..2 = rgb.0 (sigmoid), row 3 = sigma.0 (ReLU)                                   nerf.py:39-40
     const f32x4 hb = *reinterpret_cast<const f32x4*>(lds + TX_RING + depth * HID * 4);
 #pragma unroll
-    for (int i = 0; i < 3; ++i) res[i] = 1.0f / (1.0f + expf(-(acc[0][i] + hb[i])));
-    res[3] = fmaxf(acc[0][3] + hb[3], 0.0f);
+    for (int i = 0; i < 3; ++i) res[i] = 1.0f / (1.0f + expf(-((TX_SPLIT_ACC ? acc[0][i] + acc[TX_SPLIT_ACC * NH][i] : acc[0][i]) + hb[i])));
+    res[3] = fmaxf((TX_SPLIT_ACC ? acc[0][3] + acc[TX_SPLIT_ACC * NH][3] : acc[0][3]) + hb[3], 0.0f);
 }
 
 template <int HID, bool TRAIN>
@@ -230,7 +230,7 @@ __device__ __forceinline__ void tx_bwd_tile(PipeX& p, const unsigned char* lds, 
         Z.p1[0] = __builtin_bit_cast(bf16x8, w1); Z.p2[0] = __builtin_bit_cast(bf16x8, w2); Z.p3[0] = __builtin_bit_cast(bf16x8, w3);
     }
     constexpr int NH = NT / 2, KH = HID / 16, NP = NH * 8, NW = TxCfg<HID>::NW;
-    f32x16 accA[NH], accB[NH];
+    f32x16 accA[TX_ACCN(HID)], accB[TX_ACCN(HID)];
     uint32_t mw[NT / 2];
     TxEpi es;
     TxMask<NT / 2> mk;                                             // asm load + counted wait (above)

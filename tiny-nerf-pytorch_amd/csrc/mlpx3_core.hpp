@@ -27,6 +27,14 @@
 #define TX_LEAD 3                              // stages in flight behind the published one (LEAD + 2 <= NS)
 // Waves per workgroup: 256-wide nets need the 512-register budget of one wave per SIMD; a 128-wide wave fits 256 registers, so
 // two of them share a SIMD and fill each other's gaps (encoder, compositing, barriers).
+// Diagnostic builds only (-DTX_SPLIT_ACC=1, tools/x3_accuracy_probe.py): the five correction products of a k-step accumulate in a
+// second accumulator set (acc[NH + tile]) that never holds the large a1.b1 sums, and the two are added in the epilogue — what the
+// chain would deliver if the matrix pipe did not drop addends below 1/8 ulp of its accumulator (accuracy).  Costs
+// 128 registers the 256-wide kernels do not have (it spills): a measurement, not a product option.
+#ifndef TX_SPLIT_ACC
+#define TX_SPLIT_ACC 0
+#endif
+#define TX_ACCN(HID) ((HID) / 64 * (1 + TX_SPLIT_ACC))
 #ifndef TX_NW128
 #define TX_NW128 8
 #endif
@@ -148,7 +156,7 @@ __device__ __forceinline__ FragX tx_frag_load(const unsigned char* base, int tl)
 // The next group's A fragments are read from LDS behind the first MFMA of a group (not across a stage boundary).
 template <int HID, int KIND, bool ZERO, int NW, typename Hook>
 __device__ __forceinline__ void tx_pass(PipeX& p, const unsigned char* lds, const ActX<HID>& X, const EncX& E,
-                                        f32x16 (&acc)[HID / 64], Hook&& hook) {
+                                        f32x16 (&acc)[TX_ACCN(HID)], Hook&& hook) {
     constexpr int NH = HID / 64, KH = HID / 16, RPS = TX_STAGE / (NH * 3), DPW = TX_STAGE / NW;
     constexpr int NK = KIND == 0 ? TN16_KE : (KIND == 3 ? KH / NH : KH);
     constexpr int NTU = NH;
@@ -176,15 +184,16 @@ __device__ __forceinline__ void tx_pass(PipeX& p, const unsigned char* lds, cons
             constexpr int s0 = (k * NTU + tl) * 6;
             FragX nxt;
             if constexpr (early) tx_boundary<DPW, true>(p);
-            if constexpr (ZERO && ks == 0) { const f32x16 z = {}; acc[ta] = TN16_MFMA(cur.a3, b1, z); }
-            else                          acc[ta] = TN16_MFMA(cur.a3, b1, acc[ta]);
+            constexpr int tc_ = TX_SPLIT_ACC ? ta + NH : ta;         // where the correction products go
+            if constexpr (ZERO && ks == 0) { const f32x16 z = {}; acc[tc_] = TN16_MFMA(cur.a3, b1, z); }
+            else                          acc[tc_] = TN16_MFMA(cur.a3, b1, acc[tc_]);
             if constexpr (more_tile)     nxt = tx_frag_load(base, tl + 1);
             else if constexpr (more_rec) nxt = tx_frag_load(base + NH * 3 * 1024, 0);
             else if constexpr (early)    nxt = tx_frag_load(lds + p.cur + p.lane16, 0);
             hook(std::integral_constant<int, s0>{});     TX_PIN();
-            acc[ta] = TN16_MFMA(cur.a2, b2, acc[ta]); hook(std::integral_constant<int, s0 + 1>{}); TX_PIN();
-            acc[ta] = TN16_MFMA(cur.a1, b3, acc[ta]); hook(std::integral_constant<int, s0 + 2>{}); TX_PIN();
-            acc[ta] = TN16_MFMA(cur.a2, b1, acc[ta]); hook(std::integral_constant<int, s0 + 3>{});
+            acc[tc_] = TN16_MFMA(cur.a2, b2, acc[tc_]); hook(std::integral_constant<int, s0 + 1>{}); TX_PIN();
+            acc[tc_] = TN16_MFMA(cur.a1, b3, acc[tc_]); hook(std::integral_constant<int, s0 + 2>{}); TX_PIN();
+            acc[tc_] = TN16_MFMA(cur.a2, b1, acc[tc_]); hook(std::integral_constant<int, s0 + 3>{});
             {   // this group's share of the pending stage's DMA pieces
                 constexpr int GPS = RPS * NTU, PPS = (DPW + GPS - 2) / (GPS - 1), g = (k % RPS) * NTU + tl;
                 tn_static_for<PPS>([&](auto uc) TN_INLINE_LAMBDA {
@@ -193,8 +202,10 @@ __device__ __forceinline__ void tx_pass(PipeX& p, const unsigned char* lds, cons
                 });
             }
             TX_PIN();
-            acc[ta] = TN16_MFMA(cur.a1, b2, acc[ta]); hook(std::integral_constant<int, s0 + 4>{}); TX_PIN();
-            acc[ta] = TN16_MFMA(cur.a1, b1, acc[ta]); hook(std::integral_constant<int, s0 + 5>{}); TX_PIN();
+            acc[tc_] = TN16_MFMA(cur.a1, b2, acc[tc_]); hook(std::integral_constant<int, s0 + 4>{}); TX_PIN();
+            if constexpr (TX_SPLIT_ACC && ZERO && ks == 0) { const f32x16 z = {}; acc[ta] = TN16_MFMA(cur.a1, b1, z); }
+            else                                            acc[ta] = TN16_MFMA(cur.a1, b1, acc[ta]);
+            hook(std::integral_constant<int, s0 + 5>{}); TX_PIN();
             if constexpr (more_tile || more_rec || early) cur = nxt;
         });
     });
@@ -203,7 +214,7 @@ __device__ __forceinline__ void tx_pass(PipeX& p, const unsigned char* lds, cons
 // heads^T of the backward stream: ONE k-step (B operand = Z.p*[0]) into both halves' accumulators; the stage holds record A,
 // record B and padding.
 template <int HID, int NW>
-__device__ __forceinline__ void tx_pass_headsT(PipeX& p, const unsigned char* lds, const EncX& Z, f32x16 (&accA)[HID / 64], f32x16 (&accB)[HID / 64]) {
+__device__ __forceinline__ void tx_pass_headsT(PipeX& p, const unsigned char* lds, const EncX& Z, f32x16 (&accA)[TX_ACCN(HID)], f32x16 (&accB)[TX_ACCN(HID)]) {
     constexpr int NH = HID / 64;
     tx_boundary<TX_STAGE / NW, false>(p);
     const unsigned char* base = lds + p.cur + p.lane16;
@@ -215,6 +226,7 @@ __device__ __forceinline__ void tx_pass_headsT(PipeX& p, const unsigned char* ld
         a = TN16_MFMA(f.a2, Z.p2[0], a); a = TN16_MFMA(f.a1, Z.p3[0], a);
         a = TN16_MFMA(f.a2, Z.p1[0], a); a = TN16_MFMA(f.a1, Z.p2[0], a); a = TN16_MFMA(f.a1, Z.p1[0], a);
         if constexpr (t < NH) accA[t] = a; else accB[t - NH] = a;
+        if constexpr (TX_SPLIT_ACC) { if constexpr (t < NH) accA[t + NH] = z; else accB[t] = z; }
     });
 }
 
@@ -255,7 +267,7 @@ __device__ __forceinline__ void tx_epi_split(ActX<HID>& X, TxEpi& e) {
 // compiler's lgkmcnt wait lands a whole MFMA later.
 // srow: per-lane stash pointer of the layer's activation rows (row 4h, this sample); mword: per-lane pointer of its sign words.
 template <int HID, int HALF, int I, int J, bool TRAIN, int PPG>
-__device__ __forceinline__ void tx_epi_fwd(const f32x16 (&acc)[HID / 64], ActX<HID>& X, TxEpi& e, const unsigned char* lds, uint32_t vb,
+__device__ __forceinline__ void tx_epi_fwd(const f32x16 (&acc)[TX_ACCN(HID)], ActX<HID>& X, TxEpi& e, const unsigned char* lds, uint32_t vb,
                                            float* __restrict__ srow, uint32_t* __restrict__ mword) {
     using P = TxPair<HID, HALF, I>;
     constexpr int u = I % 4;
@@ -263,6 +275,7 @@ __device__ __forceinline__ void tx_epi_fwd(const f32x16 (&acc)[HID / 64], ActX<H
     if constexpr (J == 0) {
         if constexpr (I < PPG) e.b[u] = *reinterpret_cast<const f32x2*>(lds + vb + P::row0 * 4);      // the window's first group
         e.v0[u] = acc[P::tl][P::r0]; e.v1[u] = acc[P::tl][P::r1];
+        if constexpr (TX_SPLIT_ACC) { e.v0[u] += acc[P::tl + P::NH][P::r0]; e.v1[u] += acc[P::tl + P::NH][P::r1]; }
     } else if constexpr (J == 1) {
         e.v0[u] = fmaxf(e.v0[u] + e.b[u][0], 0.0f); e.v1[u] = fmaxf(e.v1[u] + e.b[u][1], 0.0f);
     } else if constexpr (J == 5 && I + PPG < P::NH * 8) {          // (also runs the split's step 5 below)
@@ -282,11 +295,12 @@ __device__ __forceinline__ void tx_epi_fwd(const f32x16 (&acc)[HID / 64], ActX<H
 // Backward: ReLU backward with the forward's sign bits (mw: the words of the layer this activation gradient belongs to),
 // dZ to the stash, split.
 template <int HID, int HALF, int I, int J>
-__device__ __forceinline__ void tx_epi_bwd(const f32x16 (&acc)[HID / 64], ActX<HID>& X, TxEpi& e, const uint32_t (&mw)[HID / 64], float* __restrict__ zrow) {
+__device__ __forceinline__ void tx_epi_bwd(const f32x16 (&acc)[TX_ACCN(HID)], ActX<HID>& X, TxEpi& e, const uint32_t (&mw)[HID / 64], float* __restrict__ zrow) {
     using P = TxPair<HID, HALF, I>;
     constexpr int u = I % 4;
     if constexpr (J == 0) {
         e.v0[u] = acc[P::tl][P::r0]; e.v1[u] = acc[P::tl][P::r1];
+        if constexpr (TX_SPLIT_ACC) { e.v0[u] += acc[P::tl + P::NH][P::r0]; e.v1[u] += acc[P::tl + P::NH][P::r1]; }
     } else if constexpr (J == 1) {
         e.v0[u] = __int_as_float(__float_as_int(e.v0[u]) & __builtin_amdgcn_sbfe((int)mw[P::t / 2], (P::t & 1) * 16 + P::r0, 1));
         e.v1[u] = __int_as_float(__float_as_int(e.v1[u]) & __builtin_amdgcn_sbfe((int)mw[P::t / 2], (P::t & 1) * 16 + P::r1, 1));
