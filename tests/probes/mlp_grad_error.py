@@ -2,7 +2,7 @@
 """Diagnostic: error of the MLP parameter gradients against an fp64 evaluation for every combination of forward and dgrad
 kernel (x3 = split-bf16 chain, m32 = fp32 MFMA); the weight-gradient kernel is the same in all of them."""
 import ctypes as C, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tiny-nerf-pytorch_amd")); sys.path.insert(0, os.path.join(ROOT, "tiny-nerf-pytorch_amd", "src")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 from conftest import load_golden, golden_params

@@ -13,6 +13,13 @@
 #include "mlp_core.hpp"
 #include "mlp_args.hpp"
 
+// The WX_* knobs below strip parts of the split-bf16 kernel for ablation timings (tools/wgrad_x3_probe.py) and produce WRONG
+// numerics.  They only compile in a diagnostic build (tools/build_variant.sh passes -DTN_DIAG): a stray -DWX_... on the product
+// build is a hard error instead of a library that silently ships garbage.
+#if (defined(WX_NO_SPLIT) || defined(WX_ONE_MFMA) || defined(WX_NO_CONVERT) || defined(WX_NO_PIN)) && !defined(TN_DIAG)
+#error "WX_NO_SPLIT / WX_ONE_MFMA / WX_NO_CONVERT / WX_NO_PIN are diagnostic knobs with wrong numerics: build with -DTN_DIAG (tools/build_variant.sh)"
+#endif
+
 #define WG_LDS_ROWS 256                       // per operand
 #define WG_LDS_FLOATS (2 * 2 * WG_LDS_ROWS * 32)
 
