@@ -324,6 +324,8 @@ typedef struct tnerf_step_args {
     const void* packed_x3;
     const int32_t* scatter_x3;
     int32_t scatter_x3_width;
+    const int32_t* pack_x3;       /* the x3 pack table itself (tnerf_x3_pack_table, on the device): after the update the layers' weight
+                                     maxima and scales are refreshed through it (required with scatter_x3)                          */
 } tnerf_step_args;
 int tnerf_train_step_dataset(const tnerf_step_args* args, tnerf_stream_t stream);
 

@@ -54,6 +54,15 @@ inline int tn_grant_dyn_lds(const void* kernel, size_t bytes, int dev, std::atom
 
 __device__ __forceinline__ int tn_lane() { return (int)(threadIdx.x & 63); }
 
+// "x3" weight stream (tnerf_internal.h): fp16 bits of piece 0 / 1 of x 2^s (wsc = 2^s), both rounded to nearest.  The clamp only
+// matters for a weight that grew sixteen-fold since the scale was chosen: it stays finite.
+__device__ __forceinline__ unsigned short tx_piece_bits(float x, float wsc, int piece) {
+    const float s = fminf(fmaxf(x * wsc, -65000.0f), 65000.0f);
+    const _Float16 p1 = (_Float16)s;
+    const _Float16 p = piece == 0 ? p1 : (_Float16)(s - (float)p1);
+    return __builtin_bit_cast(unsigned short, p);
+}
+
 // ----------------------------------------------------------------------------- Philox4x32-10
 // Counter-based generator for the "speed mode" jitter (t_rand == NULL).  One 128-bit block per
 // (sample index / 4); lane takes word (index & 3).  u in [0,1) with 24 random bits, like

@@ -683,10 +683,13 @@ extern "C" int tn_build_netx3(const tnerf_mlp_desc* d, NetX3* n) {
     memset(n, 0, sizeof(*n));
     const int H = d->hidden <= 128 ? 128 : 256;                            // the kernel width (zero-padded weights, see check_desc)
     n->in_dim = d->in_dim; n->hidden = H; n->depth = d->depth; n->skip_at = d->skip_at; n->Lf = (d->in_dim - 3) / 6;
-    n->NT = H / 32; n->KH = H / 16; n->rec_frags = n->NT / 2 * 3;           // a record covers HALF of the output tiles
+    n->NT = H / 32; n->KH = H / 16; n->rec_frags = n->NT / 2 * TX_NP;       // a record covers HALF of the output tiles
     int rec = 2 * TN16_KE;
-    for (int l = 1; l < d->depth; ++l) rec += 2 * (n->KH + ((d->skip_at > 0 && l == d->skip_at) ? TN16_KE : 0));
+    n->fw_rec0[0] = 0;
+    for (int l = 1; l < d->depth; ++l) { n->fw_rec0[l] = rec; rec += 2 * (n->KH + ((d->skip_at > 0 && l == d->skip_at) ? TN16_KE : 0)); }
+    n->fw_rec0[d->depth] = rec;
     rec += n->KH / (n->NT / 2);                                             // heads: NT/2 k-steps of the one head tile per record
+    n->fw_rec0[d->depth + 1] = rec;
     if ((rec * n->rec_frags) % TX_STAGE != 0) { tn_set_error("x3 chain: the record stream is not a whole number of stages"); return TNERF_EUNSUPPORTED; }
     n->n_rec = rec; n->n_stage = rec * n->rec_frags / TX_STAGE;
     const int rps = TX_STAGE / n->rec_frags;                               // records per stage
@@ -695,7 +698,8 @@ extern "C" int tn_build_netx3(const tnerf_mlp_desc* d, NetX3* n) {
     n->n_bw_stage = n->n_bw_rec * n->rec_frags / TX_STAGE;
     n->bias_off = (rec + n->n_bw_rec) * n->rec_frags * 1024;
     n->n_bias = d->depth * H + 4;
-    n->packed_bytes = (int64_t)n->bias_off + (int64_t)n->n_bias * 4;
+    n->meta_off = n->bias_off + n->n_bias * 4;                              // the scale records follow the biases (one LDS copy serves both)
+    n->packed_bytes = (int64_t)n->meta_off + (int64_t)(d->depth + 1) * TX_META * 4;
     n->pack_entries = (int64_t)(rec + n->n_bw_rec) * n->rec_frags * 512 + n->n_bias;
     return TNERF_OK;
 }
@@ -716,10 +720,10 @@ extern "C" int tnerf_x3_pack_table(const tnerf_mlp_desc* d, int32_t* T) {
     for (int64_t i = 0; i < n.pack_entries; ++i) T[i] = -1;
     const int H = L.hidden, NH = n.NT / 2, KH = n.KH, Lf = n.Lf;
     int64_t rec = 0;                                                        // running record index
-    // all three piece fragments of (record, tile slot tl) refer to the same parameters: the pack kernel derives the piece from
-    // the fragment's position (fragment index mod 3).  Tile slot tl of a half-h record is output tile h*NH + tl.
+    // both piece fragments of (record, tile slot tl) refer to the same parameters: the pack kernel derives the piece from
+    // the fragment's position (fragment index mod TX_NP).  Tile slot tl of a half-h record is output tile h*NH + tl.
     auto put = [&](int tl, int lane, int e, int64_t src) {
-        for (int piece = 0; piece < 3; ++piece) T[(((rec * NH + tl) * 3 + piece) * 64 + lane) * 8 + e] = (int32_t)src;
+        for (int piece = 0; piece < TX_NP; ++piece) T[(((rec * NH + tl) * TX_NP + piece) * 64 + lane) * 8 + e] = (int32_t)src;
     };
     auto head_w = [&](int row, int k) -> int64_t { return row < 3 ? L.p_wc + (int64_t)row * H + k : (row == 3 ? L.p_ws + k : -1); };
     for (int l = 0; l < L.depth; ++l) {

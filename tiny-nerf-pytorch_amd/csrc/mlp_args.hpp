@@ -67,7 +67,10 @@ struct FinishArgs {
     // re-pack: parameter i goes to packed position scatter[i * width + k] (< 0: none); positions < bf16_elems are bf16
     // elements of the fragment stream, the rest fp32 (biases) counted from bias_base
     const int32_t* scatter; int32_t width; void* packed; int64_t bf16_elems; int64_t bias_off_bytes;
-    // second re-pack target: the x3 record stream (element i carries piece (i >> 9) mod 3 of its parameter; biases behind x3_elems)
-    const int32_t* scatter3; int32_t width3; void* packed3; int64_t x3_elems; int64_t x3_bias_off_bytes;
+    // second re-pack target: the x3 record stream (element i carries piece (i >> 9) mod TX_NP of its parameter times the layer's
+    // scale, record [3] of the TX_META floats at n3.meta_off; biases behind x3_elems).  The caller launches tnx3_launch_stats
+    // (post = 1) behind the finishing kernel.
+    const int32_t* scatter3; int32_t width3; void* packed3; int64_t x3_elems; NetX3 n3;
 };
+int tnx3_launch_stats(const NetX3& n, const float* params, const int32_t* table, void* packed3, int post, hipStream_t stream);
 int tn_launch_finish(const FinishArgs& f, hipStream_t stream);

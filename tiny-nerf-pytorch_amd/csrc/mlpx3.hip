@@ -1,9 +1,8 @@
 // "x3" chain kernels: the fused ray -> sample -> encode -> MLP -> composite path (reference src/train.py:46-56, :114-121)
-// with the MLP's fp32 products formed exactly on the bf16 matrix pipe (mlpx3_core.hpp).  Same inputs, outputs, sample bins,
+// with the MLP's fp32 products formed from three partial products on the fp16 matrix pipe (mlpx3_core.hpp).  Same inputs, outputs, sample bins,
 // encoder arithmetic (fp32-accurate sin/cos), compositing and — when training — the same block-major fp32 stash (activations,
 // ReLU sign bits, head outputs, loss gradient) as the fp32-MFMA kernels of mlp_fwd.hip, so the dgrad / weight-gradient kernels
-// and every caller are unchanged.  One persistent workgroup per CU — 4 waves (one per SIMD, 512-register budget) for 256-wide
-// networks and the 128-wide training forward, 8 waves (two per SIMD) for the 128-wide inference and dgrad kernels (TxCfg);
+// and every caller are unchanged.  One persistent workgroup per CU — 4 waves (one per SIMD, 512-register budget: TxCfg);
 // a wave owns one ray at a time and marches it 32 samples per pass over the record stream.  A layer is two half-passes whose
 // epilogues ride in each other's MFMA shadows (mlpx3_core.hpp).
 #include "mlpx3_core.hpp"
@@ -27,13 +26,17 @@ struct FwdX3Args {
     const unsigned char* packed3;   // record stream + biases (tnerf_mlp_pack_x3)
 };
 
+// Per-sample facts of the network input: encmax >= every |input value| and >= 1, l1 >= the L1 norm of the input, te = the
+// exponent its pieces are scaled by.
+struct TxIn { float encmax, l1; int te; };
+
 // The network for one 32-sample tile.  m: this lane's sample index in the stash (valid if `valid`).  res[4]: r,g,b after
-// sigmoid, sigma after ReLU (lane-half 0).
+// sigmoid, sigma after ReLU (lane-half 0).  E: this lane's LDS slots of the input pieces, scaled by 2^in.te (rescaled in place for
+// the skip layer).
 template <int HID, bool TRAIN>
-__device__ __forceinline__ void tx_mlp_tile(PipeX& p, const unsigned char* lds, const FwdX3Args& a, int h, int lane, const EncX& E,
+__device__ __forceinline__ void tx_mlp_tile(PipeX& p, const unsigned char* lds, const FwdX3Args& a, int h, int lane, unsigned char* E, const TxIn& in,
                                             const float (&encf)[8 * TN16_KE], int64_t m, bool valid, float (&res)[4], TxProf& pf) {
     constexpr int NT = HID / 32;
-    constexpr int ST = 0;                                          // stores allowed outstanding at a stage boundary
     const MlpLayout& L = a.f.L;
     const int depth = a.n.depth, skip_at = a.n.skip_at;
     const uint32_t vb0 = TX_RING + 16u * h;                        // + layer * HID * 4
@@ -48,19 +51,31 @@ __device__ __forceinline__ void tx_mlp_tile(PipeX& p, const unsigned char* lds, 
             if (st < L.NE) TN_STASH_STORE(&pl[(L.enc_row0 + 2 * st - 3 * h) * 32], encf[st]);
         });
     }
-    constexpr int NH = NT / 2, KH = HID / 16, NP = NH * 8, NW = TxCfg<HID, TRAIN>::NW;
+    constexpr int NH = NT / 2, KH = HID / 16, NP = NH * 8, NW = TxCfg<HID, TRAIN>::NW, G2 = KH / 2 * NH;
     ActX<HID> X;
     f32x16 accA[TX_ACCN(HID)], accB[TX_ACCN(HID)];
     TxEpi es;
+    TxScale sc{0.0f, 0.0f, 0.0f};
+    int t_prev = in.te;                                            // exponent of the scale of the pieces the running passes consume
     // per-lane stash pointers of the layer whose epilogue is running (training)
     float* __restrict__ srow = nullptr; uint32_t* __restrict__ mword = nullptr;
     uint32_t vbe = vb0;                                            // LDS offset of that layer's biases
+    // Layer l's epilogues are about to start: its input's L1 norm is complete (the previous layer's half B epilogue ended in the
+    // middle of pass A), so the bound on its outputs — and with it the scale of its pieces — is known.
     auto point_at = [&](int l) TN_INLINE_LAMBDA {
         vbe = vb0 + l * HID * 4;
         if constexpr (TRAIN) { srow = pl + L.h_row0[l] * 32; mword = mrow + (int64_t)l * (Mp + 32) * NT; }
+        const f32x4 mt = tx_meta(lds, a.n, l);                     // {2^-s, max|W|, max|b|}
+        float l1_in = l == 0 ? in.l1 : sc.l1 + tx_partner(sc.l1);
+        if (l > 0 && l == skip_at) l1_in += in.l1;
+        float bound = __builtin_fmaf(mt[1], l1_in, mt[2]);
+        if (l + 1 == skip_at) bound = fmaxf(bound, in.encmax);     // the skip layer's input pieces share this layer's output scale
+        const int t_out = tx_scale_exp(bound);
+        sc.dsc = mt[0] * tx_exp2i(-t_prev); sc.osc = tx_exp2i(t_out); sc.l1 = 0.0f;
+        t_prev = t_out;
     };
-    auto epiA = [&](auto ic, auto jc, auto pc) TN_INLINE_LAMBDA { tx_epi_fwd<HID, 0, decltype(ic)::value, decltype(jc)::value, TRAIN, decltype(pc)::value>(accA, X, es, lds, vbe, srow, mword); };
-    auto epiB = [&](auto ic, auto jc, auto pc) TN_INLINE_LAMBDA { tx_epi_fwd<HID, 1, decltype(ic)::value, decltype(jc)::value, TRAIN, decltype(pc)::value>(accB, X, es, lds, vbe, srow, mword); };
+    auto epiA = [&](auto ic, auto jc, auto pc) TN_INLINE_LAMBDA { tx_epi_fwd<HID, 0, decltype(ic)::value, decltype(jc)::value, TRAIN, decltype(pc)::value>(accA, X, es, sc, lds, vbe, srow, mword); };
+    auto epiB = [&](auto ic, auto jc, auto pc) TN_INLINE_LAMBDA { tx_epi_fwd<HID, 1, decltype(ic)::value, decltype(jc)::value, TRAIN, decltype(pc)::value>(accB, X, es, sc, lds, vbe, srow, mword); };
     auto none = [](auto) TN_INLINE_LAMBDA {};
     TX_PROF_BEGIN(pf);
     // layer 0: half A bare, half A's epilogue behind half B
@@ -69,21 +84,22 @@ __device__ __forceinline__ void tx_mlp_tile(PipeX& p, const unsigned char* lds, 
     tx_pass<HID, 0, true, NW>(p, lds, X, E, accB, tx_window<0, TN16_KE * NH, NP>(epiA));
     // layer l: half B's epilogue of layer l-1 behind the first half of pass A, half A's of layer l behind the second half of pass B
     for (int l = 1; l < depth; ++l) {
-        tx_pass<HID, 1, true, NW>(p, lds, X, E, accA, tx_window<0, KH / 2 * NH, NP>(epiB));
+        if (l == skip_at) tx_rescale_input(E, t_prev - in.te);     // the skip layer consumes the input at its own input's scale
+        tx_pass<HID, 1, true, NW>(p, lds, X, E, accA, tx_window<0, G2, NP>(epiB));
         if (l == skip_at) tx_pass<HID, 0, false, NW>(p, lds, X, E, accA, none);                    // + W_l[:, hidden:] . encoding
         point_at(l);
-        tx_pass<HID, 1, true, NW>(p, lds, X, E, accB, tx_window<KH / 2 * NH * 6, KH / 2 * NH, NP>(epiA));
+        tx_pass<HID, 1, true, NW>(p, lds, X, E, accB, tx_window<G2 * TX_SPG, G2, NP>(epiA));
         if (l == skip_at) tx_pass<HID, 0, false, NW>(p, lds, X, E, accB, none);
     }
     // heads (tile slot 0 of accA): the last layer's half B epilogue must be through before k-step KH/2
     tx_pass<HID, 3, true, NW>(p, lds, X, E, accA, tx_window<0, KH / 2, NP>(epiB));
     TX_PROF_ADD(pf, walk);
-    const f32x16 (&acc)[TX_ACCN(HID)] = accA;
     // heads: rows 0..2 = rgb.0 (sigmoid), row 3 = sigma.0 (ReLU)                                   nerf.py:39-40
     const f32x4 hb = *reinterpret_cast<const f32x4*>(lds + TX_RING + depth * HID * 4);
+    const float dh = tx_meta(lds, a.n, depth)[0] * tx_exp2i(-t_prev);
 #pragma unroll
-    for (int i = 0; i < 3; ++i) res[i] = 1.0f / (1.0f + expf(-((TX_SPLIT_ACC ? acc[0][i] + acc[TX_SPLIT_ACC * NH][i] : acc[0][i]) + hb[i])));
-    res[3] = fmaxf((TX_SPLIT_ACC ? acc[0][3] + acc[TX_SPLIT_ACC * NH][3] : acc[0][3]) + hb[3], 0.0f);
+    for (int i = 0; i < 3; ++i) res[i] = 1.0f / (1.0f + expf(-(__builtin_fmaf(accA[0][i] + accA[NH][i], dh, hb[i]))));
+    res[3] = fmaxf(__builtin_fmaf(accA[0][3] + accA[NH][3], dh, hb[3]), 0.0f);
 }
 
 template <int HID, bool TRAIN>
@@ -98,6 +114,7 @@ __global__ __launch_bounds__((TxCfg<HID, TRAIN>::NW * 64), 1) void k_renderx3(Fw
     const int S = sa.S, Lf = a.n.Lf;
     PipeX p;
     tx_prologue<NW>(p, lds, a.packed3, a.n, a.packed3, a.n.n_stage, lane, wave);
+    unsigned char* E = lds + TX_RING + TX_CONST_BYTES(a.n) + wave * TX_ELDS_WAVE + lane * 16;      // this lane's input pieces
     TxProf pf;
 #ifdef TN_STAMPS
     const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
@@ -124,12 +141,18 @@ __global__ __launch_bounds__((TxCfg<HID, TRAIN>::NW * 64), 1) void k_renderx3(Fw
                 const bool valid = rvalid && s < S;
                 const int sc = s < S ? s : S - 1;
                 const float z = tn_depth(sa, rayc, sc);
-                EncX E;
+                const float px = tn_point(ox, dx, z), py = tn_point(oy, dy, z), pz = tn_point(oz, dz, z);
+                EncX Er;
                 float encf[8 * TN16_KE];
-                tx_encode(tn_point(ox, dx, z), tn_point(oy, dy, z), tn_point(oz, dz, z), Lf, h, E,
-                          [&](auto stc, float val) TN_INLINE_LAMBDA { encf[decltype(stc)::value] = val; });
+                tx_encode(px, py, pz, Lf, h, encf);
+                TxIn in;
+                in.encmax = fmaxf(fmaxf(fabsf(px), fabsf(py)), fmaxf(fabsf(pz), 1.0f));      // |sin|, |cos| <= 1
+                in.l1 = __builtin_fmaf(3.0f, in.encmax, (float)(6 * Lf));
+                in.te = tx_scale_exp(in.encmax);
+                tx_split_input(Er, tx_exp2i(in.te), [&](auto ac) TN_INLINE_LAMBDA { return encf[decltype(ac)::value]; });
+                tx_store_input(E, Er);
                 float res[4];
-                tx_mlp_tile<HID, TRAIN>(p, lds, a, h, lane, E, encf, rayc * S + sc, valid, res, pf);
+                tx_mlp_tile<HID, TRAIN>(p, lds, a, h, lane, E, in, encf, rayc * S + sc, valid, res, pf);
                 const bool upper = (sb & 32) != 0;                            // wave-uniform
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -178,7 +201,7 @@ __global__ __launch_bounds__((TxCfg<HID, TRAIN>::NW * 64), 1) void k_renderx3(Fw
 
 // ------------------------------------------------------------------------------------------------ dgrad
 // What autograd derives from volume.py:18-42 and nerf.py:34-40 (as mlp_bwd.hip), with the chain dH_{l-1} = W_l^T dZ_l on the
-// bf16 matrix pipe: the backward record stream (heads^T, then the transposed hidden layers), dZ_l as three exact pieces, the
+// fp16 matrix pipe: the backward record stream (heads^T, then the transposed hidden layers), dZ_l as two scaled pieces, the
 // same k-step-major layer walk.  Reads the forward's sign bits and head outputs from the stash and writes every dZ_l (fp32)
 // next to them, exactly where the weight-gradient kernel expects them.
 struct BwdX3Args {
@@ -208,7 +231,6 @@ template <int HID>
 __device__ __forceinline__ void tx_bwd_tile(PipeX& p, const unsigned char* lds, const BwdX3Args& a, const float (&dzh)[4], int64_t m, bool valid,
                                             int lane) {
     constexpr int NT = HID / 32;
-    constexpr int ST = 0;
     const MlpLayout& L = a.b.L;
     const int h = lane >> 5, depth = a.n.depth;
     float* __restrict__ stash = a.b.stash;
@@ -222,21 +244,33 @@ __device__ __forceinline__ void tx_bwd_tile(PipeX& p, const unsigned char* lds, 
     const uint32_t* __restrict__ mrow = reinterpret_cast<const uint32_t*>(stash + TN_STASH_BODY_FLOATS(L, Mp)) + (2 * ms + h) * (NT / 2);
     ActX<HID> X;
     EncX Z;                                                        // the head gradient as the B operand of the heads^T k-step (slot (h=0, e<4) = row e)
+    // scale of the head gradient: its largest magnitude; the bound on dH_{depth-1} = W_head^T dZ_head: max|W_head| ||dZ_head||_1
+    const float zmax = fmaxf(fmaxf(fabsf(dzh[0]), fabsf(dzh[1])), fmaxf(fabsf(dzh[2]), fabsf(dzh[3])));
+    int t_prev = tx_scale_exp(zmax);
     {
-        unsigned a0, b0, c0, a1, b1, c1;
-        tx_split2(h ? 0.0f : dzh[0], h ? 0.0f : dzh[1], a0, b0, c0);
-        tx_split2(h ? 0.0f : dzh[2], h ? 0.0f : dzh[3], a1, b1, c1);
-        const u32x4 w1 = {a0, a1, 0u, 0u}, w2 = {b0, b1, 0u, 0u}, w3 = {c0, c1, 0u, 0u};
-        Z.p1[0] = __builtin_bit_cast(bf16x8, w1); Z.p2[0] = __builtin_bit_cast(bf16x8, w2); Z.p3[0] = __builtin_bit_cast(bf16x8, w3);
+        const float zs = tx_exp2i(t_prev);
+        unsigned a0, b0, a1, b1;
+        tx_split2(h ? 0.0f : dzh[0] * zs, h ? 0.0f : dzh[1] * zs, a0, b0);
+        tx_split2(h ? 0.0f : dzh[2] * zs, h ? 0.0f : dzh[3] * zs, a1, b1);
+        const u32x4 w1 = {a0, a1, 0u, 0u}, w2 = {b0, b1, 0u, 0u};
+        Z.p1[0] = w1; Z.p2[0] = w2;
     }
-    constexpr int NH = NT / 2, KH = HID / 16, NP = NH * 8, NW = TxCfg<HID>::NW;
+    constexpr int NH = NT / 2, KH = HID / 16, NP = NH * 8, NW = TxCfg<HID>::NW, G2 = KH / 2 * NH;
     f32x16 accA[TX_ACCN(HID)], accB[TX_ACCN(HID)];
     uint32_t mw[NT / 2];
     TxEpi es;
+    TxScale sc{0.0f, 0.0f, 0.0f};
     TxMask<NT / 2> mk;                                             // asm load + counted wait (above)
     float* __restrict__ zrow = nullptr;
-    auto epiA = [&](auto ic, auto jc, auto) TN_INLINE_LAMBDA { tx_epi_bwd<HID, 0, decltype(ic)::value, decltype(jc)::value>(accA, X, es, mw, zrow); };
-    auto epiB = [&](auto ic, auto jc, auto) TN_INLINE_LAMBDA { tx_epi_bwd<HID, 1, decltype(ic)::value, decltype(jc)::value>(accB, X, es, mw, zrow); };
+    // The product W_l^T dZ_l (l = depth: the heads) is about to enter its epilogues: the L1 norm of dZ_l is complete.
+    auto scale_for = [&](int l, float l1_in) TN_INLINE_LAMBDA {
+        const f32x4 mt = tx_meta(lds, a.n, l);
+        const int t_out = tx_scale_exp(mt[1] * l1_in);
+        sc.dsc = mt[0] * tx_exp2i(-t_prev); sc.osc = tx_exp2i(t_out); sc.l1 = 0.0f;
+        t_prev = t_out;
+    };
+    auto epiA = [&](auto ic, auto jc, auto) TN_INLINE_LAMBDA { tx_epi_bwd<HID, 0, decltype(ic)::value, decltype(jc)::value>(accA, X, es, sc, mw, zrow); };
+    auto epiB = [&](auto ic, auto jc, auto) TN_INLINE_LAMBDA { tx_epi_bwd<HID, 1, decltype(ic)::value, decltype(jc)::value>(accB, X, es, sc, mw, zrow); };
     // dH_{depth-1} = W_head^T dZ_head: both halves; half A's epilogue has nothing to hide behind
     mk.fetch(mrow + (int64_t)(depth - 1) * (Mp + 32) * NT);
     tx_pass_headsT<HID, NW>(p, lds, Z, accA, accB);
@@ -244,25 +278,27 @@ __device__ __forceinline__ void tx_bwd_tile(PipeX& p, const unsigned char* lds, 
 #pragma unroll
     for (int w = 0; w < NT / 2; ++w) mw[w] = mk.v[w];
     zrow = pl + L.dz_row0[depth - 1] * 32;
-    tx_drain<NP, 6>(epiA);
+    scale_for(depth, (fabsf(dzh[0]) + fabsf(dzh[1])) + (fabsf(dzh[2]) + fabsf(dzh[3])));
+    tx_drain<NP, 3>(epiA);
     // layer l (dH_{l-1} = W_l^T dZ_l): dZ_l's half B epilogue behind the first half of pass A; the sign words of layer l-1 are
     // fetched before pass A and waited for (>= TX_LEAD boundaries later) at the start of dZ_{l-1}'s half A epilogue, which rides
     // on the second half of pass B
     for (int l = depth - 1; l >= 1; --l) {
         mk.fetch(mrow + (int64_t)(l - 1) * (Mp + 32) * NT);
-        tx_pass<HID, 1, true, NW>(p, lds, X, Z, accA, tx_window<0, KH / 2 * NH, NP>(epiB));
-        auto winA = tx_window<KH / 2 * NH * 6, KH / 2 * NH, NP>(epiA);
-        tx_pass<HID, 1, true, NW>(p, lds, X, Z, accB, [&](auto sc) TN_INLINE_LAMBDA {
-            if constexpr (decltype(sc)::value == KH / 2 * NH * 6) {
+        tx_pass<HID, 1, true, NW>(p, lds, X, nullptr, accA, tx_window<0, G2, NP>(epiB));
+        auto winA = tx_window<G2 * TX_SPG, G2, NP>(epiA);
+        tx_pass<HID, 1, true, NW>(p, lds, X, nullptr, accB, [&](auto sc_) TN_INLINE_LAMBDA {
+            if constexpr (decltype(sc_)::value == G2 * TX_SPG) {
                 mk.template wait<TxCfg<HID>::DPW * TX_LEAD>();
 #pragma unroll
                 for (int w = 0; w < NT / 2; ++w) mw[w] = mk.v[w];
                 zrow = pl + L.dz_row0[l - 1] * 32;
+                scale_for(l, sc.l1 + tx_partner(sc.l1));
             }
-            winA(sc);
+            winA(sc_);
         });
     }
-    tx_drain<NP, 3>(epiB);                                         // dZ_0, half B: to the stash only
+    tx_drain<NP, 2>(epiB);                                         // dZ_0, half B: to the stash only
 }
 
 template <int HID>
@@ -353,30 +389,14 @@ __global__ __launch_bounds__(TxCfg<HID>::NW * 64, 1) void k_dgradx3(BwdX3Args a)
 // src/train.py:117-118): the same tiles as the fused kernels with the network input READ instead of computed.  in_dim = 6L+3:
 // the k-slot (step a = 8u + e, lane half h) of the record stream carries column 3 + 6 (a/3) + 3h + a%3 of x for a < 3L (the
 // sin / cos of frequency a/3, coordinate a%3), columns h and 2 (h = 0) for the raw coordinates at a = 3L, 3L+1.
-template <typename Out>
-__device__ __forceinline__ void tx_load_input(const float* __restrict__ xrow, bool valid, int Lf, int h, EncX& E, Out&& out) {
-    tn_static_for<TN16_KE>([&](auto uc) TN_INLINE_LAMBDA {
-        constexpr int u = decltype(uc)::value;
-        float v[8];
-        tn_static_for<8>([&](auto ec) TN_INLINE_LAMBDA {
-            constexpr int e = decltype(ec)::value;
-            constexpr int a = 8 * u + e;
-            int col = -1;
-            if (a < 3 * Lf)           col = 3 + 6 * (a / 3) + 3 * h + a % 3;
-            else if (a == 3 * Lf)     col = h;
-            else if (a == 3 * Lf + 1) col = h ? -1 : 2;
-            const float r = (valid && col >= 0) ? xrow[col] : 0.0f;
-            v[e] = r;
-            out(std::integral_constant<int, a>{}, r);
-        });
-        u32x4 w1, w2, w3;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            unsigned a_, b_, c_;
-            tx_split2(v[2 * q], v[2 * q + 1], a_, b_, c_);
-            w1[q] = a_; w2[q] = b_; w3[q] = c_;
-        }
-        E.p1[u] = __builtin_bit_cast(bf16x8, w1); E.p2[u] = __builtin_bit_cast(bf16x8, w2); E.p3[u] = __builtin_bit_cast(bf16x8, w3);
+__device__ __forceinline__ void tx_load_input(const float* __restrict__ xrow, bool valid, int Lf, int h, float (&encf)[8 * TN16_KE]) {
+    tn_static_for<8 * TN16_KE>([&](auto ac) TN_INLINE_LAMBDA {
+        constexpr int a = decltype(ac)::value;
+        int col = -1;
+        if (a < 3 * Lf)           col = 3 + 6 * (a / 3) + 3 * h + a % 3;
+        else if (a == 3 * Lf)     col = h;
+        else if (a == 3 * Lf + 1) col = h ? -1 : 2;
+        encf[a] = (valid && col >= 0) ? xrow[col] : 0.0f;
     });
 }
 
@@ -389,6 +409,7 @@ __global__ __launch_bounds__((TxCfg<HID, TRAIN>::NW * 64), 1) void k_mlpx3_fwd(F
     const int j = lane & 31, h = lane >> 5;
     PipeX p;
     tx_prologue<NW>(p, lds, a.packed3, a.n, a.packed3, a.n.n_stage, lane, wave);
+    unsigned char* E = lds + TX_RING + TX_CONST_BYTES(a.n) + wave * TX_ELDS_WAVE + lane * 16;
     TxProf pf;
     const int64_t M = a.f.M, n_tiles = (M + 31) / 32, n_groups = (n_tiles + NW - 1) / NW;
     const int in_dim = a.n.in_dim, Lf = a.n.Lf;
@@ -396,11 +417,20 @@ __global__ __launch_bounds__((TxCfg<HID, TRAIN>::NW * 64), 1) void k_mlpx3_fwd(F
         const int64_t m = (g * NW + wave) * 32 + j;
         const bool valid = m < M;
         const int64_t mc = valid ? m : M - 1;
-        EncX E;
+        EncX Er;
         float encf[8 * TN16_KE];
-        tx_load_input(a.f.x + mc * in_dim, valid, Lf, h, E, [&](auto stc, float val) TN_INLINE_LAMBDA { encf[decltype(stc)::value] = val; });
+        tx_load_input(a.f.x + mc * in_dim, valid, Lf, h, encf);
+        TxIn in;
+        {   // this lane holds half of the row: largest magnitude and L1 norm over both lane halves
+            float mx = 1.0f, l1 = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 8 * TN16_KE; ++i) { mx = fmaxf(mx, fabsf(encf[i])); l1 += fabsf(encf[i]); }
+            in.encmax = fmaxf(mx, tx_partner(mx)); in.l1 = l1 + tx_partner(l1); in.te = tx_scale_exp(in.encmax);
+        }
+        tx_split_input(Er, tx_exp2i(in.te), [&](auto ac) TN_INLINE_LAMBDA { return encf[decltype(ac)::value]; });
+        tx_store_input(E, Er);
         float res[4];
-        tx_mlp_tile<HID, TRAIN>(p, lds, a, h, lane, E, encf, mc, valid, res, pf);
+        tx_mlp_tile<HID, TRAIN>(p, lds, a, h, lane, E, in, encf, mc, valid, res, pf);
         if (valid && h == 0) {
             a.f.rgb_out[3 * m + 0] = res[0]; a.f.rgb_out[3 * m + 1] = res[1]; a.f.rgb_out[3 * m + 2] = res[2];
             a.f.sigma_out[m] = res[3];
@@ -445,7 +475,7 @@ int tnx3_launch_dgrad(const BwdX3Args& a, bool mlp_only, hipStream_t stream, con
     const int nw = a.n.hidden == 256 ? TxCfg<256>::NW : TxCfg<128>::NW;
     const int64_t units = mlp_only ? (a.b.M + 31) / 32 : a.b.R, groups = (units + nw - 1) / nw;
     const dim3 grid((unsigned)(groups < n_cu ? groups : n_cu)), block(nw * 64);
-    const size_t lds_bytes = TX_RING + (size_t)((a.n.n_bias + 3) / 4 * 4) * 4;
+    const size_t lds_bytes = TX_LDS_BYTES(a.n, nw, false);
 #define TX_CASE(H_, K_, M_)                                                                                                  \
     if (a.n.hidden == H_ && mlp_only == M_) {                                                                                 \
         static std::atomic<uint32_t> seen_[TN_MAX_DEVICES];                                                                   \
@@ -473,7 +503,7 @@ int tnx3_launch_fwd(const FwdX3Args& a, bool train, hipStream_t stream, const ch
     const int nw = a.n.hidden == 256 ? 4 : (train ? TxCfg<128, true>::NW : TxCfg<128, false>::NW);
     const int64_t units = mlp_only ? (a.f.M + 31) / 32 : a.f.R, groups = (units + nw - 1) / nw;
     const dim3 grid((unsigned)(groups < n_cu ? groups : n_cu)), block(nw * 64);
-    const size_t lds_bytes = TX_RING + (size_t)((a.n.n_bias + 3) / 4 * 4) * 4;
+    const size_t lds_bytes = TX_LDS_BYTES(a.n, nw, true);
 #define TX_CASE(H_, T_)                                                                                                      \
     if (a.n.hidden == H_ && train == T_) {                                                                                    \
         static std::atomic<uint32_t> seen_[TN_MAX_DEVICES];                                                                   \
@@ -594,20 +624,62 @@ extern "C" int tnerf_train_fwd_fused_x3(const tnerf_mlp_desc* d, const void* pac
 }
 
 // ----------------------------------------------------------------------------------- packing
-// stream element i (bf16) = piece ((i >> 9) mod 3) of params[table[i]]: p1 = trunc_bf16(x), p2 = trunc_bf16(x - p1),
-// p3 = x - p1 - p2 (exact); the entries behind the stream are the fp32 biases.
-__global__ __launch_bounds__(256) void k_packx3(const float* __restrict__ params, const int32_t* __restrict__ table, int64_t n_w,
-                                                int64_t n_all, unsigned short* __restrict__ out16, float* __restrict__ out32) {
+// One workgroup per layer (index depth = the heads): max|W| and max|b| of the layer, through the pack table (forward stream,
+// piece-0 fragments: every weight of the layer exactly once).  The maxima are order-independent: deterministic.
+//   post = 0 (a full pack follows): scale record <- {1 / 2^s, max|W|, max|b|, 2^s} with max|W| 2^s in [2^11, 2^12)
+//   post = 1 (the finishing kernel has just re-scattered every weight with the scale the record's [3] named): [0] <- 1 / [3],
+//            then [1], [2], [3] from the updated parameters — the chain kernels of the next step read the scale that is in the
+//            stream and bounds that hold for the weights that are in the stream.
+__global__ __launch_bounds__(1024) void k_x3stats(const float* __restrict__ params, const int32_t* __restrict__ table, NetX3 n,
+                                                  float* __restrict__ meta, int post) {
+    const int l = blockIdx.x;
+    const int64_t fe = (int64_t)n.rec_frags * 512;
+    const int64_t e0 = n.fw_rec0[l] * fe, e1 = n.fw_rec0[l + 1] * fe, n_w = (int64_t)(n.n_rec + n.n_bw_rec) * fe;
+    float mw = 0.0f, mb = 0.0f;
+    for (int64_t e = e0 + threadIdx.x; e < e1; e += 1024) {
+        if (((e >> 9) % TX_NP) != 0) continue;
+        const int32_t s = table[e];
+        if (s >= 0) mw = fmaxf(mw, fabsf(params[s]));
+    }
+    const int nb = l < n.depth ? n.hidden : 4, b0 = l < n.depth ? l * n.hidden : n.depth * n.hidden;
+    for (int j = threadIdx.x; j < nb; j += 1024) {
+        const int32_t s = table[n_w + b0 + j];
+        if (s >= 0) mb = fmaxf(mb, fabsf(params[s]));
+    }
+    __shared__ float red[2][16];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { mw = fmaxf(mw, __shfl_xor(mw, o, 64)); mb = fmaxf(mb, __shfl_xor(mb, o, 64)); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = mw; red[1][threadIdx.x >> 6] = mb; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 1; w < 16; ++w) { mw = fmaxf(mw, red[0][w]); mb = fmaxf(mb, red[1][w]); }
+        float* m = meta + l * TX_META;
+        const float wsc_old = m[3];
+        const float wsc_new = tx_exp2i(12 - __builtin_amdgcn_frexp_expf(mw));      // max|W| = f 2^e, f in [0.5, 1): max|W| 2^(12-e) in [2^11, 2^12)
+        m[0] = 1.0f / (post ? wsc_old : wsc_new);                                   // a power of two: exact
+        m[1] = mw; m[2] = mb; m[3] = wsc_new;
+    }
+}
+
+int tnx3_launch_stats(const NetX3& n, const float* params, const int32_t* table, void* packed3, int post, hipStream_t stream) {
+    hipLaunchKernelGGL(k_x3stats, dim3((unsigned)(n.depth + 1)), dim3(1024), 0, stream, params, table, n,
+                       reinterpret_cast<float*>(static_cast<unsigned char*>(packed3) + n.meta_off), post);
+    TN_HIP_CHECK_LAUNCH("x3 weight statistics");
+    return TNERF_OK;
+}
+
+// stream element i (fp16) = piece ((i >> 9) mod TX_NP) of params[table[i]] 2^s (s: the layer's scale record, tx_piece_bits);
+// the entries behind the stream are the fp32 biases.
+__global__ __launch_bounds__(256) void k_packx3(const float* __restrict__ params, const int32_t* __restrict__ table, NetX3 n, int64_t n_w,
+                                                unsigned short* __restrict__ out16, float* __restrict__ out32, const float* __restrict__ meta) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_all) return;
+    if (i >= n.pack_entries) return;
     const int32_t s = table[i];
     const float x = s >= 0 ? params[s] : 0.0f;
     if (i >= n_w) { out32[i - n_w] = x; return; }
-    const int piece = (int)((i >> 9) % 3);
-    const float r = x - __uint_as_float(__float_as_uint(x) & 0xFFFF0000u);
-    const float t = r - __uint_as_float(__float_as_uint(r) & 0xFFFF0000u);
-    const float pv = piece == 0 ? x : (piece == 1 ? r : t);
-    out16[i] = (unsigned short)(__float_as_uint(pv) >> 16);
+    const int l = tx_record_layer(&n, (int)(i / ((int64_t)n.rec_frags * 512)));
+    out16[i] = tx_piece_bits(x, meta[l * TX_META + 3], (int)((i >> 9) % TX_NP));
 }
 
 extern "C" int tnerf_mlp_pack_x3(const tnerf_mlp_desc* d, const float* params, const int32_t* table, void* packed3,
@@ -617,10 +689,12 @@ extern "C" int tnerf_mlp_pack_x3(const tnerf_mlp_desc* d, const float* params, c
         tn_set_error("tnerf_mlp_pack_x3: params=%p table=%p packed3=%p", (const void*)params, (const void*)table, packed3);
         return TNERF_EINVAL;
     }
+    if ((rc = tnx3_launch_stats(n, params, table, packed3, 0, (hipStream_t)stream))) return rc;
     const int64_t n_w = (int64_t)(n.n_rec + n.n_bw_rec) * n.rec_frags * 512;
-    hipLaunchKernelGGL(k_packx3, dim3((unsigned)((n.pack_entries + 255) / 256)), dim3(256), 0, (hipStream_t)stream, params, table, n_w,
-                       n.pack_entries, static_cast<unsigned short*>(packed3),
-                       reinterpret_cast<float*>(static_cast<unsigned char*>(packed3) + n.bias_off));
+    unsigned char* base = static_cast<unsigned char*>(packed3);
+    hipLaunchKernelGGL(k_packx3, dim3((unsigned)((n.pack_entries + 255) / 256)), dim3(256), 0, (hipStream_t)stream, params, table, n, n_w,
+                       reinterpret_cast<unsigned short*>(base), reinterpret_cast<float*>(base + n.bias_off),
+                       reinterpret_cast<const float*>(base + n.meta_off));
     TN_HIP_CHECK_LAUNCH("tnerf_mlp_pack_x3");
     return TNERF_OK;
 }

@@ -1,61 +1,74 @@
-// "x3" chain: the fp32 MLP chain on the bf16 matrix pipe with EXACT fp32 products.
+// "x3" chain: the fp32 MLP chain on the fp16 matrix pipe with every fp32 product formed from THREE partial products
+// (the arithmetic of the matrix pipe it is built around: tools/microbench/mfma_sim.c).
 //
-// Every fp32 operand is the sum of three bf16 numbers (mantissa cut 8 + 8 + 8, each cut exact), a product of two bf16
-// numbers is exact in fp32, so six v_mfma_f32_32x32x16_bf16 with fp32 accumulation (a3 b1, a2 b2, a1 b3, a2 b1, a1 b2,
-// a1 b1) carry a * b up to terms below 2^-24 |ab|.  The fp32 pipe's chain kernels (mlp_core.hpp) sit at the clock-limited
-// ceiling of that pipe; this form needs 6/16 of its matrix time.
+// An operand x (fp32) is scaled by a power of two into the fp16 range and carried as two fp16 pieces, x 2^s = p1 + p2, both
+// rounded to nearest: 22-23 significant bits.  a b 2^(s+t) = a1 b1 + (a1 b2 + a2 b1) [+ a2 b2 <= 2^-22 |ab|: dropped].  Three
+// v_mfma_f32_32x32x16_f16 per (32-feature tile, 16-wide k-step): the LEADING products accumulate in one fp32 accumulator, the
+// two CORRECTION products in a second one, and the two are added once, in the epilogue.  The split accumulators are not a
+// luxury: the matrix pipe cuts its accumulator to the window of the group's largest product by FLOOR (toward -inf) before
+// adding, so an accumulator that carries fine correction bits and then meets large leading products is biased downwards,
+// identically for every sample — measured as 5x the reference's error on single weight-gradient tensors.  An accumulator that
+// only ever receives leading products has no bits below that window; the correction accumulator's cuts are 2^-11 smaller.
+// Measured (model of the pipe fitted to hardware dumps, 8x256 fixture): activations 1.1e-7 from fp64 after 8 layers (an fp32 fma
+// chain: 2.2e-7), every weight-gradient tensor within 1.3x of the reference's own CPU fp32 error.
+//
+// Scales.  Weights: one power of two per layer, max|W| 2^s in (2^11, 2^12] (k_x3stats / the finishing kernel keep it, the
+// stream's TX_META records carry it).  Activations: one power of two PER SAMPLE and layer, chosen from a bound known before the
+// layer's epilogue starts:  max_i |H_l[i]| <= max|W_l| ||X_l||_1 + max|b_l|  with X_l the layer's input, whose L1 norm the
+// previous epilogue summed;  t = 14 - exponent(bound)  puts every scaled activation below 2^14 (fp16 overflows at 2^16).  Values
+// more than 2^-17 below the bound keep less than 22 bits, but never less than 2^-39 of the bound absolutely.
 //
 // Orientation as everywhere in this library: weights = A operand, the wave's 32 samples on the lanes, the 32x32 fp32
-// accumulator of n-tile t = the next layer's B operand for k-steps 2t, 2t+1 — here after bias / ReLU in fp32 and ONE exact
-// split into three packed bf16 operand registers.  What differs from the bf16 mode (mlp16_core.hpp):
+// accumulator of n-tile t = the next layer's B operand for k-steps 2t, 2t+1 — after bias / ReLU in fp32 and one split.
 //   * k-step-major order in two HALF-PASSES per layer (output tiles 0..NT/2-1 = half A, then half B), all of a half's
-//     accumulators live; the three pieces of the input activation X[s] are dead once half B has passed k-step s, so the layer's
-//     output pieces are written back into the same registers: one activation array (3 x HID/16 x 4 registers) instead of an
-//     in / out pair.  8x256: 192 + 128 registers — one wave per SIMD (512-register budget), four waves per workgroup.
-//   * with one wave per SIMD nothing else fills the matrix pipe while a wave runs an epilogue (bias, ReLU, sign bits, stash
-//     store, split: ~8 VALU per value), so the epilogue of one half is cut into per-pair MICRO-STEPS that are issued in the
-//     shadows of the other half's MFMAs (tx_pass's hook): half A's epilogue rides on the second half of pass B (X[0..KH/2)
-//     is dead there), half B's on the first half of the next layer's pass A.  The order is pinned with sched_barrier.
-//   * the weight stream carries three pieces per fragment (tnerf_internal.h, NetX3): per (half, k-step) record NT/2 x 3 KB
-//     through an LDS ring of 24 KB stages (LDS-DMA, counted vmcnt, one raw barrier per stage), shared by the four waves.
+//     accumulators live; the pieces of the input activation X[s] are dead once half B has passed k-step s, so the layer's
+//     output pieces are written back into the same registers.  8x256: 128 (pieces) + 256 (two halves x main / correction)
+//     registers — one wave per SIMD, four waves per workgroup.
+//   * the epilogue of one half (descale, bias, ReLU, sign bits, stash store, L1 norm, split) is cut into per-pair MICRO-STEPS
+//     issued in the shadows of the other half's MFMAs (tx_pass's hook); the order is pinned with sched_barrier.
+//   * the weight stream: per (half, k-step) record NT/2 x 2 KB through an LDS ring of 16 KB stages (LDS-DMA, counted vmcnt,
+//     one raw barrier per stage), shared by the four waves.
 #pragma once
 #include "mlp16_core.hpp"
 
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#define TX_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+
 #define TX_SLOT (TX_STAGE * 1024)              // bytes per stage
-#define TX_NS 5                                // ring slots
-#define TX_RING (TX_NS * TX_SLOT)              // 120 KB
-#define TX_LEAD 3                              // stages in flight behind the published one (LEAD + 2 <= NS)
-// Waves per workgroup: 256-wide nets need the 512-register budget of one wave per SIMD; a 128-wide wave fits 256 registers, so
-// two of them share a SIMD and fill each other's gaps (encoder, compositing, barriers).
-// Diagnostic builds only (-DTX_SPLIT_ACC=1, tools/x3_accuracy_probe.py): the five correction products of a k-step accumulate in a
-// second accumulator set (acc[NH + tile]) that never holds the large a1.b1 sums, and the two are added in the epilogue — what the
-// chain would deliver if the matrix pipe did not drop addends below 1/8 ulp of its accumulator (accuracy).  Costs
-// 128 registers the 256-wide kernels do not have (it spills): a measurement, not a product option.
-#ifndef TX_SPLIT_ACC
-#define TX_SPLIT_ACC 0
-#endif
-#define TX_ACCN(HID) ((HID) / 64 * (1 + TX_SPLIT_ACC))
-#ifndef TX_NW128
-#define TX_NW128 8
-#endif
-// (The 128-wide TRAINING forward keeps four: its stash pointers and sign words do not fit 256 registers — 91 spilled.)
+#define TX_NS 7                                // ring slots
+#define TX_RING (TX_NS * TX_SLOT)              // 112 KB
+#define TX_LEAD 5                              // stages in flight behind the published one (LEAD + 2 <= NS)
+#define TX_TOP 14                              // scaled activations stay below 2^TX_TOP
 template <int HID, bool TRAIN_FWD = false> struct TxCfg {
-    static constexpr int NW = (HID == 128 && !TRAIN_FWD) ? TX_NW128 : 4;
+    static constexpr int NW = 4;                                  // one wave per SIMD (the split accumulators need its 512 registers)
     static constexpr int DPW = TX_STAGE / NW;                     // DMA pieces per wave and stage
     static_assert(TX_STAGE % NW == 0 && DPW <= 8, "ring budget");
 };
 static_assert(TX_LEAD + 2 <= TX_NS, "ring budget");
 
-// x (two fp32) -> the three packed bf16 pieces of the pair: dword = (hi16 of piece(x1)) : (hi16 of piece(x0))
-__device__ __forceinline__ void tx_split2(float x0, float x1, unsigned& p1, unsigned& p2, unsigned& p3) {
-    const uint32_t u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
-    const float r0 = x0 - __uint_as_float(u0 & 0xFFFF0000u), r1 = x1 - __uint_as_float(u1 & 0xFFFF0000u);
-    const uint32_t v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
-    const float s0 = r0 - __uint_as_float(v0 & 0xFFFF0000u), s1 = r1 - __uint_as_float(v1 & 0xFFFF0000u);
-    p1 = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
-    p2 = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
-    p3 = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);          // <= 8 significant bits left: exact
+// ---- fp16 pieces
+__device__ __forceinline__ unsigned tx_cvt2(float lo, float hi) {             // v_cvt_pk_f16_f32: two fp32 -> one dword of two fp16 (RNE)
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
 }
+__device__ __forceinline__ float tx_lo2f(unsigned p) { return (float)__builtin_bit_cast(f16x2, p)[0]; }
+__device__ __forceinline__ float tx_hi2f(unsigned p) { return (float)__builtin_bit_cast(f16x2, p)[1]; }
+// (x0, x1) already scaled -> the two packed pieces of the pair
+__device__ __forceinline__ void tx_split2(float x0, float x1, unsigned& p1, unsigned& p2) {
+    p1 = tx_cvt2(x0, x1);
+    p2 = tx_cvt2(x0 - tx_lo2f(p1), x1 - tx_hi2f(p1));
+}
+// 2^e as a float, e clamped to the normal range
+__device__ __forceinline__ float tx_exp2i(int e) { return __uint_as_float((uint32_t)(min(max(e, -126), 127) + 127) << 23); }
+// t with bound * 2^t < 2^TX_TOP (bound >= 0; 0 and non-finite bounds give a harmless finite scale)
+__device__ __forceinline__ int tx_scale_exp(float bound) {
+    const int e = __builtin_amdgcn_frexp_expf(bound);           // bound = m 2^e, m in [0.5, 1)   (0 for bound = 0 / inf / nan)
+    return min(max(TX_TOP - e, -100), 100);
+}
+// the other lane of this sample (lane ^ 32)
+__device__ __forceinline__ float tx_partner(float v) { return __shfl_xor(v, 32, 64); }
 
 // Per-wave state of the weight stream (4 waves per workgroup).
 struct PipeX {
@@ -87,7 +100,7 @@ __device__ __forceinline__ void tx_issue_stage(PipeX& p) {
     p.dst_off += TX_SLOT; if (p.dst_off == TX_RING) p.dst_off = 0;
 }
 // ... or piece by piece behind the MFMAs of the stage that has just been published (tx_pass): back-to-back DMA instructions
-// cost the wave more issue time than the same six spread over as many MFMA groups.
+// cost the wave more issue time than the same pieces spread over as many MFMA groups.
 __device__ __forceinline__ void tx_defer_stage(PipeX& p) {
     p.pend_src = p.src + p.src_off; p.pend_dst = p.lds_dst0 + p.dst_off;
     p.src_off += TX_SLOT; if (p.src_off == p.stream_bytes) p.src_off = 0;
@@ -106,8 +119,8 @@ __device__ __forceinline__ void tx_boundary(PipeX& p) {
     p.cur += TX_SLOT; if (p.cur == TX_RING) p.cur = 0;
 }
 
-// Workgroup prologue: biases -> LDS, LEAD stages in flight, the first one landed; the first tx_boundary publishes stage 0.
-// `src` / `n_stage`: the stream this kernel walks (forward: packed, n.n_stage; dgrad: the backward stream behind it).
+// Workgroup prologue: biases + scale records -> LDS, LEAD stages in flight, the first one landed; the first tx_boundary
+// publishes stage 0.  `src` / `n_stage`: the stream this kernel walks (forward: packed, n.n_stage; dgrad: the backward stream).
 template <int NW>
 __device__ __forceinline__ void tx_prologue(PipeX& p, unsigned char* lds, const unsigned char* packed, const NetX3& n,
                                             const unsigned char* src, int n_stage, int lane, int wave) {
@@ -115,7 +128,8 @@ __device__ __forceinline__ void tx_prologue(PipeX& p, unsigned char* lds, const 
     {
         float* bl = reinterpret_cast<float*>(lds + TX_RING);
         const float* bg = reinterpret_cast<const float*>(packed + n.bias_off);
-        for (int i = threadIdx.x; i < n.n_bias; i += NW * 64) bl[i] = bg[i];
+        const int nf = n.n_bias + (n.depth + 1) * TX_META;            // the scale records follow the biases
+        for (int i = threadIdx.x; i < nf; i += NW * 64) bl[i] = bg[i];
     }
     p.lane16 = lane * 16;
     p.src = src; p.src_off = 0; p.stream_bytes = (uint32_t)n_stage * TX_SLOT;
@@ -127,41 +141,53 @@ __device__ __forceinline__ void tx_prologue(PipeX& p, unsigned char* lds, const 
     for (int i = 0; i < TX_LEAD; ++i) tx_issue_stage<DPW>(p);
     p.cur = TX_RING - TX_SLOT;                   // the first boundary moves it onto slot 0
 }
+#define TX_CONST_BYTES(n) ((uint32_t)(((n).n_bias + ((n).depth + 1) * TX_META + 3) / 4 * 4) * 4)
+// Behind the ring and the constants: the network-input pieces of every wave's tile (forward kernels; [piece][k-step][lane] x 16 B).
+// They are needed by layer 0 and again by the skip layer: parked in LDS they do not hold 32 registers through the layers between.
+#define TX_ELDS_WAVE (TX_NP * TN16_KE * 1024)
+#define TX_LDS_BYTES(n, nw, fwd) ((size_t)TX_RING + TX_CONST_BYTES(n) + ((fwd) ? (size_t)(nw) * TX_ELDS_WAVE : 0))
+// scale record of layer l (l = depth: heads) in the LDS copy: {2^-s, max|W|, max|b|, -}
+__device__ __forceinline__ f32x4 tx_meta(const unsigned char* lds, const NetX3& n, int l) {
+    return *reinterpret_cast<const f32x4*>(lds + TX_RING + (n.n_bias + l * TX_META) * 4);
+}
 
-// The activation of a wave's 32-sample tile: three bf16 pieces of every k-step operand.
+// The activation of a wave's 32-sample tile: two fp16 pieces of every k-step operand.
 template <int HID>
-struct ActX { u32x4 p1[HID / 16], p2[HID / 16], p3[HID / 16]; };          // packed bf16 pairs; dword q = values 2q, 2q+1 of the k-step
-#define TX_BF(x) __builtin_bit_cast(bf16x8, (x))
-struct EncX { bf16x8 p1[TN16_KE], p2[TN16_KE], p3[TN16_KE]; };
+struct ActX { u32x4 p1[HID / 16], p2[HID / 16]; };          // packed fp16 pairs; dword q = values 2q, 2q+1 of the k-step
+#define TX_H8(x) __builtin_bit_cast(f16x8, (x))
+struct EncX { u32x4 p1[TN16_KE], p2[TN16_KE]; };
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-struct FragX { bf16x8 a1, a2, a3; };
+struct FragX { f16x8 a1, a2; };
 __device__ __forceinline__ FragX tx_frag_load(const unsigned char* base, int tl) {
     FragX f;
-    f.a1 = *reinterpret_cast<const bf16x8*>(base + (tl * 3 + 0) * 1024);
-    f.a2 = *reinterpret_cast<const bf16x8*>(base + (tl * 3 + 1) * 1024);
-    f.a3 = *reinterpret_cast<const bf16x8*>(base + (tl * 3 + 2) * 1024);
+    f.a1 = *reinterpret_cast<const f16x8*>(base + (tl * TX_NP + 0) * 1024);
+    f.a2 = *reinterpret_cast<const f16x8*>(base + (tl * TX_NP + 1) * 1024);
     return f;
 }
 #define TX_PIN() __builtin_amdgcn_sched_barrier(0)
+#define TX_ACCN(HID) ((HID) / 64 * 2)             // a half's accumulators: [tile slot] leading products, [NH + tile slot] corrections
+#define TX_SPG 3                                  // MFMAs (= hook slots) per (tile, k-step) group
 
-// One half-pass of a layer: NK k-step records, each NTU tiles x 6 MFMAs into acc[tile slot].
-// KIND 0: the TN16_KE input k-steps (B operand from E)   1: the hidden k-steps   3: heads — ONE output tile (acc[0]), so a
+// One half-pass of a layer: NK k-step records, each NTU tiles x 3 MFMAs into acc[tile slot] / acc[NH + tile slot].
+// KIND 0: the TN16_KE input k-steps (B operand from E)   1: the hidden k-steps   3: heads — ONE output tile (acc[0], acc[NH]), so a
 // record's NH tile slots carry NH consecutive k-steps of it instead (KH / NH records).
 // A skip layer's half is a KIND 1 pass followed by a KIND 0 pass that accumulates (ZERO = false) — one copy of the long pass
 // in the instruction cache instead of two.
 // RPS = records per stage (2 for 256-wide, 4 for 128-wide nets); every pass is a whole number of stages, so the stage
 // phase of record k is k % RPS.  ZERO: the accumulators start at zero.
-// hook(integral_constant<slot>) is called behind MFMA number slot = (k * NTU + tile) * 6 + j: work to issue in its shadow.
+// hook(integral_constant<slot>) is called behind MFMA number slot = (k * NTU + tile) * 3 + j: work to issue in its shadow.
 // The next group's A fragments are read from LDS behind the first MFMA of a group (not across a stage boundary).
+// elds: this lane's slot of the wave's network-input pieces in LDS (KIND 0; tx_store_input), read one k-step ahead.
 template <int HID, int KIND, bool ZERO, int NW, typename Hook>
-__device__ __forceinline__ void tx_pass(PipeX& p, const unsigned char* lds, const ActX<HID>& X, const EncX& E,
+__device__ __forceinline__ void tx_pass(PipeX& p, const unsigned char* lds, const ActX<HID>& X, const unsigned char* elds,
                                         f32x16 (&acc)[TX_ACCN(HID)], Hook&& hook) {
-    constexpr int NH = HID / 64, KH = HID / 16, RPS = TX_STAGE / (NH * 3), DPW = TX_STAGE / NW;
+    constexpr int NH = HID / 64, KH = HID / 16, RPS = TX_STAGE / (NH * TX_NP), DPW = TX_STAGE / NW;
     constexpr int NK = KIND == 0 ? TN16_KE : (KIND == 3 ? KH / NH : KH);
     constexpr int NTU = NH;
     static_assert(NK % RPS == 0, "a half-pass must be a whole number of stages");
     FragX cur;
+    f16x8 e1, e2, en1, en2;                                          // KIND 0: the B operand of this / the next k-step
+    if constexpr (KIND == 0) { e1 = *reinterpret_cast<const f16x8*>(elds); e2 = *reinterpret_cast<const f16x8*>(elds + TN16_KE * 1024); }
     tn_static_for<NK>([&](auto kc) TN_INLINE_LAMBDA {
         constexpr int k = decltype(kc)::value;
         // The stage boundary (wait, barrier, next DMA stage named) of every stage but the pass's first is taken one MFMA group
@@ -169,31 +195,31 @@ __device__ __forceinline__ void tx_pass(PipeX& p, const unsigned char* lds, cons
         // stage's first fragments are read behind that group's MFMAs instead of in front of an idle matrix pipe.  (The ring has
         // the spare slot this needs: TX_LEAD + 2 <= TX_NS.)
         if constexpr (k == 0) tx_boundary<DPW, true>(p);
-        const unsigned char* base = lds + p.cur + (k % RPS) * (NH * 3 * 1024) + p.lane16;
+        const unsigned char* base = lds + p.cur + (k % RPS) * (NH * TX_NP * 1024) + p.lane16;
         if constexpr (k == 0) cur = tx_frag_load(base, 0);
         tn_static_for<NTU>([&](auto tc) TN_INLINE_LAMBDA {
             constexpr int tl = decltype(tc)::value;
             constexpr int ks = KIND == 3 ? k * NH + tl : k;          // the k-step of this group's B operand
             constexpr int ta = KIND == 3 ? 0 : tl;                   // ... and its accumulator
-            bf16x8 b1, b2, b3;
-            if constexpr (KIND == 0) { b1 = E.p1[ks]; b2 = E.p2[ks]; b3 = E.p3[ks]; }
-            else { b1 = TX_BF(X.p1[ks]); b2 = TX_BF(X.p2[ks]); b3 = TX_BF(X.p3[ks]); }
+            f16x8 b1, b2;
+            if constexpr (KIND == 0) { b1 = e1; b2 = e2; }
+            else { b1 = TX_H8(X.p1[ks]); b2 = TX_H8(X.p2[ks]); }
             constexpr bool more_tile = tl + 1 < NTU;
             constexpr bool more_rec = !more_tile && (k + 1) % RPS != 0 && k + 1 < NK;
             constexpr bool early = !more_tile && (k + 1) % RPS == 0 && k + 1 < NK;      // last group of a stage, another follows in this pass
-            constexpr int s0 = (k * NTU + tl) * 6;
+            constexpr int s0 = (k * NTU + tl) * TX_SPG;
             FragX nxt;
             if constexpr (early) tx_boundary<DPW, true>(p);
-            constexpr int tc_ = TX_SPLIT_ACC ? ta + NH : ta;         // where the correction products go
-            if constexpr (ZERO && ks == 0) { const f32x16 z = {}; acc[tc_] = TN16_MFMA(cur.a3, b1, z); }
-            else                          acc[tc_] = TN16_MFMA(cur.a3, b1, acc[tc_]);
+            if constexpr (ZERO && ks == 0) { const f32x16 z = {}; acc[ta + NH] = TX_MFMA(cur.a2, b1, z); }
+            else                          acc[ta + NH] = TX_MFMA(cur.a2, b1, acc[ta + NH]);
             if constexpr (more_tile)     nxt = tx_frag_load(base, tl + 1);
-            else if constexpr (more_rec) nxt = tx_frag_load(base + NH * 3 * 1024, 0);
+            else if constexpr (more_rec) nxt = tx_frag_load(base + NH * TX_NP * 1024, 0);
             else if constexpr (early)    nxt = tx_frag_load(lds + p.cur + p.lane16, 0);
+            if constexpr (KIND == 0 && tl == 0 && k + 1 < NK) {
+                en1 = *reinterpret_cast<const f16x8*>(elds + (k + 1) * 1024); en2 = *reinterpret_cast<const f16x8*>(elds + (TN16_KE + k + 1) * 1024);
+            }
             hook(std::integral_constant<int, s0>{});     TX_PIN();
-            acc[tc_] = TN16_MFMA(cur.a2, b2, acc[tc_]); hook(std::integral_constant<int, s0 + 1>{}); TX_PIN();
-            acc[tc_] = TN16_MFMA(cur.a1, b3, acc[tc_]); hook(std::integral_constant<int, s0 + 2>{}); TX_PIN();
-            acc[tc_] = TN16_MFMA(cur.a2, b1, acc[tc_]); hook(std::integral_constant<int, s0 + 3>{});
+            acc[ta + NH] = TX_MFMA(cur.a1, b2, acc[ta + NH]); hook(std::integral_constant<int, s0 + 1>{});
             {   // this group's share of the pending stage's DMA pieces
                 constexpr int GPS = RPS * NTU, PPS = (DPW + GPS - 2) / (GPS - 1), g = (k % RPS) * NTU + tl;
                 tn_static_for<PPS>([&](auto uc) TN_INLINE_LAMBDA {
@@ -202,12 +228,12 @@ __device__ __forceinline__ void tx_pass(PipeX& p, const unsigned char* lds, cons
                 });
             }
             TX_PIN();
-            acc[tc_] = TN16_MFMA(cur.a1, b2, acc[tc_]); hook(std::integral_constant<int, s0 + 4>{}); TX_PIN();
-            if constexpr (TX_SPLIT_ACC && ZERO && ks == 0) { const f32x16 z = {}; acc[ta] = TN16_MFMA(cur.a1, b1, z); }
-            else                                            acc[ta] = TN16_MFMA(cur.a1, b1, acc[ta]);
-            hook(std::integral_constant<int, s0 + 5>{}); TX_PIN();
+            if constexpr (ZERO && ks == 0) { const f32x16 z = {}; acc[ta] = TX_MFMA(cur.a1, b1, z); }
+            else                          acc[ta] = TX_MFMA(cur.a1, b1, acc[ta]);
+            hook(std::integral_constant<int, s0 + 2>{}); TX_PIN();
             if constexpr (more_tile || more_rec || early) cur = nxt;
         });
+        if constexpr (KIND == 0 && k + 1 < NK) { e1 = en1; e2 = en2; }
     });
 }
 
@@ -222,11 +248,10 @@ __device__ __forceinline__ void tx_pass_headsT(PipeX& p, const unsigned char* ld
     tn_static_for<2 * NH>([&](auto tc) TN_INLINE_LAMBDA {
         constexpr int t = decltype(tc)::value;
         const FragX f = tx_frag_load(base, t);                                    // record B follows record A: slot t = half * NH + tl
-        f32x16 a = TN16_MFMA(f.a3, Z.p1[0], z);
-        a = TN16_MFMA(f.a2, Z.p2[0], a); a = TN16_MFMA(f.a1, Z.p3[0], a);
-        a = TN16_MFMA(f.a2, Z.p1[0], a); a = TN16_MFMA(f.a1, Z.p2[0], a); a = TN16_MFMA(f.a1, Z.p1[0], a);
-        if constexpr (t < NH) accA[t] = a; else accB[t - NH] = a;
-        if constexpr (TX_SPLIT_ACC) { if constexpr (t < NH) accA[t + NH] = z; else accB[t] = z; }
+        f32x16 c = TX_MFMA(f.a2, TX_H8(Z.p1[0]), z);
+        c = TX_MFMA(f.a1, TX_H8(Z.p2[0]), c);
+        const f32x16 m = TX_MFMA(f.a1, TX_H8(Z.p1[0]), z);
+        if constexpr (t < NH) { accA[t] = m; accA[t + NH] = c; } else { accB[t - NH] = m; accB[t] = c; }
     });
 }
 
@@ -242,46 +267,35 @@ template <int HID, int HALF, int I> struct TxPair {
     static constexpr int xs = 2 * t + pr / 4, xq = pr % 4;            // activation k-step and dword the pair lands in
     static constexpr int row0 = 32 * t + (r0 & 3) + 8 * (r0 >> 2), row1 = 32 * t + (r1 & 3) + 8 * (r1 >> 2);   // feature rows (+ 4h) of the stash
 };
-struct TxEpi { float v0[4], v1[4], r0[4], r1[4], s0[4], s1[4]; f32x2 b[4]; uint32_t msk; };      // up to 4 pairs in flight
+// Per-sample scalars of the epilogue that is running: dsc = 2^-(s + t_in) turns the accumulator sum into the layer's output,
+// osc = 2^t_out scales that output into the fp16 range for the split; l1 sums |output| (the next bound).
+struct TxScale { float dsc, osc, l1; };
+struct TxEpi { float v0[4], v1[4]; unsigned p1[4]; f32x2 b[4]; uint32_t msk; };      // up to 4 pairs in flight
 
-// steps 3..5 of any epilogue: the exact split of the pair into the activation registers
-template <int HID, int HALF, int I, int J>
+// step 2 of any epilogue: the second piece, and both into the activation registers
+template <int HID, int HALF, int I>
 __device__ __forceinline__ void tx_epi_split(ActX<HID>& X, TxEpi& e) {
     using P = TxPair<HID, HALF, I>;
     constexpr int u = I % 4;
-    if constexpr (J == 3) {
-        e.r0[u] = e.v0[u] - __uint_as_float(__float_as_uint(e.v0[u]) & 0xFFFF0000u);
-        e.r1[u] = e.v1[u] - __uint_as_float(__float_as_uint(e.v1[u]) & 0xFFFF0000u);
-    } else if constexpr (J == 4) {
-        e.s0[u] = e.r0[u] - __uint_as_float(__float_as_uint(e.r0[u]) & 0xFFFF0000u);
-        e.s1[u] = e.r1[u] - __uint_as_float(__float_as_uint(e.r1[u]) & 0xFFFF0000u);
-    } else if constexpr (J == 5) {
-        X.p1[P::xs][P::xq] = __builtin_amdgcn_perm(__float_as_uint(e.v1[u]), __float_as_uint(e.v0[u]), 0x07060302u);
-        X.p2[P::xs][P::xq] = __builtin_amdgcn_perm(__float_as_uint(e.r1[u]), __float_as_uint(e.r0[u]), 0x07060302u);
-        X.p3[P::xs][P::xq] = __builtin_amdgcn_perm(__float_as_uint(e.s1[u]), __float_as_uint(e.s0[u]), 0x07060302u);
-    }
+    X.p1[P::xs][P::xq] = e.p1[u];
+    X.p2[P::xs][P::xq] = tx_cvt2(e.v0[u] - tx_lo2f(e.p1[u]), e.v1[u] - tx_hi2f(e.p1[u]));
 }
 
-// Forward: bias (fp32, LDS byte offset vb + 16 h: this layer's biases for rows 4h..), ReLU, [training: fp32 value to the stash,
-// sign bit], split.  The bias pair is READ one micro-step before it is used (step 0 of the pair; step 1 adds), so that the
-// compiler's lgkmcnt wait lands a whole MFMA later.
+// Forward: descale, bias (fp32, LDS byte offset vb + 16 h: this layer's biases for rows 4h..), ReLU, [training: fp32 value to the
+// stash, sign bit], L1 norm, scale, split.  The bias pair is READ one group before it is used, so that the compiler's lgkmcnt
+// wait lands a whole group later.
 // srow: per-lane stash pointer of the layer's activation rows (row 4h, this sample); mword: per-lane pointer of its sign words.
 template <int HID, int HALF, int I, int J, bool TRAIN, int PPG>
-__device__ __forceinline__ void tx_epi_fwd(const f32x16 (&acc)[TX_ACCN(HID)], ActX<HID>& X, TxEpi& e, const unsigned char* lds, uint32_t vb,
+__device__ __forceinline__ void tx_epi_fwd(const f32x16 (&acc)[TX_ACCN(HID)], ActX<HID>& X, TxEpi& e, TxScale& sc, const unsigned char* lds, uint32_t vb,
                                            float* __restrict__ srow, uint32_t* __restrict__ mword) {
     using P = TxPair<HID, HALF, I>;
     constexpr int u = I % 4;
     // PPG: pairs per MFMA group of the window this runs in; pair I + PPG is the one that takes this register slot next
     if constexpr (J == 0) {
         if constexpr (I < PPG) e.b[u] = *reinterpret_cast<const f32x2*>(lds + vb + P::row0 * 4);      // the window's first group
-        e.v0[u] = acc[P::tl][P::r0]; e.v1[u] = acc[P::tl][P::r1];
-        if constexpr (TX_SPLIT_ACC) { e.v0[u] += acc[P::tl + P::NH][P::r0]; e.v1[u] += acc[P::tl + P::NH][P::r1]; }
+        e.v0[u] = fmaxf(__builtin_fmaf(acc[P::tl][P::r0] + acc[P::tl + P::NH][P::r0], sc.dsc, e.b[u][0]), 0.0f);
+        e.v1[u] = fmaxf(__builtin_fmaf(acc[P::tl][P::r1] + acc[P::tl + P::NH][P::r1], sc.dsc, e.b[u][1]), 0.0f);
     } else if constexpr (J == 1) {
-        e.v0[u] = fmaxf(e.v0[u] + e.b[u][0], 0.0f); e.v1[u] = fmaxf(e.v1[u] + e.b[u][1], 0.0f);
-    } else if constexpr (J == 5 && I + PPG < P::NH * 8) {          // (also runs the split's step 5 below)
-        e.b[(I + PPG) % 4] = *reinterpret_cast<const f32x2*>(lds + vb + TxPair<HID, HALF, I + PPG>::row0 * 4);
-        tx_epi_split<HID, HALF, I, J>(X, e);
-    } else if constexpr (J == 2) {
         if constexpr (TRAIN) {
             TN_STASH_STORE(&srow[P::row0 * 32], e.v0[u]); TN_STASH_STORE(&srow[P::row1 * 32], e.v1[u]);
             if constexpr (I % 16 == 0) e.msk = 0u;
@@ -289,27 +303,34 @@ __device__ __forceinline__ void tx_epi_fwd(const f32x16 (&acc)[TX_ACCN(HID)], Ac
             e.msk = __builtin_amdgcn_alignbit(e.msk, __float_as_uint(e.v0[u]) + 0x7FFFFFFFu, 31);
             if constexpr (I % 16 == 15) mword[P::t / 2] = e.msk;
         }
-    } else tx_epi_split<HID, HALF, I, J>(X, e);
+        sc.l1 += e.v0[u] + e.v1[u];
+        e.v0[u] *= sc.osc; e.v1[u] *= sc.osc;
+        e.p1[u] = tx_cvt2(e.v0[u], e.v1[u]);
+    } else {
+        if constexpr (I + PPG < P::NH * 8) e.b[(I + PPG) % 4] = *reinterpret_cast<const f32x2*>(lds + vb + TxPair<HID, HALF, I + PPG>::row0 * 4);
+        tx_epi_split<HID, HALF, I>(X, e);
+    }
 }
 
-// Backward: ReLU backward with the forward's sign bits (mw: the words of the layer this activation gradient belongs to),
-// dZ to the stash, split.
+// Backward: descale, ReLU backward with the forward's sign bits (mw: the words of the layer this activation gradient belongs
+// to), dZ to the stash, L1 norm, scale, split.
 template <int HID, int HALF, int I, int J>
-__device__ __forceinline__ void tx_epi_bwd(const f32x16 (&acc)[TX_ACCN(HID)], ActX<HID>& X, TxEpi& e, const uint32_t (&mw)[HID / 64], float* __restrict__ zrow) {
+__device__ __forceinline__ void tx_epi_bwd(const f32x16 (&acc)[TX_ACCN(HID)], ActX<HID>& X, TxEpi& e, TxScale& sc, const uint32_t (&mw)[HID / 64], float* __restrict__ zrow) {
     using P = TxPair<HID, HALF, I>;
     constexpr int u = I % 4;
     if constexpr (J == 0) {
-        e.v0[u] = acc[P::tl][P::r0]; e.v1[u] = acc[P::tl][P::r1];
-        if constexpr (TX_SPLIT_ACC) { e.v0[u] += acc[P::tl + P::NH][P::r0]; e.v1[u] += acc[P::tl + P::NH][P::r1]; }
+        const float a0 = (acc[P::tl][P::r0] + acc[P::tl + P::NH][P::r0]) * sc.dsc, a1 = (acc[P::tl][P::r1] + acc[P::tl + P::NH][P::r1]) * sc.dsc;
+        e.v0[u] = __int_as_float(__float_as_int(a0) & __builtin_amdgcn_sbfe((int)mw[P::t / 2], (P::t & 1) * 16 + P::r0, 1));
+        e.v1[u] = __int_as_float(__float_as_int(a1) & __builtin_amdgcn_sbfe((int)mw[P::t / 2], (P::t & 1) * 16 + P::r1, 1));
     } else if constexpr (J == 1) {
-        e.v0[u] = __int_as_float(__float_as_int(e.v0[u]) & __builtin_amdgcn_sbfe((int)mw[P::t / 2], (P::t & 1) * 16 + P::r0, 1));
-        e.v1[u] = __int_as_float(__float_as_int(e.v1[u]) & __builtin_amdgcn_sbfe((int)mw[P::t / 2], (P::t & 1) * 16 + P::r1, 1));
-    } else if constexpr (J == 2) {
         TN_STASH_STORE(&zrow[P::row0 * 32], e.v0[u]); TN_STASH_STORE(&zrow[P::row1 * 32], e.v1[u]);
-    } else tx_epi_split<HID, HALF, I, J>(X, e);
+        sc.l1 += fabsf(e.v0[u]) + fabsf(e.v1[u]);
+        e.v0[u] *= sc.osc; e.v1[u] *= sc.osc;
+        e.p1[u] = tx_cvt2(e.v0[u], e.v1[u]);
+    } else tx_epi_split<HID, HALF, I>(X, e);
 }
 
-// The slots [W0, W0 + 6 G) of a pass as an epilogue window: group g = (slot - W0) / 6 carries micro-step (slot - W0) % 6 of the
+// The slots [W0, W0 + 3 G) of a pass as an epilogue window: group g = (slot - W0) / 3 carries micro-step (slot - W0) % 3 of the
 // pairs g*PPG .. g*PPG + PPG - 1 (PPG = ceil(NP / G) <= 4).  f(integral_constant<I>, integral_constant<J>, integral_constant<PPG>).
 template <int W0, int G, int NP, typename F>
 __device__ __forceinline__ auto tx_window(F&& f) {
@@ -317,8 +338,8 @@ __device__ __forceinline__ auto tx_window(F&& f) {
         constexpr int s = decltype(sc)::value;
         constexpr int PPG = (NP + G - 1) / G;
         static_assert(PPG <= 4, "epilogue window too short");
-        if constexpr (s >= W0 && s < W0 + 6 * G) {
-            constexpr int g = (s - W0) / 6, j = (s - W0) % 6;
+        if constexpr (s >= W0 && s < W0 + TX_SPG * G) {
+            constexpr int g = (s - W0) / TX_SPG, j = (s - W0) % TX_SPG;
             tn_static_for<PPG>([&](auto uc) TN_INLINE_LAMBDA {
                 constexpr int i = g * PPG + decltype(uc)::value;
                 if constexpr (i < NP) f(std::integral_constant<int, i>{}, std::integral_constant<int, j>{}, std::integral_constant<int, PPG>{});
@@ -326,7 +347,7 @@ __device__ __forceinline__ auto tx_window(F&& f) {
         }
     };
 }
-// A whole epilogue with nothing to hide behind.  NJ = 6: all micro-steps; 3: without the split (nothing consumes the pieces).
+// A whole epilogue with nothing to hide behind.  NJ = 3: all micro-steps; 2: without the second piece (nothing consumes the pieces).
 template <int NP, int NJ, typename F>
 __device__ __forceinline__ void tx_drain(F&& f) {
     tn_static_for<NP>([&](auto ic) TN_INLINE_LAMBDA {
@@ -334,38 +355,59 @@ __device__ __forceinline__ void tx_drain(F&& f) {
     });
 }
 
-// PositionalEncoding(L, include_input=True) of one point, fp32-accurate (tn_sincos, as the fp32 kernels), in the slot map of
-// the input k-steps (tnerf_internal.h), split into three pieces.                         reference src/encoding.py:27-33
-// `out(st, value)`: the fp32 value of input step st = 8u + e (the step numbering of the fp32 path's pairing: the training stash).
-template <typename Out>
-__device__ __forceinline__ void tx_encode(float px, float py, float pz, int Lf, int h, EncX& E, Out&& out) {
+// The network input of one sample as the B operand of the input k-steps (slot map: tnerf_internal.h), scaled by `esc` and split.
+// value(integral_constant<a>) is the fp32 value of input step a = 8u + e (the step numbering of the fp32 path's pairing: the
+// training stash).
+template <typename Val>
+__device__ __forceinline__ void tx_split_input(EncX& E, float esc, Val&& value) {
     tn_static_for<TN16_KE>([&](auto uc) TN_INLINE_LAMBDA {
         constexpr int u = decltype(uc)::value;
-        float v[8];
-        tn_static_for<8>([&](auto ec) TN_INLINE_LAMBDA {
-            constexpr int e = decltype(ec)::value;
-            constexpr int a = 8 * u + e, k = a / 3, c = a % 3;
-            const float pc = c == 0 ? px : (c == 1 ? py : pz);
-            float r = 0.0f;
-            if (a < 3 * Lf) {
-                float sn, cs;
-                tn_sincos(pc * (float)(1u << (k < 31 ? k : 0)), sn, cs);
-                r = h ? cs : sn;
-            } else if (a == 3 * Lf) {
-                r = h ? py : px;
-            } else if (a == 3 * Lf + 1) {
-                r = h ? 0.0f : pz;
-            }
-            v[e] = r;
-            out(std::integral_constant<int, a>{}, r);
+        u32x4 w1, w2;
+        tn_static_for<4>([&](auto qc) TN_INLINE_LAMBDA {
+            constexpr int q = decltype(qc)::value;
+            unsigned a_, b_;
+            tx_split2(value(std::integral_constant<int, 8 * u + 2 * q>{}) * esc, value(std::integral_constant<int, 8 * u + 2 * q + 1>{}) * esc, a_, b_);
+            w1[q] = a_; w2[q] = b_;
         });
-        u32x4 w1, w2, w3;
+        E.p1[u] = w1; E.p2[u] = w2;
+    });
+}
+// The input pieces to / in this lane's LDS slots (only this lane ever touches them: no barrier).
+__device__ __forceinline__ void tx_store_input(unsigned char* elds, const EncX& E) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            unsigned a_, b_, c_;
-            tx_split2(v[2 * q], v[2 * q + 1], a_, b_, c_);
-            w1[q] = a_; w2[q] = b_; w3[q] = c_;
+    for (int u = 0; u < TN16_KE; ++u) {
+        *reinterpret_cast<u32x4*>(elds + u * 1024) = E.p1[u];
+        *reinterpret_cast<u32x4*>(elds + (TN16_KE + u) * 1024) = E.p2[u];
+    }
+}
+// ... scaled by 2^d (d <= 0) in place, as two fp16 factors so that neither is subnormal
+__device__ __forceinline__ void tx_rescale_input(unsigned char* elds, int d) {
+    const int d1 = max(d, -14), d2 = max(d - d1, -14);
+    const _Float16 f1 = (_Float16)tx_exp2i(d1), f2 = (_Float16)tx_exp2i(d2);
+    const f16x8 m1 = {f1, f1, f1, f1, f1, f1, f1, f1}, m2 = {f2, f2, f2, f2, f2, f2, f2, f2};
+#pragma unroll
+    for (int i = 0; i < TX_NP * TN16_KE; ++i) {
+        f16x8* q = reinterpret_cast<f16x8*>(elds + i * 1024);
+        *q = (*q * m1) * m2;
+    }
+}
+
+// PositionalEncoding(L, include_input=True) of one point, fp32-accurate (tn_sincos, as the fp32 kernels), in the step numbering
+// of the training stash: encf[a], a = 8u + e.                                                reference src/encoding.py:27-33
+__device__ __forceinline__ void tx_encode(float px, float py, float pz, int Lf, int h, float (&encf)[8 * TN16_KE]) {
+    tn_static_for<8 * TN16_KE>([&](auto ac) TN_INLINE_LAMBDA {
+        constexpr int a = decltype(ac)::value, k = a / 3, c = a % 3;
+        const float pc = c == 0 ? px : (c == 1 ? py : pz);
+        float r = 0.0f;
+        if (a < 3 * Lf) {
+            float sn, cs;
+            tn_sincos(pc * (float)(1u << (k < 31 ? k : 0)), sn, cs);
+            r = h ? cs : sn;
+        } else if (a == 3 * Lf) {
+            r = h ? py : px;
+        } else if (a == 3 * Lf + 1) {
+            r = h ? 0.0f : pz;
         }
-        E.p1[u] = __builtin_bit_cast(bf16x8, w1); E.p2[u] = __builtin_bit_cast(bf16x8, w2); E.p3[u] = __builtin_bit_cast(bf16x8, w3);
+        encf[a] = r;
     });
 }

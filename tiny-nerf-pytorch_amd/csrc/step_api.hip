@@ -26,8 +26,9 @@ static int check_step_args(const tnerf_step_args* a) {
     }
     if (p2 && (!a->slabs || !a->reduce_table || !a->grads)) { tn_set_error("tnerf_train_step_dataset: reduce phase needs slabs, reduce_table, grads"); return TNERF_EINVAL; }
     if (p3 && (!a->grads || !a->params || !a->exp_avg || !a->exp_avg_sq || !a->step || !(a->lr >= 0.0f) ||
-               (a->scatter_table && (a->scatter_width < 1 || !a->packed)))) {
-        tn_set_error("tnerf_train_step_dataset: update phase needs grads, params, exp_avg, exp_avg_sq, step (and packed with a scatter table)"); return TNERF_EINVAL; }
+               (a->scatter_table && (a->scatter_width < 1 || !a->packed)) ||
+               (a->precision == 0 && a->packed_x3 && a->scatter_x3 && !a->pack_x3))) {
+        tn_set_error("tnerf_train_step_dataset: update phase needs grads, params, exp_avg, exp_avg_sq, step (packed with a scatter table; pack_x3 with scatter_x3)"); return TNERF_EINVAL; }
     return TNERF_OK;
 }
 
@@ -71,10 +72,13 @@ extern "C" int tnerf_train_step_dataset(const tnerf_step_args* a, tnerf_stream_t
         if (a->precision == 0 && a->packed_x3 && a->scatter_x3) {
             NetX3 n; if ((rc = tn_build_netx3(&a->desc, &n))) return rc;
             f.scatter3 = a->scatter_x3; f.width3 = a->scatter_x3_width; f.packed3 = const_cast<void*>(a->packed_x3);
-            f.x3_elems = (int64_t)(n.n_rec + n.n_bw_rec) * n.rec_frags * 512; f.x3_bias_off_bytes = n.bias_off;
+            f.x3_elems = (int64_t)(n.n_rec + n.n_bw_rec) * n.rec_frags * 512; f.n3 = n;
         }
     }
-    return tn_launch_finish(f, stream);
+    if ((rc = tn_launch_finish(f, stream))) return rc;
+    // the finishing kernel re-scattered every weight into the x3 stream: publish the scale it used and refresh the layers' maxima
+    if (f.scatter3) return tnx3_launch_stats(f.n3, a->params, a->pack_x3, f.packed3, 1, stream);
+    return TNERF_OK;
 }
 
 // ------------------------------------------------------------------------------------------- hipGraph

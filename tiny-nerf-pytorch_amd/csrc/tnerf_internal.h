@@ -77,30 +77,49 @@ struct Net16 {
 #define TN16_STASH_MASK_BYTES(n, tiles) ((int64_t)(n).depth * ((tiles) + 1) * 64 * ((n).hidden / 64) * 4)
 #define TN16_STASH_OUT_BYTES(n, tiles)  ((int64_t)((tiles) + 1) * 32 * 16)
 
-// "x3" chain kernels (mlpx3.hip): the fp32 MLP chain on the bf16 matrix pipe with exact three-way operand splitting
-// (DESIGN.md §13/§14).  The weights are a STREAM of k-step RECORDS in the order a wavefront consumes them.  A layer is walked
+// "x3" chain kernels (mlpx3.hip): the fp32 MLP chain on the fp16 matrix pipe ("three partial products").  Every
+// fp32 operand is carried as TWO fp16 pieces of its power-of-two-scaled value (round to nearest: x 2^s = p1 + p2 up to 2^-22
+// relative), a product is the three partial products p1 q1 (-> main accumulator), p1 q2 + p2 q1 (-> correction accumulator),
+// both accumulators fp32.  The weights are a STREAM of k-step RECORDS in the order a wavefront consumes them.  A layer is walked
 // as two HALF-PASSES (output tiles 0..NT/2-1, then NT/2..NT-1: the epilogue of one half hides behind the MFMAs of the other);
-// a record holds, for every tile slot tl of ONE half, the three bf16 pieces W1, W2, W3 (W = W1 + W2 + W3 exactly) of the A
-// fragment of (n-tile half*NT/2 + tl, this k-step):
-//   record = [tl = 0 .. NT/2-1][piece 0..2] x 1 KB,   fragment = lane (row l&31, half l>>5) x 8 bf16 (k-slots 8 (l>>5) + e)
+// a record holds, for every tile slot tl of ONE half, the two fp16 pieces of the A fragment of (n-tile half*NT/2 + tl, this k-step):
+//   record = [tl = 0 .. NT/2-1][piece 0..1] x 1 KB,   fragment = lane (row l&31, half l>>5) x 8 fp16 (k-slots 8 (l>>5) + e)
 // Forward order: layer 0: half A: TN16_KE input k-steps, half B: the same; layer l >= 1: per half hidden/16 hidden k-steps
 // (+ TN16_KE input k-steps for the skip layer); heads: ONE output tile (rows r,g,b,sigma), so the NT/2 slots of a record carry
 // NT/2 consecutive k-steps of it: hidden/16 / (NT/2) records.  k-slot <-> feature maps as in the bf16 mode (above).  Records are cut into stages of
-// TX_STAGE fragments (24 KB: two records of a 256-wide net, four of a 128-wide one) for the LDS ring.  After the stream: the
-// fp32 biases as in the bf16 mode.
-#define TX_STAGE 24
+// TX_STAGE fragments (16 KB: two records of a 256-wide net, four of a 128-wide one) for the LDS ring.  After the stream: the
+// fp32 biases as in the bf16 mode, then TX_META floats per layer (index depth = the heads):
+//   [0] 2^-s   : what the layer's pieces in the stream must be multiplied by to give the weights (the scale IN EFFECT)
+//   [1] max|W| , [2] max|b| of the layer as of the last k_x3stats (the chain kernels bound their activations with them)
+//   [3] 2^s'   : the scale the NEXT (re)pack of the layer uses, chosen from [1] so that max|W| 2^s' is in (2^11, 2^12]
+#define TX_STAGE 16
+#define TX_NP 2
+#define TX_META 4
 struct NetX3 {
     int32_t in_dim, hidden, depth, skip_at, Lf;
     int32_t NT, KH;               // n-tiles (hidden/32), hidden k-steps (hidden/16)
-    int32_t rec_frags;            // NT / 2 * 3
+    int32_t rec_frags;            // NT / 2 * TX_NP
     int32_t n_rec, n_stage;       // forward stream, per pass
     int32_t n_bw_rec, n_bw_stage; // backward (dgrad) stream, per pass: starts at byte n_rec * rec_frags * 1024
     int32_t bias_off, n_bias;     // byte offset / count of the fp32 biases (depth*hidden + 4)
+    int32_t meta_off;             // byte offset of the (depth + 1) * TX_META scale floats (= bias_off + 4 n_bias: contiguous with the biases)
+    int32_t fw_rec0[TN_MAXD + 2]; // first forward record of layer l; [depth] = heads; [depth + 1] = n_rec
     int64_t packed_bytes, pack_entries;     // pack_entries = (n_rec + n_bw_rec) * rec_frags * 512 + n_bias
 };
 // Backward stream: heads^T (two records, half A and half B: fragment row 32t+i <-> feature, k-slot (h=0, e<4) <-> head row
 // e = r,g,b,sigma; padded to a whole stage), then for l = depth-1 .. 1 the hidden part of W_l transposed: per half hidden/16
 // records, fragment row 32t+i <-> input feature, k-slot (s,h,e) <-> output feature.
+// Layer of a stream record (forward or backward numbering continued behind n_rec); depth = heads.
+#ifdef __HIPCC__
+#define TN_HD __host__ __device__
+#else
+#define TN_HD
+#endif
+TN_HD static inline int tx_record_layer(const NetX3* n, int rec) {
+    if (rec < n->n_rec) { int l = 0; while (rec >= n->fw_rec0[l + 1]) ++l; return l; }
+    const int r = rec - n->n_rec, rps = TX_STAGE / n->rec_frags;
+    return r < rps ? n->depth : n->depth - 1 - (r - rps) / (2 * n->KH);
+}
 
 #ifdef __cplusplus
 extern "C" {

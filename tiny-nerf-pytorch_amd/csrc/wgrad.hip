@@ -616,17 +616,19 @@ __global__ __launch_bounds__(256) void k_finish(FinishArgs f) {
                 }
             }
         }
-        if (f.scatter3) {                                          // the x3 record stream: three exact bf16 pieces (as k_packx3)
-            const float r_ = pn - __uint_as_float(__float_as_uint(pn) & 0xFFFF0000u);
-            const float t_ = r_ - __uint_as_float(__float_as_uint(r_) & 0xFFFF0000u);
+        if (f.scatter3) {                                          // the x3 record stream: two scaled fp16 pieces (as k_packx3)
+            const int32_t d0 = f.scatter3[i * f.width3];
+            float wsc = 1.0f;
+            if (d0 >= 0 && d0 < f.x3_elems)                        // every position of a weight lies in the same layer
+                wsc = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(f.packed3) + f.n3.meta_off)
+                          [tx_record_layer(&f.n3, (int)(d0 / (f.n3.rec_frags * 512))) * TX_META + 3];
             for (int k = 0; k < f.width3; ++k) {
                 const int32_t d = f.scatter3[i * f.width3 + k];
                 if (d < 0) break;
                 if (d < f.x3_elems) {
-                    const int piece = (d >> 9) % 3;
-                    reinterpret_cast<unsigned short*>(f.packed3)[d] = (unsigned short)(__float_as_uint(piece == 0 ? pn : (piece == 1 ? r_ : t_)) >> 16);
+                    reinterpret_cast<unsigned short*>(f.packed3)[d] = tx_piece_bits(pn, wsc, (d >> 9) % TX_NP);
                 } else {
-                    reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(f.packed3) + f.x3_bias_off_bytes)[d - f.x3_elems] = pn;
+                    reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(f.packed3) + f.n3.bias_off)[d - f.x3_elems] = pn;
                 }
             }
         }

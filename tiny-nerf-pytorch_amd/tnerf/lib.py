@@ -49,7 +49,8 @@ class StepArgs(C.Structure):
                 ("params", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
                 ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
                 ("scatter_table", C.c_void_p), ("scatter_width", C.c_int32),
-                ("packed_x3", C.c_void_p), ("scatter_x3", C.c_void_p), ("scatter_x3_width", C.c_int32)]
+                ("packed_x3", C.c_void_p), ("scatter_x3", C.c_void_p), ("scatter_x3_width", C.c_int32),
+                ("pack_x3", C.c_void_p)]
 
 
 PHASE_GRADIENT, PHASE_REDUCE, PHASE_UPDATE = 1, 2, 4

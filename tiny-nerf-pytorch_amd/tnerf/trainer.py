@@ -273,7 +273,7 @@ class DatasetTrainer:
             tab = st.pack_table.cpu().numpy()
             if st.x3_capable and not (st.desc.flags & _l.FLAG_FP32_MFMA):    # forward on the x3 chain kernel; the finishing kernel keeps its stream current
                 x3 = st.repack_x3(tuple(p._version for p in model._param_list()))
-                self._x3_packed = x3.packed
+                self._x3_packed, self._x3_table = x3.packed, x3.table
                 self._x3_scatter = torch.from_numpy(_scatter_table(x3.table.cpu().numpy(), st.n_params)).to(dev)
         else:
             b = st.repack_bf16(tuple(p._version for p in model._param_list()))
@@ -306,6 +306,7 @@ class DatasetTrainer:
         a.scatter_table, a.scatter_width = self._scatter.data_ptr(), int(self._scatter.shape[1])
         if self._x3_packed is not None:
             a.packed_x3, a.scatter_x3, a.scatter_x3_width = self._x3_packed.data_ptr(), self._x3_scatter.data_ptr(), int(self._x3_scatter.shape[1])
+            a.pack_x3 = self._x3_table.data_ptr()
         return a
 
     def _hyper_key(self):
