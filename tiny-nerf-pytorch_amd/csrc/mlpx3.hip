@@ -11,13 +11,16 @@
 // Diagnostic builds (-DTN_STAMPS, tools/x3_stamp_probe.py): cycles a wave spends in the layer walks and in the epilogues, and the
 // shader clock (s_memtime / s_memrealtime).  The values go to a.f.stamps only; the product build has none of this.
 #ifdef TN_STAMPS
-struct TxProf { unsigned long long walk = 0, epi = 0, t = 0; };
+struct TxProf { unsigned long long walk = 0, epi = 0, t = 0; unsigned long long* marks = nullptr; int n = 0; };
 #define TX_PROF_BEGIN(pf) (pf).t = __builtin_amdgcn_s_memtime()
 #define TX_PROF_ADD(pf, field) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); (pf).field += n_ - (pf).t; (pf).t = n_; } while (0)
+// a time stamp per pass of the FIRST tile of workgroup 0 / wave 0 (marks != nullptr there only)
+#define TX_PROF_MARK(pf) do { if ((pf).marks && (pf).n < 60) { (pf).marks[(pf).n++] = __builtin_amdgcn_s_memtime(); } } while (0)
 #else
 struct TxProf {};
 #define TX_PROF_BEGIN(pf) do {} while (0)
 #define TX_PROF_ADD(pf, field) do {} while (0)
+#define TX_PROF_MARK(pf) do {} while (0)
 #endif
 
 struct FwdX3Args {
@@ -55,7 +58,7 @@ __device__ __forceinline__ void tx_mlp_tile(PipeX& p, const unsigned char* lds, 
     ActX<HID> X;
     f32x16 accA[TX_ACCN(HID)], accB[TX_ACCN(HID)];
     TxEpi es;
-    TxScale sc{0.0f, 0.0f, 0.0f};
+    TxScale sc{0.0f, 0.0f, {0.0f, 0.0f}};
     int t_prev = in.te;                                            // exponent of the scale of the pieces the running passes consume
     // per-lane stash pointers of the layer whose epilogue is running (training)
     float* __restrict__ srow = nullptr; uint32_t* __restrict__ mword = nullptr;
@@ -66,33 +69,57 @@ __device__ __forceinline__ void tx_mlp_tile(PipeX& p, const unsigned char* lds, 
         vbe = vb0 + l * HID * 4;
         if constexpr (TRAIN) { srow = pl + L.h_row0[l] * 32; mword = mrow + (int64_t)l * (Mp + 32) * NT; }
         const f32x4 mt = tx_meta(lds, a.n, l);                     // {2^-s, max|W|, max|b|}
-        float l1_in = l == 0 ? in.l1 : sc.l1 + tx_partner(sc.l1);
+        const float l1_own = sc.l1[0] + sc.l1[1];
+        float l1_in = l == 0 ? in.l1 : l1_own + tx_partner(l1_own);
         if (l > 0 && l == skip_at) l1_in += in.l1;
         float bound = __builtin_fmaf(mt[1], l1_in, mt[2]);
         if (l + 1 == skip_at) bound = fmaxf(bound, in.encmax);     // the skip layer's input pieces share this layer's output scale
         const int t_out = tx_scale_exp(bound);
-        sc.dsc = mt[0] * tx_exp2i(-t_prev); sc.osc = tx_exp2i(t_out); sc.l1 = 0.0f;
+        sc.dsc = mt[0] * tx_exp2i(-t_prev); sc.osc = tx_exp2i(t_out); sc.l1 = f32x2{0.0f, 0.0f};
         t_prev = t_out;
     };
-    auto epiA = [&](auto ic, auto jc, auto pc) TN_INLINE_LAMBDA { tx_epi_fwd<HID, 0, decltype(ic)::value, decltype(jc)::value, TRAIN, decltype(pc)::value>(accA, X, es, sc, lds, vbe, srow, mword); };
-    auto epiB = [&](auto ic, auto jc, auto pc) TN_INLINE_LAMBDA { tx_epi_fwd<HID, 1, decltype(ic)::value, decltype(jc)::value, TRAIN, decltype(pc)::value>(accB, X, es, sc, lds, vbe, srow, mword); };
+    // steps 0..3 = part V, 4..9 = part S    (mlpx3_core.hpp)
+    auto epi_full = [&](auto halfc, auto& acc, auto ic, auto kc) TN_INLINE_LAMBDA {
+        constexpr int HALF = decltype(halfc)::value, I = decltype(ic)::value, K = decltype(kc)::value;
+        if constexpr (K < TX_VSTEPS) tx_epi_fwd_value<HID, HALF, I, K, false>(acc, es, sc, lds, vbe);
+        else tx_epi_split<HID, HALF, I, K, TRAIN, true, false>(acc, X, es, sc, srow, mword);
+    };
+    auto epiA = [&](auto ic, auto kc) TN_INLINE_LAMBDA { epi_full(std::integral_constant<int, 0>{}, accA, ic, kc); };
+    auto epiB = [&](auto ic, auto kc) TN_INLINE_LAMBDA { epi_full(std::integral_constant<int, 1>{}, accB, ic, kc); };
+    // half A of a hidden layer: part V parked in the first half of pass B, part S from the parked values in the second half
+    auto epiA_value = [&](auto ic, auto kc) TN_INLINE_LAMBDA { tx_epi_fwd_value<HID, 0, decltype(ic)::value, decltype(kc)::value, true>(accA, es, sc, lds, vbe); };
+    auto epiA_split = [&](auto ic, auto kc) TN_INLINE_LAMBDA { tx_epi_split<HID, 0, decltype(ic)::value, decltype(kc)::value, TRAIN, true, true>(accA, X, es, sc, srow, mword); };
+    // 256-wide: one pair per group, the chain pipelined over the gaps (SPS 1); 128-wide: two pairs per group, chains inside the group
+    constexpr int SPF = HID == 256 ? 1 : 4, SPV = HID == 256 ? 1 : 4, SPS_ = HID == 256 ? 1 : 2;
     auto none = [](auto) TN_INLINE_LAMBDA {};
     TX_PROF_BEGIN(pf);
+    TX_PROF_MARK(pf);
     // layer 0: half A bare, half A's epilogue behind half B
     tx_pass<HID, 0, true, NW>(p, lds, X, E, accA, none);
     point_at(0);
-    tx_pass<HID, 0, true, NW>(p, lds, X, E, accB, tx_window<0, TN16_KE * NH, NP>(epiA));
+    TX_PROF_MARK(pf);
+    tx_pass<HID, 0, true, NW>(p, lds, X, E, accB, tx_window<0, TN16_KE * NH, NP, 0, TX_NSTEP, 4>(epiA));
+    TX_PROF_MARK(pf);
     // layer l: half B's epilogue of layer l-1 behind the first half of pass A, half A's of layer l behind the second half of pass B
     for (int l = 1; l < depth; ++l) {
         if (l == skip_at) tx_rescale_input(E, t_prev - in.te);     // the skip layer consumes the input at its own input's scale
-        tx_pass<HID, 1, true, NW>(p, lds, X, E, accA, tx_window<0, G2, NP>(epiB));
+        tx_pass<HID, 1, true, NW>(p, lds, X, E, accA, tx_window<0, G2, NP, 0, TX_NSTEP, SPF>(epiB));
         if (l == skip_at) tx_pass<HID, 0, false, NW>(p, lds, X, E, accA, none);                    // + W_l[:, hidden:] . encoding
+        TX_PROF_MARK(pf);
         point_at(l);
-        tx_pass<HID, 1, true, NW>(p, lds, X, E, accB, tx_window<G2 * TX_SPG, G2, NP>(epiA));
+        {
+            // part S starts one group before the middle: its last pair's last step then ends with the pass, and no pair writes an
+            // activation slot before pass B has read it (slot xs of pair i is read until group 4 xs + 3, written in group >= G2 + i)
+            auto w1 = tx_window<0, G2, NP, 0, TX_VSTEPS, SPV>(epiA_value);
+            auto w2 = tx_window<(G2 - (HID == 256 ? 1 : 0)) * TX_SPG, G2, NP, TX_VSTEPS, TX_NSTEP, SPS_>(epiA_split);
+            tx_pass<HID, 1, true, NW>(p, lds, X, E, accB, [&](auto sc_) TN_INLINE_LAMBDA { w1(sc_); w2(sc_); });
+        }
         if (l == skip_at) tx_pass<HID, 0, false, NW>(p, lds, X, E, accB, none);
+        TX_PROF_MARK(pf);
     }
     // heads (tile slot 0 of accA): the last layer's half B epilogue must be through before k-step KH/2
-    tx_pass<HID, 3, true, NW>(p, lds, X, E, accA, tx_window<0, KH / 2, NP>(epiB));
+    tx_pass<HID, 3, true, NW>(p, lds, X, E, accA, tx_window<0, KH / 2, NP, 0, TX_NSTEP, 4>(epiB));
+    TX_PROF_MARK(pf);
     TX_PROF_ADD(pf, walk);
     // heads: rows 0..2 = rgb.0 (sigmoid), row 3 = sigma.0 (ReLU)                                   nerf.py:39-40
     const f32x4 hb = *reinterpret_cast<const f32x4*>(lds + TX_RING + depth * HID * 4);
@@ -118,6 +145,7 @@ __global__ __launch_bounds__((TxCfg<HID, TRAIN>::NW * 64), 1) void k_renderx3(Fw
     TxProf pf;
 #ifdef TN_STAMPS
     const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+    if (a.f.stamps && blockIdx.x == 0 && wave == 0) pf.marks = a.f.stamps + (size_t)gridDim.x * NW * 8;      // behind the per-wave records
 #endif
 
     // Every wave of the workgroup runs the same number of network passes (the stage barriers are workgroup-wide): rays beyond
@@ -195,6 +223,7 @@ __global__ __launch_bounds__((TxCfg<HID, TRAIN>::NW * 64), 1) void k_renderx3(Fw
     if (a.f.stamps && lane == 0) {
         unsigned long long* o = a.f.stamps + (blockIdx.x * NW + wave) * 8;
         o[0] = __builtin_amdgcn_s_memtime() - st_c0; o[1] = __builtin_amdgcn_s_memrealtime() - st_r0; o[2] = pf.walk; o[3] = pf.epi;
+        if (pf.marks) pf.marks[63] = pf.n;
     }
 #endif
 }
@@ -259,18 +288,27 @@ __device__ __forceinline__ void tx_bwd_tile(PipeX& p, const unsigned char* lds, 
     f32x16 accA[TX_ACCN(HID)], accB[TX_ACCN(HID)];
     uint32_t mw[NT / 2];
     TxEpi es;
-    TxScale sc{0.0f, 0.0f, 0.0f};
+    TxScale sc{0.0f, 0.0f, {0.0f, 0.0f}};
     TxMask<NT / 2> mk;                                             // asm load + counted wait (above)
     float* __restrict__ zrow = nullptr;
     // The product W_l^T dZ_l (l = depth: the heads) is about to enter its epilogues: the L1 norm of dZ_l is complete.
     auto scale_for = [&](int l, float l1_in) TN_INLINE_LAMBDA {
         const f32x4 mt = tx_meta(lds, a.n, l);
         const int t_out = tx_scale_exp(mt[1] * l1_in);
-        sc.dsc = mt[0] * tx_exp2i(-t_prev); sc.osc = tx_exp2i(t_out); sc.l1 = 0.0f;
+        sc.dsc = mt[0] * tx_exp2i(-t_prev); sc.osc = tx_exp2i(t_out); sc.l1 = f32x2{0.0f, 0.0f};
         t_prev = t_out;
     };
-    auto epiA = [&](auto ic, auto jc, auto) TN_INLINE_LAMBDA { tx_epi_bwd<HID, 0, decltype(ic)::value, decltype(jc)::value>(accA, X, es, sc, mw, zrow); };
-    auto epiB = [&](auto ic, auto jc, auto) TN_INLINE_LAMBDA { tx_epi_bwd<HID, 1, decltype(ic)::value, decltype(jc)::value>(accB, X, es, sc, mw, zrow); };
+    // steps 0..3 = part V, 4..9 = part S    (mlpx3_core.hpp)
+    auto epi_full = [&](auto halfc, auto& acc, auto ic, auto kc) TN_INLINE_LAMBDA {
+        constexpr int HALF = decltype(halfc)::value, I = decltype(ic)::value, K = decltype(kc)::value;
+        if constexpr (K < TX_VSTEPS) tx_epi_bwd_value<HID, HALF, I, K, false>(acc, es, sc, mw);
+        else tx_epi_split<HID, HALF, I, K, true, false, false>(acc, X, es, sc, zrow, nullptr);
+    };
+    auto epiA = [&](auto ic, auto kc) TN_INLINE_LAMBDA { epi_full(std::integral_constant<int, 0>{}, accA, ic, kc); };
+    auto epiB = [&](auto ic, auto kc) TN_INLINE_LAMBDA { epi_full(std::integral_constant<int, 1>{}, accB, ic, kc); };
+    auto epiA_value = [&](auto ic, auto kc) TN_INLINE_LAMBDA { tx_epi_bwd_value<HID, 0, decltype(ic)::value, decltype(kc)::value, true>(accA, es, sc, mw); };
+    auto epiA_split = [&](auto ic, auto kc) TN_INLINE_LAMBDA { tx_epi_split<HID, 0, decltype(ic)::value, decltype(kc)::value, true, false, true>(accA, X, es, sc, zrow, nullptr); };
+    constexpr int SPF = HID == 256 ? 1 : 4, SPV = HID == 256 ? 1 : 4, SPS_ = HID == 256 ? 1 : 2;
     // dH_{depth-1} = W_head^T dZ_head: both halves; half A's epilogue has nothing to hide behind
     mk.fetch(mrow + (int64_t)(depth - 1) * (Mp + 32) * NT);
     tx_pass_headsT<HID, NW>(p, lds, Z, accA, accB);
@@ -279,26 +317,28 @@ __device__ __forceinline__ void tx_bwd_tile(PipeX& p, const unsigned char* lds, 
     for (int w = 0; w < NT / 2; ++w) mw[w] = mk.v[w];
     zrow = pl + L.dz_row0[depth - 1] * 32;
     scale_for(depth, (fabsf(dzh[0]) + fabsf(dzh[1])) + (fabsf(dzh[2]) + fabsf(dzh[3])));
-    tx_drain<NP, 3>(epiA);
+    tx_drain<NP, TX_NSTEP>(epiA);
     // layer l (dH_{l-1} = W_l^T dZ_l): dZ_l's half B epilogue behind the first half of pass A; the sign words of layer l-1 are
-    // fetched before pass A and waited for (>= TX_LEAD boundaries later) at the start of dZ_{l-1}'s half A epilogue, which rides
-    // on the second half of pass B
+    // fetched before pass A and waited for (>= TX_LEAD boundaries later) at the start of pass B, where dZ_{l-1}'s half A epilogue
+    // begins: part V (mask) in the first half of pass B, part S in the second
     for (int l = depth - 1; l >= 1; --l) {
         mk.fetch(mrow + (int64_t)(l - 1) * (Mp + 32) * NT);
-        tx_pass<HID, 1, true, NW>(p, lds, X, nullptr, accA, tx_window<0, G2, NP>(epiB));
-        auto winA = tx_window<G2 * TX_SPG, G2, NP>(epiA);
+        tx_pass<HID, 1, true, NW>(p, lds, X, nullptr, accA, tx_window<0, G2, NP, 0, TX_NSTEP, SPF>(epiB));
+        auto w1 = tx_window<0, G2, NP, 0, TX_VSTEPS, SPV>(epiA_value);
+        auto w2 = tx_window<(G2 - (HID == 256 ? 1 : 0)) * TX_SPG, G2, NP, TX_VSTEPS, TX_NSTEP, SPS_>(epiA_split);
         tx_pass<HID, 1, true, NW>(p, lds, X, nullptr, accB, [&](auto sc_) TN_INLINE_LAMBDA {
-            if constexpr (decltype(sc_)::value == G2 * TX_SPG) {
+            if constexpr (decltype(sc_)::value == 0) {
                 mk.template wait<TxCfg<HID>::DPW * TX_LEAD>();
 #pragma unroll
                 for (int w = 0; w < NT / 2; ++w) mw[w] = mk.v[w];
                 zrow = pl + L.dz_row0[l - 1] * 32;
-                scale_for(l, sc.l1 + tx_partner(sc.l1));
+                const float l1_own = sc.l1[0] + sc.l1[1];
+                scale_for(l, l1_own + tx_partner(l1_own));
             }
-            winA(sc_);
+            w1(sc_); w2(sc_);
         });
     }
-    tx_drain<NP, 2>(epiB);                                         // dZ_0, half B: to the stash only
+    tx_drain<NP, 5>(epiB);                                         // dZ_0, half B: to the stash only (steps 0 .. 4)
 }
 
 template <int HID>

@@ -31,6 +31,11 @@
 #pragma once
 #include "mlp16_core.hpp"
 
+// Ablation knobs for timing (tools/x3_stamp_probe.py): WRONG numerics, diagnostic builds only (tools/build_variant.sh passes -DTN_DIAG).
+#if (defined(TX_NO_EPI) || defined(TX_NO_FRAG) || defined(TX_NO_DMA)) && !defined(TN_DIAG)
+#error "TX_NO_EPI / TX_NO_FRAG / TX_NO_DMA are diagnostic knobs with wrong numerics: build with -DTN_DIAG (tools/build_variant.sh)"
+#endif
+
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -55,6 +60,8 @@ __device__ __forceinline__ unsigned tx_cvt2(float lo, float hi) {             //
 }
 __device__ __forceinline__ float tx_lo2f(unsigned p) { return (float)__builtin_bit_cast(f16x2, p)[0]; }
 __device__ __forceinline__ float tx_hi2f(unsigned p) { return (float)__builtin_bit_cast(f16x2, p)[1]; }
+// (v_fma_mix_f32 would do x - (float)half in one instruction, but only inline asm reaches it and hipcc then pads every MFMA in
+// front of such an asm with s_nop 11: measured 2x slower.)
 // (x0, x1) already scaled -> the two packed pieces of the pair
 __device__ __forceinline__ void tx_split2(float x0, float x1, unsigned& p1, unsigned& p2) {
     p1 = tx_cvt2(x0, x1);
@@ -87,6 +94,9 @@ struct PipeX {
 // the LDS address.  M0 (the DMA's LDS base) is compiler-reserved: saved and restored around the load.
 template <int I>
 __device__ __forceinline__ void tx_issue_piece(const unsigned char* src, uint32_t voff, uint32_t lds_dst) {
+#ifdef TX_NO_DMA
+    return;
+#endif
     uint32_t keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%4\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(src + (I >> 2) * 4096), "s"(lds_dst + (I >> 2) * 4096), "n"((I & 3) * 1024) : "memory");
@@ -165,6 +175,11 @@ __device__ __forceinline__ FragX tx_frag_load(const unsigned char* base, int tl)
     return f;
 }
 #define TX_PIN() __builtin_amdgcn_sched_barrier(0)
+// sched_barrier pins the machine scheduler, not the IR: an epilogue step whose results are only consumed by the NEXT layer's
+// passes (half A's, computed in pass B) is otherwise sunk to the end of the loop body, out of every MFMA shadow (seen in the
+// ISA: 1100 vector instructions in one block behind pass B).  An empty volatile asm that "modifies" a step's results keeps the
+// step where it was written.
+#define TX_KEEP(x) asm volatile("" : "+v"(x))
 #define TX_ACCN(HID) ((HID) / 64 * 2)             // a half's accumulators: [tile slot] leading products, [NH + tile slot] corrections
 #define TX_SPG 3                                  // MFMAs (= hook slots) per (tile, k-step) group
 
@@ -173,68 +188,75 @@ __device__ __forceinline__ FragX tx_frag_load(const unsigned char* base, int tl)
 // record's NH tile slots carry NH consecutive k-steps of it instead (KH / NH records).
 // A skip layer's half is a KIND 1 pass followed by a KIND 0 pass that accumulates (ZERO = false) — one copy of the long pass
 // in the instruction cache instead of two.
-// RPS = records per stage (2 for 256-wide, 4 for 128-wide nets); every pass is a whole number of stages, so the stage
-// phase of record k is k % RPS.  ZERO: the accumulators start at zero.
+// RPS = records per stage (2 for 256-wide, 4 for 128-wide nets); every pass is a whole number of stages.  ZERO: the
+// accumulators start at zero.
 // hook(integral_constant<slot>) is called behind MFMA number slot = (k * NTU + tile) * 3 + j: work to issue in its shadow.
-// The next group's A fragments are read from LDS behind the first MFMA of a group (not across a stage boundary).
+// A (tile, k-step) GROUP is three MFMAs = 96 cycles, less than an LDS read takes to return when the other three waves and the
+// DMA are busy on the same LDS: the A fragments are read TX_FD groups ahead (behind the first MFMA of a group), and the stage
+// boundary (wait, barrier, next DMA stage named) of every stage but the pass's first is taken TX_FD groups EARLY, so that the new
+// stage's first fragments are read behind MFMAs as well.  (The ring has the spare slot this needs: TX_LEAD + 2 <= TX_NS; the
+// slot a boundary hands to the DMA held the stage before the one whose last TX_FD groups are still running.)
 // elds: this lane's slot of the wave's network-input pieces in LDS (KIND 0; tx_store_input), read one k-step ahead.
+#define TX_FD 2
 template <int HID, int KIND, bool ZERO, int NW, typename Hook>
 __device__ __forceinline__ void tx_pass(PipeX& p, const unsigned char* lds, const ActX<HID>& X, const unsigned char* elds,
                                         f32x16 (&acc)[TX_ACCN(HID)], Hook&& hook) {
     constexpr int NH = HID / 64, KH = HID / 16, RPS = TX_STAGE / (NH * TX_NP), DPW = TX_STAGE / NW;
     constexpr int NK = KIND == 0 ? TN16_KE : (KIND == 3 ? KH / NH : KH);
-    constexpr int NTU = NH;
+    constexpr int NTU = NH, NG = NK * NTU, GPS = RPS * NTU;          // groups of the pass / per stage
     static_assert(NK % RPS == 0, "a half-pass must be a whole number of stages");
-    FragX cur;
+    static_assert(TX_FD < GPS && TX_FD <= NG, "fragment prefetch distance");
+    FragX fr[TX_FD + 1];
     f16x8 e1, e2, en1, en2;                                          // KIND 0: the B operand of this / the next k-step
     if constexpr (KIND == 0) { e1 = *reinterpret_cast<const f16x8*>(elds); e2 = *reinterpret_cast<const f16x8*>(elds + TN16_KE * 1024); }
-    tn_static_for<NK>([&](auto kc) TN_INLINE_LAMBDA {
-        constexpr int k = decltype(kc)::value;
-        // The stage boundary (wait, barrier, next DMA stage named) of every stage but the pass's first is taken one MFMA group
-        // EARLY — in front of the last group of the stage before, whose A fragments are already in registers — so that the new
-        // stage's first fragments are read behind that group's MFMAs instead of in front of an idle matrix pipe.  (The ring has
-        // the spare slot this needs: TX_LEAD + 2 <= TX_NS.)
-        if constexpr (k == 0) tx_boundary<DPW, true>(p);
-        const unsigned char* base = lds + p.cur + (k % RPS) * (NH * TX_NP * 1024) + p.lane16;
-        if constexpr (k == 0) cur = tx_frag_load(base, 0);
-        tn_static_for<NTU>([&](auto tc) TN_INLINE_LAMBDA {
-            constexpr int tl = decltype(tc)::value;
-            constexpr int ks = KIND == 3 ? k * NH + tl : k;          // the k-step of this group's B operand
-            constexpr int ta = KIND == 3 ? 0 : tl;                   // ... and its accumulator
-            f16x8 b1, b2;
-            if constexpr (KIND == 0) { b1 = e1; b2 = e2; }
-            else { b1 = TX_H8(X.p1[ks]); b2 = TX_H8(X.p2[ks]); }
-            constexpr bool more_tile = tl + 1 < NTU;
-            constexpr bool more_rec = !more_tile && (k + 1) % RPS != 0 && k + 1 < NK;
-            constexpr bool early = !more_tile && (k + 1) % RPS == 0 && k + 1 < NK;      // last group of a stage, another follows in this pass
-            constexpr int s0 = (k * NTU + tl) * TX_SPG;
-            FragX nxt;
-            if constexpr (early) tx_boundary<DPW, true>(p);
-            if constexpr (ZERO && ks == 0) { const f32x16 z = {}; acc[ta + NH] = TX_MFMA(cur.a2, b1, z); }
-            else                          acc[ta + NH] = TX_MFMA(cur.a2, b1, acc[ta + NH]);
-            if constexpr (more_tile)     nxt = tx_frag_load(base, tl + 1);
-            else if constexpr (more_rec) nxt = tx_frag_load(base + NH * TX_NP * 1024, 0);
-            else if constexpr (early)    nxt = tx_frag_load(lds + p.cur + p.lane16, 0);
-            if constexpr (KIND == 0 && tl == 0 && k + 1 < NK) {
-                en1 = *reinterpret_cast<const f16x8*>(elds + (k + 1) * 1024); en2 = *reinterpret_cast<const f16x8*>(elds + (TN16_KE + k + 1) * 1024);
-            }
-            hook(std::integral_constant<int, s0>{});     TX_PIN();
-            acc[ta + NH] = TX_MFMA(cur.a1, b2, acc[ta + NH]); hook(std::integral_constant<int, s0 + 1>{});
-            {   // this group's share of the pending stage's DMA pieces
-                constexpr int GPS = RPS * NTU, PPS = (DPW + GPS - 2) / (GPS - 1), g = (k % RPS) * NTU + tl;
-                tn_static_for<PPS>([&](auto uc) TN_INLINE_LAMBDA {
-                    constexpr int i = g * PPS + decltype(uc)::value;
-                    if constexpr (i < DPW && g < GPS - 1) tx_issue_piece<i>(p.pend_src, p.voff, p.pend_dst);
-                });
-            }
-            TX_PIN();
-            if constexpr (ZERO && ks == 0) { const f32x16 z = {}; acc[ta] = TX_MFMA(cur.a1, b1, z); }
-            else                          acc[ta] = TX_MFMA(cur.a1, b1, acc[ta]);
-            hook(std::integral_constant<int, s0 + 2>{}); TX_PIN();
-            if constexpr (more_tile || more_rec || early) cur = nxt;
-        });
-        if constexpr (KIND == 0 && k + 1 < NK) { e1 = en1; e2 = en2; }
+    tx_boundary<DPW, true>(p);
+    tn_static_for<TX_FD>([&](auto ic) TN_INLINE_LAMBDA {
+        constexpr int i = decltype(ic)::value;
+        fr[i] = tx_frag_load(lds + p.cur + p.lane16, i);
     });
+    tn_static_for<NG>([&](auto fc) TN_INLINE_LAMBDA {
+        constexpr int f = decltype(fc)::value, k = f / NTU, tl = f % NTU;
+        constexpr int ks = KIND == 3 ? k * NH + tl : k;              // the k-step of this group's B operand
+        constexpr int ta = KIND == 3 ? 0 : tl;                       // ... and its accumulator
+        f16x8 b1, b2;
+        if constexpr (KIND == 0) { b1 = e1; b2 = e2; }
+        else { b1 = TX_H8(X.p1[ks]); b2 = TX_H8(X.p2[ks]); }
+        constexpr int s0 = f * TX_SPG, fn = f + TX_FD;               // fn: the group whose fragments are read behind this one's first MFMA
+        const FragX& cur = fr[f % (TX_FD + 1)];
+        if constexpr (fn < NG && fn % GPS == 0) tx_boundary<DPW, true>(p);            // fn opens a stage: publish it first
+        if constexpr (ZERO && ks == 0) { const f32x16 z = {}; acc[ta + NH] = TX_MFMA(cur.a2, b1, z); }
+        else                          acc[ta + NH] = TX_MFMA(cur.a2, b1, acc[ta + NH]);
+#ifdef TX_NO_FRAG
+        fr[fn % (TX_FD + 1)] = cur;
+#else
+        if constexpr (fn < NG) fr[fn % (TX_FD + 1)] = tx_frag_load(lds + p.cur + p.lane16, fn % GPS);
+#endif
+        if constexpr (KIND == 0 && tl == 0 && k + 1 < NK) {
+            en1 = *reinterpret_cast<const f16x8*>(elds + (k + 1) * 1024); en2 = *reinterpret_cast<const f16x8*>(elds + (TN16_KE + k + 1) * 1024);
+        }
+        hook(std::integral_constant<int, s0>{});     TX_PIN();
+        acc[ta + NH] = TX_MFMA(cur.a1, b2, acc[ta + NH]); hook(std::integral_constant<int, s0 + 1>{});
+        {   // this group's share of the DMA pieces of the pending stage (named by the last boundary), all issued before the next one
+            constexpr int NS_ = NG / GPS;                                             // stages of the pass
+            constexpr int sidx = (f + TX_FD) / GPS < NS_ - 1 ? (f + TX_FD) / GPS : NS_ - 1;
+            constexpr int last_b = sidx == 0 ? 0 : sidx * GPS - TX_FD;               // the group in front of which the last boundary was taken
+            constexpr int next_b = sidx + 1 <= NS_ - 1 ? (sidx + 1) * GPS - TX_FD : NG;
+            constexpr int since = f - last_b, span = next_b - last_b;
+            constexpr int PPS = (DPW + span - 2) / (span - 1);
+            tn_static_for<PPS>([&](auto uc) TN_INLINE_LAMBDA {
+                constexpr int i = since * PPS + decltype(uc)::value;
+                if constexpr (i < DPW && since < span - 1) tx_issue_piece<i>(p.pend_src, p.voff, p.pend_dst);
+            });
+        }
+        TX_PIN();
+        if constexpr (ZERO && ks == 0) { const f32x16 z = {}; acc[ta] = TX_MFMA(cur.a1, b1, z); }
+        else                          acc[ta] = TX_MFMA(cur.a1, b1, acc[ta]);
+        hook(std::integral_constant<int, s0 + 2>{}); TX_PIN();
+        if constexpr (KIND == 0 && tl == NTU - 1 && k + 1 < NK) { e1 = en1; e2 = en2; }
+    });
+#ifdef TX_NO_EPI      // ablation: nothing consumes the accumulators — keep the MFMAs alive
+    tn_static_for<TX_ACCN(HID)>([&](auto ic) TN_INLINE_LAMBDA { const float d_ = acc[decltype(ic)::value][0]; asm volatile("" :: "v"(d_)); });
+#endif
 }
 
 // heads^T of the backward stream: ONE k-step (B operand = Z.p*[0]) into both halves' accumulators; the stage holds record A,
@@ -268,90 +290,143 @@ template <int HID, int HALF, int I> struct TxPair {
     static constexpr int row0 = 32 * t + (r0 & 3) + 8 * (r0 >> 2), row1 = 32 * t + (r1 & 3) + 8 * (r1 >> 2);   // feature rows (+ 4h) of the stash
 };
 // Per-sample scalars of the epilogue that is running: dsc = 2^-(s + t_in) turns the accumulator sum into the layer's output,
-// osc = 2^t_out scales that output into the fp16 range for the split; l1 sums |output| (the next bound).
-struct TxScale { float dsc, osc, l1; };
-struct TxEpi { float v0[4], v1[4]; unsigned p1[4]; f32x2 b[4]; uint32_t msk; };      // up to 4 pairs in flight
+// osc = 2^t_out scales that output into the fp16 range for the split; l1 sums |output| pairwise (the next bound).
+struct TxScale { float dsc, osc; f32x2 l1; };
+struct TxEpi { f32x2 v[4], c[4], f[4]; unsigned p1[4]; f32x2 b[4]; uint32_t msk; };      // up to 4 pairs in flight
 
-// step 2 of any epilogue: the second piece, and both into the activation registers
-template <int HID, int HALF, int I>
-__device__ __forceinline__ void tx_epi_split(ActX<HID>& X, TxEpi& e) {
+// An epilogue is a chain of TX_NSTEP fine STEPS per register pair, each step one or two instructions per value that depend only
+// on the step before.  With one wave per SIMD a dependent instruction cannot issue until its predecessor has left the pipeline
+// (~8 cycles), and the wave issues in order — so an epilogue whose chain runs within one MFMA gap stretches the gap to 50
+// cycles (measured: stamps per pass, PMC issue-stall counters).  The steps are therefore SOFTWARE-PIPELINED over the MFMA
+// gaps: pair i runs step k behind MFMA number W0 + 3 i + k, so that a gap carries steps of three different pairs — mutually
+// independent instructions — and a pair's next step is a whole gap away.
+// The chain is also cut in two PARTS so that it can straddle the point where its activation registers become free:
+//   part V (steps 0..3): accumulators -> the layer's fp32 output (descale, bias + ReLU / sign-bit mask).  Half A's part V runs in
+//           the first half of pass B and parks the values in the leading-product accumulators themselves;
+//   part S (steps 4..9): value -> [stash, sign bits] L1 norm, scale, two fp16 pieces into the activation registers.  For half A in
+//           the second half of pass B (the slots it overwrites are dead there), from the parked values; for half B both parts run
+//           back to back in the first half of the next layer's pass A.
+#define TX_NSTEP 10
+#define TX_VSTEPS 4
+
+// steps 4..9 (part S).  FWD: the values are ReLU outputs (sign words are recorded, the L1 norm needs no abs).  PARKED: step 4 first
+// fetches the value part V left in the leading-product accumulator.
+template <int HID, int HALF, int I, int K, bool TRAIN, bool FWD, bool PARKED>
+__device__ __forceinline__ void tx_epi_split(const f32x16 (&acc)[TX_ACCN(HID)], ActX<HID>& X, TxEpi& e, TxScale& sc, float* __restrict__ srow, uint32_t* __restrict__ mword) {
     using P = TxPair<HID, HALF, I>;
     constexpr int u = I % 4;
-    X.p1[P::xs][P::xq] = e.p1[u];
-    X.p2[P::xs][P::xq] = tx_cvt2(e.v0[u] - tx_lo2f(e.p1[u]), e.v1[u] - tx_hi2f(e.p1[u]));
-}
-
-// Forward: descale, bias (fp32, LDS byte offset vb + 16 h: this layer's biases for rows 4h..), ReLU, [training: fp32 value to the
-// stash, sign bit], L1 norm, scale, split.  The bias pair is READ one group before it is used, so that the compiler's lgkmcnt
-// wait lands a whole group later.
-// srow: per-lane stash pointer of the layer's activation rows (row 4h, this sample); mword: per-lane pointer of its sign words.
-template <int HID, int HALF, int I, int J, bool TRAIN, int PPG>
-__device__ __forceinline__ void tx_epi_fwd(const f32x16 (&acc)[TX_ACCN(HID)], ActX<HID>& X, TxEpi& e, TxScale& sc, const unsigned char* lds, uint32_t vb,
-                                           float* __restrict__ srow, uint32_t* __restrict__ mword) {
-    using P = TxPair<HID, HALF, I>;
-    constexpr int u = I % 4;
-    // PPG: pairs per MFMA group of the window this runs in; pair I + PPG is the one that takes this register slot next
-    if constexpr (J == 0) {
-        if constexpr (I < PPG) e.b[u] = *reinterpret_cast<const f32x2*>(lds + vb + P::row0 * 4);      // the window's first group
-        e.v0[u] = fmaxf(__builtin_fmaf(acc[P::tl][P::r0] + acc[P::tl + P::NH][P::r0], sc.dsc, e.b[u][0]), 0.0f);
-        e.v1[u] = fmaxf(__builtin_fmaf(acc[P::tl][P::r1] + acc[P::tl + P::NH][P::r1], sc.dsc, e.b[u][1]), 0.0f);
-    } else if constexpr (J == 1) {
-        if constexpr (TRAIN) {
-            TN_STASH_STORE(&srow[P::row0 * 32], e.v0[u]); TN_STASH_STORE(&srow[P::row1 * 32], e.v1[u]);
+    if constexpr (K == 4) {
+        if constexpr (PARKED) { e.v[u][0] = acc[P::tl][P::r0]; e.v[u][1] = acc[P::tl][P::r1]; TX_KEEP(e.v[u]); }
+        if constexpr (TRAIN) { TN_STASH_STORE(&srow[P::row0 * 32], e.v[u][0]); TN_STASH_STORE(&srow[P::row1 * 32], e.v[u][1]); }
+    } else if constexpr (K == 5) {
+        if constexpr (TRAIN && FWD) {                           // ReLU sign bits
             if constexpr (I % 16 == 0) e.msk = 0u;
-            e.msk = __builtin_amdgcn_alignbit(e.msk, __float_as_uint(e.v1[u]) + 0x7FFFFFFFu, 31);
-            e.msk = __builtin_amdgcn_alignbit(e.msk, __float_as_uint(e.v0[u]) + 0x7FFFFFFFu, 31);
+            e.msk = __builtin_amdgcn_alignbit(e.msk, __float_as_uint(e.v[u][1]) + 0x7FFFFFFFu, 31);
+            e.msk = __builtin_amdgcn_alignbit(e.msk, __float_as_uint(e.v[u][0]) + 0x7FFFFFFFu, 31);
             if constexpr (I % 16 == 15) mword[P::t / 2] = e.msk;
         }
-        sc.l1 += e.v0[u] + e.v1[u];
-        e.v0[u] *= sc.osc; e.v1[u] *= sc.osc;
-        e.p1[u] = tx_cvt2(e.v0[u], e.v1[u]);
-    } else {
-        if constexpr (I + PPG < P::NH * 8) e.b[(I + PPG) % 4] = *reinterpret_cast<const f32x2*>(lds + vb + TxPair<HID, HALF, I + PPG>::row0 * 4);
-        tx_epi_split<HID, HALF, I>(X, e);
+        if constexpr (FWD) sc.l1 += e.v[u];
+        else { sc.l1[0] += fabsf(e.v[u][0]); sc.l1[1] += fabsf(e.v[u][1]); }
+        e.v[u] *= sc.osc;
+        TX_KEEP(e.v[u]); TX_KEEP(sc.l1);
+    } else if constexpr (K == 6) {
+        e.p1[u] = tx_cvt2(e.v[u][0], e.v[u][1]); TX_KEEP(e.p1[u]);
+    } else if constexpr (K == 7) {
+        e.f[u][0] = tx_lo2f(e.p1[u]); e.f[u][1] = tx_hi2f(e.p1[u]); TX_KEEP(e.f[u]);
+    } else if constexpr (K == 8) {
+        e.v[u] -= e.f[u]; TX_KEEP(e.v[u]);
+    } else if constexpr (K == 9) {
+        unsigned q2 = tx_cvt2(e.v[u][0], e.v[u][1]);
+        TX_KEEP(q2);
+        X.p1[P::xs][P::xq] = e.p1[u];
+        X.p2[P::xs][P::xq] = q2;
     }
 }
 
-// Backward: descale, ReLU backward with the forward's sign bits (mw: the words of the layer this activation gradient belongs
-// to), dZ to the stash, L1 norm, scale, split.
-template <int HID, int HALF, int I, int J>
-__device__ __forceinline__ void tx_epi_bwd(const f32x16 (&acc)[TX_ACCN(HID)], ActX<HID>& X, TxEpi& e, TxScale& sc, const uint32_t (&mw)[HID / 64], float* __restrict__ zrow) {
+// Forward part V (steps 0..3): leading + correction, descale + bias (fp32, LDS byte offset vb + 16 h: this layer's biases for rows
+// 4h..), ReLU.  PARK: step 3 puts the value back into the leading-product accumulator (half A).
+template <int HID, int HALF, int I, int K, bool PARK>
+__device__ __forceinline__ void tx_epi_fwd_value(f32x16 (&acc)[TX_ACCN(HID)], TxEpi& e, const TxScale& sc, const unsigned char* lds, uint32_t vb) {
     using P = TxPair<HID, HALF, I>;
     constexpr int u = I % 4;
-    if constexpr (J == 0) {
-        const float a0 = (acc[P::tl][P::r0] + acc[P::tl + P::NH][P::r0]) * sc.dsc, a1 = (acc[P::tl][P::r1] + acc[P::tl + P::NH][P::r1]) * sc.dsc;
-        e.v0[u] = __int_as_float(__float_as_int(a0) & __builtin_amdgcn_sbfe((int)mw[P::t / 2], (P::t & 1) * 16 + P::r0, 1));
-        e.v1[u] = __int_as_float(__float_as_int(a1) & __builtin_amdgcn_sbfe((int)mw[P::t / 2], (P::t & 1) * 16 + P::r1, 1));
-    } else if constexpr (J == 1) {
-        TN_STASH_STORE(&zrow[P::row0 * 32], e.v0[u]); TN_STASH_STORE(&zrow[P::row1 * 32], e.v1[u]);
-        sc.l1 += fabsf(e.v0[u]) + fabsf(e.v1[u]);
-        e.v0[u] *= sc.osc; e.v1[u] *= sc.osc;
-        e.p1[u] = tx_cvt2(e.v0[u], e.v1[u]);
-    } else tx_epi_split<HID, HALF, I>(X, e);
+    if constexpr (K == 0) {
+        e.b[u] = *reinterpret_cast<const f32x2*>(lds + vb + P::row0 * 4);
+        e.v[u][0] = acc[P::tl][P::r0]; e.v[u][1] = acc[P::tl][P::r1];
+        e.c[u][0] = acc[P::tl + P::NH][P::r0]; e.c[u][1] = acc[P::tl + P::NH][P::r1];
+        TX_KEEP(e.v[u]); TX_KEEP(e.c[u]);
+    } else if constexpr (K == 1) {
+        e.v[u] += e.c[u]; TX_KEEP(e.v[u]);
+    } else if constexpr (K == 2) {
+        e.v[u][0] = __builtin_fmaf(e.v[u][0], sc.dsc, e.b[u][0]); e.v[u][1] = __builtin_fmaf(e.v[u][1], sc.dsc, e.b[u][1]); TX_KEEP(e.v[u]);
+    } else if constexpr (K == 3) {
+        // ReLU as a signed-integer max: negative floats (and -0) are negative integers.  (fmaxf on a value that has just passed
+        // through an asm needs a canonicalising v_max in front of it.)
+        e.v[u][0] = __int_as_float(max(__float_as_int(e.v[u][0]), 0)); e.v[u][1] = __int_as_float(max(__float_as_int(e.v[u][1]), 0)); TX_KEEP(e.v[u]);
+        if constexpr (PARK) { acc[P::tl][P::r0] = e.v[u][0]; acc[P::tl][P::r1] = e.v[u][1]; }
+    }
+}
+// Backward part V: leading + correction, descale, ReLU backward with the forward's sign bits (mw: the words of the layer this
+// activation gradient belongs to).
+template <int HID, int HALF, int I, int K, bool PARK>
+__device__ __forceinline__ void tx_epi_bwd_value(f32x16 (&acc)[TX_ACCN(HID)], TxEpi& e, const TxScale& sc, const uint32_t (&mw)[HID / 64]) {
+    using P = TxPair<HID, HALF, I>;
+    constexpr int u = I % 4;
+    if constexpr (K == 0) {
+        e.v[u][0] = acc[P::tl][P::r0]; e.v[u][1] = acc[P::tl][P::r1];
+        e.c[u][0] = acc[P::tl + P::NH][P::r0]; e.c[u][1] = acc[P::tl + P::NH][P::r1];
+        TX_KEEP(e.v[u]); TX_KEEP(e.c[u]);
+    } else if constexpr (K == 1) {
+        e.v[u] += e.c[u]; TX_KEEP(e.v[u]);
+        e.b[u][0] = __int_as_float(__builtin_amdgcn_sbfe((int)mw[P::t / 2], (P::t & 1) * 16 + P::r0, 1));       // the mask: 0 / all ones
+        e.b[u][1] = __int_as_float(__builtin_amdgcn_sbfe((int)mw[P::t / 2], (P::t & 1) * 16 + P::r1, 1));
+        TX_KEEP(e.b[u]);
+    } else if constexpr (K == 2) {
+        e.v[u] *= sc.dsc; TX_KEEP(e.v[u]);
+    } else if constexpr (K == 3) {
+        e.v[u][0] = __int_as_float(__float_as_int(e.v[u][0]) & __float_as_int(e.b[u][0]));
+        e.v[u][1] = __int_as_float(__float_as_int(e.v[u][1]) & __float_as_int(e.b[u][1]));
+        TX_KEEP(e.v[u]);
+        if constexpr (PARK) { acc[P::tl][P::r0] = e.v[u][0]; acc[P::tl][P::r1] = e.v[u][1]; }
+    }
 }
 
-// The slots [W0, W0 + 3 G) of a pass as an epilogue window: group g = (slot - W0) / 3 carries micro-step (slot - W0) % 3 of the
-// pairs g*PPG .. g*PPG + PPG - 1 (PPG = ceil(NP / G) <= 4).  f(integral_constant<I>, integral_constant<J>, integral_constant<PPG>).
-template <int W0, int G, int NP, typename F>
+// Epilogue steps [K0, K1) of NP pairs over the slots of a pass from W0 on, SPS consecutive steps per slot.  G = groups in which
+// pairs start, PPG = ceil(NP / G) pairs start per group; pair i runs steps K0 + q SPS .. behind MFMA slot W0 + 3 (i / PPG) + q.
+// SPS = 1 is the software pipeline of the comment above (PPG = 1: four pairs in flight); SPS = 4 runs a pair's chain inside its
+// own group (several pairs per group interleave instead).  f(integral_constant<I>, integral_constant<K>).
+// The caller checks that the last pair's last step (slot W0 + 3 (G - 1) + ceil((K1 - K0) / SPS) - 1) lies inside the pass and
+// before the first read of what it writes.
+template <int W0, int G, int NP, int K0, int K1, int SPS, typename F>
 __device__ __forceinline__ auto tx_window(F&& f) {
     return [&f](auto sc) TN_INLINE_LAMBDA {
         constexpr int s = decltype(sc)::value;
-        constexpr int PPG = (NP + G - 1) / G;
-        static_assert(PPG <= 4, "epilogue window too short");
-        if constexpr (s >= W0 && s < W0 + TX_SPG * G) {
-            constexpr int g = (s - W0) / TX_SPG, j = (s - W0) % TX_SPG;
-            tn_static_for<PPG>([&](auto uc) TN_INLINE_LAMBDA {
-                constexpr int i = g * PPG + decltype(uc)::value;
-                if constexpr (i < NP) f(std::integral_constant<int, i>{}, std::integral_constant<int, j>{}, std::integral_constant<int, PPG>{});
+        constexpr int PPG = (NP + G - 1) / G, NQ = (K1 - K0 + SPS - 1) / SPS, DEPTH = (NQ + TX_SPG - 1) / TX_SPG;
+        static_assert(PPG * DEPTH <= 4, "more pairs in flight than TxEpi holds");
+#ifdef TX_NO_EPI
+        return;
+#endif
+        if constexpr (s >= W0 && s < W0 + TX_SPG * (G - 1) + NQ) {
+            constexpr int rel = s - W0;
+            tn_static_for<DEPTH>([&](auto dc) TN_INLINE_LAMBDA {                 // the group that started d groups ago is at slot-step rel % 3 + 3 d
+                constexpr int g = rel / TX_SPG - decltype(dc)::value, q = rel % TX_SPG + TX_SPG * decltype(dc)::value;
+                if constexpr (g >= 0 && g < G && q < NQ)
+                    tn_static_for<SPS>([&](auto kc) TN_INLINE_LAMBDA {
+                        constexpr int k = K0 + q * SPS + decltype(kc)::value;
+                        if constexpr (k < K1)
+                            tn_static_for<PPG>([&](auto uc) TN_INLINE_LAMBDA {
+                                constexpr int i = g * PPG + decltype(uc)::value;
+                                if constexpr (i < NP) f(std::integral_constant<int, i>{}, std::integral_constant<int, k>{});
+                            });
+                    });
             });
         }
     };
 }
-// A whole epilogue with nothing to hide behind.  NJ = 3: all micro-steps; 2: without the second piece (nothing consumes the pieces).
+// A whole epilogue with nothing to hide behind (steps 0 .. NJ-1 of every pair).
 template <int NP, int NJ, typename F>
 __device__ __forceinline__ void tx_drain(F&& f) {
     tn_static_for<NP>([&](auto ic) TN_INLINE_LAMBDA {
-        tn_static_for<NJ>([&](auto jc) TN_INLINE_LAMBDA { f(ic, jc, std::integral_constant<int, 1>{}); });
+        tn_static_for<NJ>([&](auto jc) TN_INLINE_LAMBDA { f(ic, jc); });
     });
 }
 

@@ -5,7 +5,7 @@ import ctypes as C, os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tiny-nerf-pytorch_amd")); sys.path.insert(0, os.path.join(ROOT, "tiny-nerf-pytorch_amd", "src"))
-os.environ["TNERF_LIB"] = os.path.join(ROOT, "tiny-nerf-pytorch_amd", "tnerf", "libtnerf_variant_x3stamps.so")
+os.environ["TNERF_LIB"] = os.path.join(ROOT, "tiny-nerf-pytorch_amd", "tnerf", f"libtnerf_variant_{sys.argv[1] if len(sys.argv) > 1 else 'x3stamps'}.so")
 from tnerf import ops, lib
 import nerf
 dev = torch.device("cuda:0")
@@ -22,23 +22,27 @@ for (L, hidden, depth, skip, R, S) in ((6, 256, 8, 4, 4096, 64), (10, 128, 4, 2,
     ztab = ops.depth_table(2.0, 6.0, S, dev)
     comp = torch.empty(R, 3, device=dev)
     n_wave = 256 * 4
-    stamps = torch.zeros(n_wave * 8, dtype=torch.int64, device=dev)
+    stamps = torch.zeros(n_wave * 8 + 64, dtype=torch.int64, device=dev)
     H = 128 if hidden <= 128 else 256
     in_pad = 16 * ((6 * L + 3 + 15) // 16 + (0 if (6 * L + 3) % 16 else 0))
     for train in (False, True):
         plan = st.plan(R * S) if train else None
-        for it in range(200):
+        for it in range(60):
             rc = dbg.tnerf_debug_renderx3_stamps(C.byref(st.desc), C.c_void_p(x3.packed.data_ptr()), C.c_void_p(o.data_ptr()), C.c_void_p(d.data_ptr()),
                                                  C.c_int64(R), C.c_int32(S), C.c_void_p(ztab.data_ptr()), C.c_void_p(comp.data_ptr()),
                                                  C.c_void_p(plan.stash.data_ptr() if train else None), C.c_int64(plan.Mp if train else 0),
                                                  C.c_void_p(stamps.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream))
             assert rc == 0
         torch.cuda.synchronize()
-        s = stamps.cpu().numpy().reshape(n_wave, 8).astype(np.float64)
+        marks = stamps.cpu().numpy()[n_wave * 8:]
+        s = stamps.cpu().numpy()[: n_wave * 8].reshape(n_wave, 8).astype(np.float64)
         s = s[s[:, 0] > 0]
         cyc, rt, walk, epi = s[:, 0], s[:, 1], s[:, 2], s[:, 3]
         tiles = R * S / 32 / len(s)
-        n_mfma = tiles * 6 * (H // 32) * ((depth - 1) * (H // 16) + (2 if skip else 1) * ((6 * L + 3 + 15) // 16)) + tiles * 6 * (H // 16)
+        n_mfma = tiles * 3 * (H // 32) * ((depth - 1) * (H // 16) + (2 if skip else 1) * 4) + tiles * 3 * (H // 16)
         print(f"L={L} {depth}x{hidden} R={R} S={S} train={train}: waves {len(s)}, clock {np.median(cyc / rt) * 0.1:.3f} GHz, wave lifetime {np.median(rt) / 100:.1f} us")
         print(f"   cycles/wave {np.median(cyc):.0f}: layer walks {np.median(walk):.0f} ({np.median(walk / cyc) * 100:.1f}%), epilogues {np.median(epi):.0f} ({np.median(epi / cyc) * 100:.1f}%), "
               f"rest {np.median(cyc - walk - epi):.0f};  MFMA issue floor 32 x {n_mfma:.0f} = {32 * n_mfma:.0f} ({32 * n_mfma / np.median(cyc) * 100:.1f}% of the wave, {32 * n_mfma / np.median(walk) * 100:.1f}% of the walks)")
+        nm = int(marks[63])
+        if nm > 1:
+            print("   first tile of wave 0, cycles between pass marks: " + " ".join(str(int(marks[i + 1] - marks[i])) for i in range(nm - 1)))
