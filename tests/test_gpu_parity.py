@@ -190,10 +190,9 @@ def test_mlp_forward_backward(mods, dev, tag):
     leaves = [p.double().requires_grad_(True) for p in params]
     r64, s64 = O.mlp_forward(leaves, g["x"].double(), cfg["skip_at"])
     g64 = torch.autograd.grad((r64 * g["g_rgb"].double()).sum() + (s64 * g["g_sigma"].double()).sum(), leaves)
-    # Whole gradient vector: as close to fp64 as the reference's fp32 (x2).  Per tensor the split-bf16 chain may sit further out
-    # (accuracy: the matrix pipe drops addends below ~1/8 ulp of its accumulator, so part of the small cross terms
-    # of a product is lost once the running sum is large; the sum over samples then amplifies what is a 1e-7 effect on dZ):
-    # bounded at 16x the reference's error, and every element within 1e-4 of the reference's value.
+    # Whole gradient vector AND every tensor: as close to fp64 as the reference's own fp32 evaluation (x2), and every element within
+    # 2e-5 of the reference's value (SURVEY 8c's mlp_* pin).  Round 2's split-bf16 chain needed 16x / 1e-4 here: its accumulators
+    # were biased by the matrix pipe's floor cut; the fp16 chain with split accumulators is not.
     flat = lambda ts: torch.cat([t.reshape(-1).double() for t in ts])
     gh_all, gr_all, gd_all = flat([p.grad.cpu() for p in model.parameters()]), flat([g[f"g{i:02d}"] for i in range(len(params))]), flat(g64)
     l2_hip, l2_ref = float((gh_all - gd_all).norm() / gd_all.norm()), float((gr_all - gd_all).norm() / gd_all.norm())
@@ -203,8 +202,10 @@ def test_mlp_forward_backward(mods, dev, tag):
         assert p.grad is not None
         gh, gr, gd = p.grad.cpu().double(), g[f"g{i:02d}"].double(), g64[i]
         t_hip, t_ref = float((gh - gd).norm() / gd.norm()), float((gr - gd).norm() / gd.norm())
-        assert t_hip <= 16.0 * t_ref + 2e-6, (i, t_hip, t_ref)
-        assert relmax(p.grad.cpu(), g[f"g{i:02d}"]) <= 1e-4, (i, relmax(p.grad.cpu(), g[f"g{i:02d}"]))
+        assert t_hip <= 2.0 * t_ref + 2e-7, (i, t_hip, t_ref)
+        # two fp32 evaluations cannot agree better than the reference itself agrees with fp64 (rgb.0.weight of the 8x256 fixture:
+        # the reference's own value is 4e-3 from fp64)
+        assert relmax(p.grad.cpu(), g[f"g{i:02d}"]) <= max(2e-5, 2.0 * relmax(gr, gd)), (i, relmax(p.grad.cpu(), g[f"g{i:02d}"]), relmax(gr, gd))
     # ragged row count (not a multiple of 32) and no-grad inference agree with the training forward
     with torch.no_grad():
         r2, s2 = model(g["x"][:1001].to(dev))
@@ -294,13 +295,14 @@ def test_train_gradients_match_oracle(mods, dev, tag):
     c2, _, _, _ = mods["volume"].volume_render(rgb.reshape(-1, S, 3), sig.reshape(-1, S, 1), z, rd.to(dev))
     assert float((c2 - comp).abs().max()) <= 2e-5
     torch.mean((c2 - tgt.to(dev)) ** 2).backward()
-    # (the fused op runs the split-bf16 chain, the per-function ops the fp32 MFMA: two fp32 evaluations, each judged against fp64)
+    # (both run the x3 chain kernels; the per-function path sums the exact L1 norm of the encoded input where the fused kernel
+    # uses its bound 6L + 3 max|p|, so the per-sample scales — and with them roundings at the 1e-7 level — differ)
     g_unf = flat([q.grad.cpu() for q in m2.parameters()])
     l2_unf = float((g_unf - g_ref).norm() / g_ref.norm())
     assert l2_unf <= 2.0 * l2_cpu + 1e-6, (l2_unf, l2_cpu)
     assert float((g_unf - g_hip).norm() / g_ref.norm()) <= 2.0 * l2_cpu + 1e-6
     for p, q in zip(plist, m2.parameters()):
-        assert relmax(q.grad, p.grad) <= 1e-2
+        assert relmax(q.grad, p.grad) <= 2e-4
 
 
 @pytest.mark.parametrize("tag", ["4x128", "8x256"])
@@ -399,17 +401,22 @@ def test_fused_ragged_shapes_forward_and_gradients(mods, dev, tag, R, S):
     torch.mean((comp - tgt.to(dev)) ** 2).backward()
     _, _, g32 = O.loss_and_grads(params, cfg["skip_at"], cfg["L"], o, d, tgt, 2.0, 6.0, S, u)
     _, _, g64 = O.loss_and_grads([p.double() for p in params], cfg["skip_at"], cfg["L"], o.double(), d.double(), tgt.double(), 2.0, 6.0, S, u.double())
-    # fp32 vs fp32, both judged against an fp64 evaluation.  The 1e10 tail sample makes d sigma ill-conditioned, so a single
-    # worst element (max-abs metric) fluctuates by several x between two fp32 evaluation orders; the whole-vector L2 error is
-    # the stable yardstick and must be within 2x of the CPU-fp32 oracle's; the worst element within 8x (both printed).
+    # fp32 vs fp32, both judged against an fp64 evaluation.  The whole-vector L2 error must be within 2x of the CPU-fp32 oracle's,
+    # and so must every tensor's worst element — except the sigma head's (sigma.0.weight / bias): the 1e10 tail sample makes
+    # d sigma ill-conditioned (exp(-sigma 1e10) amplifies the forward's last-bit differences in a sigma near zero), so that
+    # tensor's worst element is a draw from a wide distribution for ANY fp32 evaluation order (tests/probes/ragged_grad_probe.py on
+    # MI355X: CPU 1.3e-3 / fp32-MFMA kernels 5.7e-3 / x3 kernels 9.1e-3 on one shape, 1.8e-2 / 5.6e-3 / 3.6e-2 on another, every
+    # other tensor within 1.0-1.8x of the CPU's); it gets 8x.
     flat = lambda gs: torch.cat([x.reshape(-1).double() for x in gs])
     g_hip, g_cpu, g_ref = flat([p.grad.cpu() for p in plist]), flat(g32), flat(g64)
     l2_hip = float((g_hip - g_ref).norm() / g_ref.norm()); l2_cpu = float((g_cpu - g_ref).norm() / g_ref.norm())
-    e_hip = max(relmax(p.grad.cpu().double(), gg) for p, gg in zip(plist, g64))
-    e_cpu = max(relmax(a.double(), gg) for a, gg in zip(g32, g64))
-    print(f"[{tag} R={R} S={S}] grad err vs fp64: L2 hip {l2_hip:.2e} cpu-fp32 {l2_cpu:.2e} | worst element hip {e_hip:.2e} cpu-fp32 {e_cpu:.2e}")
+    e_hip = [relmax(p.grad.cpu().double(), gg) for p, gg in zip(plist, g64)]
+    e_cpu = [relmax(a.double(), gg) for a, gg in zip(g32, g64)]
+    print(f"[{tag} R={R} S={S}] grad err vs fp64: L2 hip {l2_hip:.2e} cpu-fp32 {l2_cpu:.2e} | worst element hip {max(e_hip):.2e} cpu-fp32 {max(e_cpu):.2e}")
     assert l2_hip <= 2.0 * l2_cpu + 1e-6, (l2_hip, l2_cpu)
-    assert e_hip <= 8.0 * e_cpu + 2e-5, (e_hip, e_cpu)
+    sigma_head = (2 * cfg["depth"], 2 * cfg["depth"] + 1)
+    for i, (eh, ec) in enumerate(zip(e_hip, e_cpu)):
+        assert eh <= (8.0 if i in sigma_head else 2.0) * ec + 2e-5, (i, eh, ec)
 
 
 def test_deterministic_render_of_large_sample_counts(mods, dev):

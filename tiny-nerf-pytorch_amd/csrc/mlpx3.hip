@@ -664,47 +664,62 @@ extern "C" int tnerf_train_fwd_fused_x3(const tnerf_mlp_desc* d, const void* pac
 }
 
 // ----------------------------------------------------------------------------------- packing
-// One workgroup per layer (index depth = the heads): max|W| and max|b| of the layer, through the pack table (forward stream,
-// piece-0 fragments: every weight of the layer exactly once).  The maxima are order-independent: deterministic.
-//   post = 0 (a full pack follows): scale record <- {1 / 2^s, max|W|, max|b|, 2^s} with max|W| 2^s in [2^11, 2^12)
-//   post = 1 (the finishing kernel has just re-scattered every weight with the scale the record's [3] named): [0] <- 1 / [3],
-//            then [1], [2], [3] from the updated parameters — the chain kernels of the next step read the scale that is in the
-//            stream and bounds that hold for the weights that are in the stream.
-__global__ __launch_bounds__(1024) void k_x3stats(const float* __restrict__ params, const int32_t* __restrict__ table, NetX3 n,
-                                                  float* __restrict__ meta, int post) {
-    const int l = blockIdx.x;
+// max|W| and max|b| of every layer (index depth = the heads) through the pack table (forward stream, piece-0 fragments: every
+// weight of the layer exactly once), TX_SCAN_NB workgroups per layer, into the running maxima of the scale records.  Maxima are
+// order-independent: deterministic.
+#define TX_SCAN_NB 16
+__global__ __launch_bounds__(256) void k_x3stats_scan(const float* __restrict__ params, const int32_t* __restrict__ table, NetX3 n,
+                                                      float* __restrict__ meta) {
+    const int l = blockIdx.x / TX_SCAN_NB, part = blockIdx.x % TX_SCAN_NB;
     const int64_t fe = (int64_t)n.rec_frags * 512;
     const int64_t e0 = n.fw_rec0[l] * fe, e1 = n.fw_rec0[l + 1] * fe, n_w = (int64_t)(n.n_rec + n.n_bw_rec) * fe;
     float mw = 0.0f, mb = 0.0f;
-    for (int64_t e = e0 + threadIdx.x; e < e1; e += 1024) {
+    for (int64_t e = e0 + part * 256 + threadIdx.x; e < e1; e += TX_SCAN_NB * 256) {
         if (((e >> 9) % TX_NP) != 0) continue;
         const int32_t s = table[e];
         if (s >= 0) mw = fmaxf(mw, fabsf(params[s]));
     }
-    const int nb = l < n.depth ? n.hidden : 4, b0 = l < n.depth ? l * n.hidden : n.depth * n.hidden;
-    for (int j = threadIdx.x; j < nb; j += 1024) {
-        const int32_t s = table[n_w + b0 + j];
-        if (s >= 0) mb = fmaxf(mb, fabsf(params[s]));
+    if (part == 0) {
+        const int nb = l < n.depth ? n.hidden : 4, b0 = l < n.depth ? l * n.hidden : n.depth * n.hidden;
+        for (int j = threadIdx.x; j < nb; j += 256) {
+            const int32_t s = table[n_w + b0 + j];
+            if (s >= 0) mb = fmaxf(mb, fabsf(params[s]));
+        }
     }
-    __shared__ float red[2][16];
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) { mw = fmaxf(mw, __shfl_xor(mw, o, 64)); mb = fmaxf(mb, __shfl_xor(mb, o, 64)); }
-    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = mw; red[1][threadIdx.x >> 6] = mb; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-#pragma unroll
-        for (int w = 1; w < 16; ++w) { mw = fmaxf(mw, red[0][w]); mb = fmaxf(mb, red[1][w]); }
-        float* m = meta + l * TX_META;
-        const float wsc_old = m[3];
-        const float wsc_new = tx_exp2i(12 - __builtin_amdgcn_frexp_expf(mw));      // max|W| = f 2^e, f in [0.5, 1): max|W| 2^(12-e) in [2^11, 2^12)
-        m[0] = 1.0f / (post ? wsc_old : wsc_new);                                   // a power of two: exact
-        m[1] = mw; m[2] = mb; m[3] = wsc_new;
+    if ((threadIdx.x & 63) == 0) {
+        unsigned* a = reinterpret_cast<unsigned*>(meta + l * TX_META + 4);
+        atomicMax(a, __float_as_uint(mw));
+        if (part == 0) atomicMax(a + 1, __float_as_uint(mb));
     }
+}
+// Running maxima -> scale records (one thread per layer), and the maxima cleared for the next round.
+//   post = 0 (a full pack follows): {1 / 2^s, max|W|, max|b|, 2^s} with max|W| 2^s in [2^11, 2^12)
+//   post = 1 (the finishing kernel has just re-scattered every weight with the scale the record's [3] named, accumulating the
+//            maxima of the updated parameters): [0] <- 1 / [3], then [1], [2], [3] from the maxima — the chain kernels of the next
+//            step read the scale that is in the stream and bounds that hold for the weights that are in the stream.
+__global__ __launch_bounds__(64) void k_x3stats_final(int n_layers, float* __restrict__ meta, int post) {
+    const int l = threadIdx.x;
+    if (l >= n_layers) return;
+    float* m = meta + l * TX_META;
+    const float mw = __uint_as_float(reinterpret_cast<unsigned*>(m)[4]), mb = __uint_as_float(reinterpret_cast<unsigned*>(m)[5]);
+    const float wsc_old = m[3];
+    const float wsc_new = tx_exp2i(12 - __builtin_amdgcn_frexp_expf(mw));      // max|W| = f 2^e, f in [0.5, 1): max|W| 2^(12-e) in [2^11, 2^12)
+    m[0] = 1.0f / (post ? wsc_old : wsc_new);                                   // a power of two: exact
+    m[1] = mw; m[2] = mb; m[3] = wsc_new;
+    reinterpret_cast<unsigned*>(m)[4] = 0u; reinterpret_cast<unsigned*>(m)[5] = 0u;
 }
 
 int tnx3_launch_stats(const NetX3& n, const float* params, const int32_t* table, void* packed3, int post, hipStream_t stream) {
-    hipLaunchKernelGGL(k_x3stats, dim3((unsigned)(n.depth + 1)), dim3(1024), 0, stream, params, table, n,
-                       reinterpret_cast<float*>(static_cast<unsigned char*>(packed3) + n.meta_off), post);
+    float* meta = reinterpret_cast<float*>(static_cast<unsigned char*>(packed3) + n.meta_off);
+    if (!post) {                                                               // full scan (the buffer may be fresh memory: clear first)
+        const hipError_t e = hipMemsetAsync(meta, 0, (size_t)(n.depth + 1) * TX_META * 4, stream);
+        if (e != hipSuccess) { tn_set_error("x3 weight statistics: hipMemsetAsync: %s", hipGetErrorString(e)); return (int)e; }
+        hipLaunchKernelGGL(k_x3stats_scan, dim3((unsigned)((n.depth + 1) * TX_SCAN_NB)), dim3(256), 0, stream, params, table, n, meta);
+        TN_HIP_CHECK_LAUNCH("x3 weight statistics (scan)");
+    }
+    hipLaunchKernelGGL(k_x3stats_final, dim3(1), dim3(64), 0, stream, n.depth + 1, meta, post);
     TN_HIP_CHECK_LAUNCH("x3 weight statistics");
     return TNERF_OK;
 }

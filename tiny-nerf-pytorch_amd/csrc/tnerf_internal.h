@@ -91,10 +91,13 @@ struct Net16 {
 // fp32 biases as in the bf16 mode, then TX_META floats per layer (index depth = the heads):
 //   [0] 2^-s   : what the layer's pieces in the stream must be multiplied by to give the weights (the scale IN EFFECT)
 //   [1] max|W| , [2] max|b| of the layer as of the last k_x3stats (the chain kernels bound their activations with them)
-//   [3] 2^s'   : the scale the NEXT (re)pack of the layer uses, chosen from [1] so that max|W| 2^s' is in (2^11, 2^12]
+//   [3] 2^s'   : the scale the NEXT (re)pack of the layer uses, chosen from [1] so that max|W| 2^s' is in [2^11, 2^12)
+//   [4], [5]   : running maxima (fp32 bit patterns, atomicMax as unsigned) of |W|, |b| that whoever rewrites the layer's
+//                parameters accumulates (the finishing kernel; k_x3stats_scan before a full pack); k_x3stats_final turns them
+//                into [1], [2], [3] and clears them
 #define TX_STAGE 16
 #define TX_NP 2
-#define TX_META 4
+#define TX_META 8
 struct NetX3 {
     int32_t in_dim, hidden, depth, skip_at, Lf;
     int32_t NT, KH;               // n-tiles (hidden/32), hidden k-steps (hidden/16)

@@ -618,10 +618,16 @@ __global__ __launch_bounds__(256) void k_finish(FinishArgs f) {
         }
         if (f.scatter3) {                                          // the x3 record stream: two scaled fp16 pieces (as k_packx3)
             const int32_t d0 = f.scatter3[i * f.width3];
+            float* meta = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(f.packed3) + f.n3.meta_off);
             float wsc = 1.0f;
-            if (d0 >= 0 && d0 < f.x3_elems)                        // every position of a weight lies in the same layer
-                wsc = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(f.packed3) + f.n3.meta_off)
-                          [tx_record_layer(&f.n3, (int)(d0 / (f.n3.rec_frags * 512))) * TX_META + 3];
+            int key = -1;                                          // 2 * layer + (bias ? 1 : 0): whose running maximum |pn| belongs to
+            if (d0 >= 0 && d0 < f.x3_elems) {                      // every position of a weight lies in the same layer
+                const int l = tx_record_layer(&f.n3, (int)(d0 / (f.n3.rec_frags * 512)));
+                wsc = meta[l * TX_META + 3]; key = 2 * l;
+            } else if (d0 >= f.x3_elems) {
+                const int bi = (int)(d0 - f.x3_elems);
+                key = 2 * (bi < f.n3.depth * f.n3.hidden ? bi / f.n3.hidden : f.n3.depth) + 1;
+            }
             for (int k = 0; k < f.width3; ++k) {
                 const int32_t d = f.scatter3[i * f.width3 + k];
                 if (d < 0) break;
@@ -630,6 +636,17 @@ __global__ __launch_bounds__(256) void k_finish(FinishArgs f) {
                 } else {
                     reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(f.packed3) + f.n3.bias_off)[d - f.x3_elems] = pn;
                 }
+            }
+            // the layer's running maxima (k_x3stats_final, launched behind this kernel, turns them into the next scale): one
+            // atomic per wave where the whole wave updates the same tensor, per lane at the few tensor boundaries
+            unsigned bits = __float_as_uint(fabsf(pn));
+            const int k0 = __builtin_amdgcn_readfirstlane(key);
+            if (__builtin_popcountll(__ballot(key == k0)) == 64) {
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) bits = max(bits, (unsigned)__shfl_xor((int)bits, o, 64));
+                if ((threadIdx.x & 63) == 0 && k0 >= 0) atomicMax(reinterpret_cast<unsigned*>(meta) + (k0 >> 1) * TX_META + 4 + (k0 & 1), bits);
+            } else if (key >= 0) {
+                atomicMax(reinterpret_cast<unsigned*>(meta) + (key >> 1) * TX_META + 4 + (key & 1), bits);
             }
         }
     }

@@ -17,8 +17,16 @@ class TinyNeRF(nn.Module):
     the gradient all-reduce operate on).
     """
 
-    def __init__(self, in_dim: int, hidden: int = 128, depth: int = 4, skip_at: int = 2):
+    def __init__(self, in_dim: int, hidden: int = 128, depth: int = 4, skip_at: int = 2, *, matrix_pipe=None):
+        """matrix_pipe (keyword only, not in the reference): how the fp32 products are formed —
+        "x3"  (default): three partial products of two-piece fp16 operands on the fp16 matrix pipe (22-23 significant bits per
+                         operand, fp32 accumulation; measured at or below the reference's own fp32 error, DESIGN.md 14);
+        "fp32_mfma"    : v_mfma_f32_32x32x2_f32, plain fp32 fma chains (TNERF_FLAG_FP32_MFMA), ~2.5x slower.
+        None reads the environment variable TNERF_FP32_PIPE (mfma32 -> "fp32_mfma") and otherwise means "x3"."""
         super().__init__()
+        if matrix_pipe not in (None, "x3", "fp32_mfma"):
+            raise ValueError(f"matrix_pipe must be None, 'x3' or 'fp32_mfma', got {matrix_pipe!r}")
+        self.matrix_pipe = matrix_pipe
         self.in_dim, self.hidden, self.depth, self.skip_at = in_dim, hidden, depth, skip_at
         self.layers = nn.ModuleList()
         width = in_dim
@@ -44,7 +52,8 @@ class TinyNeRF(nn.Module):
             skip = self.skip_at if 1 <= self.skip_at <= self.depth - 1 else 0
             if self.skip_at == self.depth:
                 raise RuntimeError("TinyNeRF: skip_at == depth feeds hidden+in_dim features to the heads")
-            st = self._hip = ops.ModelState(self.in_dim, self.hidden, self.depth, skip, dev)
+            flags = None if self.matrix_pipe is None else (ops.FLAG_FP32_MFMA if self.matrix_pipe == "fp32_mfma" else 0)
+            st = self._hip = ops.ModelState(self.in_dim, self.hidden, self.depth, skip, dev, flags)
         if not st.owns(params):          # first use, or some parameter was rebound since: re-adopt all of them
             st.adopt(params)
         return st

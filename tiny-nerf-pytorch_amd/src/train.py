@@ -58,6 +58,7 @@ class Config:
     depth: int = 4
     skip_at: int = 2
     data_path: str = "data/tiny_nerf_data.npz"   # "synthetic" = the seeded stand-in scene (explicit opt-in; a missing file raises)
+    matrix_pipe: Optional[str] = None     # None / "x3": fp16 three-partial-product chain; "fp32_mfma": plain fp32 MFMA (nerf.TinyNeRF)
     gpus: int = 1               # > 1 from a plain shell: spawn that many rank processes (one per GPU, RCCL all-reduce)
     rng: str = "torch"          # "torch": inds / jitter drawn with torch.randint / torch.rand like the reference (parity path);
                                 # "philox": drawn inside the kernels from a device-side step counter — the whole step is one
@@ -175,7 +176,7 @@ def main(cfg: Config):
         print(f"[data] N={N} H={H} W={W} focal={focal:.2f}" + (" (synthetic stand-in)" if d.get("synthetic") else ""))
 
     encoder = PositionalEncoding(num_freqs=cfg.num_freqs, include_input=True).to(device)
-    model = TinyNeRF(in_dim=encoder.out_dim, hidden=cfg.hidden, depth=cfg.depth, skip_at=cfg.skip_at).to(device)
+    model = TinyNeRF(in_dim=encoder.out_dim, hidden=cfg.hidden, depth=cfg.depth, skip_at=cfg.skip_at, matrix_pipe=cfg.matrix_pipe).to(device)
     if cfg.rng not in ("torch", "philox") or (cfg.rng == "philox" and not cfg.fused):
         raise SystemExit("--rng must be 'torch' or 'philox' (philox needs the fused step)")
     if cfg.fused:

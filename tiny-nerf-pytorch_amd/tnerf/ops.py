@@ -17,6 +17,7 @@ import torch
 from . import lib as _l
 
 _NULL = None
+FLAG_FP32_MFMA = _l.FLAG_FP32_MFMA
 
 
 def _stream(dev: torch.device) -> int:
