@@ -578,6 +578,7 @@ def test_hidden_widths_other_than_128_and_256(mods, dev, arch):
         tr = mods["trainer"].DatasetTrainer(m, opt, images.to(dev), poses.to(dev), focal, Rg, S, 2.0, 6.0, seed=seed, precision=prec, record_pixels=True)
         ps = [p.clone() for p in params]
         adam = O.AdamState(ps, lr=5e-4)
+        gmin = None
         for s in range(3):
             loss, _ = tr.step()
             torch.cuda.synchronize()
@@ -586,14 +587,20 @@ def test_hidden_widths_other_than_128_and_256(mods, dev, arch):
             ro, rd = O.pinhole_rays(H, W, focal, poses[s % N])
             lo_, _, grads = O.loss_and_grads(ps, skip, L, ro[pix], rd[pix], pixs[s % N, pix], 2.0, 6.0, S, u)
             assert math.isclose(float(loss), float(lo_), rel_tol=3e-4 if prec == "fp32" else 3e-2), (prec, s, float(loss), float(lo_))
+            go_ = torch.cat([x.reshape(-1) for x in grads])
             if s == 0:                                                     # identical weights on both sides: the gradient itself
-                go_ = torch.cat([x.reshape(-1) for x in grads])
                 assert relmax(m.hip_state().grad.cpu(), go_) <= (1e-3 if prec == "fp32" else 6e-2), (prec, relmax(m.hip_state().grad.cpu(), go_))
+            gmin = go_.abs() if gmin is None else torch.minimum(gmin, go_.abs())
             adam.step(ps, grads)
-        err = max(float((p.detach().cpu() - q).abs().max()) for p, q in zip(m.parameters(), ps))
-        # Adam's first steps move every weight by ~lr * g / (|g| + eps): units of these narrow random-init nets that are (almost)
-        # dead have |g| ~ eps = 1e-8, where fp32 noise in g changes the update by a fraction of lr = 5e-4
-        assert err <= (2.5e-4 if prec == "fp32" else 2e-3), (prec, err)
+        err = torch.cat([(p.detach().cpu() - q).abs().reshape(-1) for p, q in zip(m.parameters(), ps)])
+        # Adam moves a weight by ~lr * g / (|g| + eps) per step: where |g| is within a few orders of eps = 1e-8 (units of these narrow
+        # random-init nets that are almost dead) fp32 noise in g — any evaluation order's — changes the update by a fraction of
+        # lr = 5e-4 (tests/probes/narrow_traj_probe.py: the x3 and the fp32-MFMA kernels deviate from the oracle at the same elements by
+        # the same 1e-4).  Those elements may be off by up to the three steps' 3 lr; every other element must sit on the oracle's.
+        noisy = gmin < 1e-6
+        assert float(err[~noisy].max()) <= (5e-5 if prec == "fp32" else 2e-3), (prec, float(err[~noisy].max()))
+        assert float(err.max()) <= 3 * 5e-4 * 1.01, (prec, float(err.max()))
+        assert int(noisy.sum()) < 0.5 * err.numel()
 
 
 # ------------------------------------------------- the split-bf16 chain kernels against the fp32-MFMA ones, region by region

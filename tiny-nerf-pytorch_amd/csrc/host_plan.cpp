@@ -208,6 +208,7 @@ extern "C" int tnerf_param_layout(const tnerf_mlp_desc* d, int64_t* offsets, int
 namespace {
 struct JobClass {
     int a_row0, a_rows, b_row0, b_rows, n_at, n_bt, wa, has_bias;
+    int a_bound, b_bound;  // TNB_* index of the rows' magnitude bound
     int cost;              // max 32x32 tiles per wave
     int chunks;            // workgroups
     int64_t slab0;         // float offset of chunk 0
@@ -238,8 +239,9 @@ static void pick_split(int n_at, int n_bt, int* wa_out, int* cost_out) {
 static int build_classes(const MlpLayout& L, int64_t M, int n_cu, std::vector<JobClass>& cls, int64_t* slab_total) {
     const int H = L.hidden, NT = L.NT, encT = (2 * L.NE + 31) / 32;
     bool bad_split = false;
-    auto add = [&](int a0, int ar, int b0, int br, int nat, int nbt, int bias) {
+    auto add = [&](int a0, int ar, int b0, int br, int nat, int nbt, int bias, int ab, int bb) {
         JobClass c{}; c.a_row0 = a0; c.a_rows = ar; c.b_row0 = b0; c.b_rows = br; c.n_at = nat; c.n_bt = nbt; c.has_bias = bias;
+        c.a_bound = ab; c.b_bound = bb;
         pick_split(nat, nbt, &c.wa, &c.cost); cls.push_back(c);
         if (c.wa == 0) bad_split = true;
     };
@@ -248,10 +250,10 @@ static int build_classes(const MlpLayout& L, int64_t M, int n_cu, std::vector<Jo
     //   [0]                 : (dZ_0, ENC)         owns b_0
     //   [depth]             : (dZ_skip, ENC)      (only if skip)
     //   [last]              : (dZ_head, H_{depth-1}) owns head biases
-    add(L.dz_row0[0], H, L.enc_row0, 2 * L.NE, NT, encT, 1);
-    for (int l = 1; l < L.depth; ++l) add(L.dz_row0[l], H, L.h_row0[l - 1], H, NT, NT, 1);
-    if (L.skip_at > 0) add(L.dz_row0[L.skip_at], H, L.enc_row0, 2 * L.NE, NT, encT, 0);
-    add(L.dzh_row0, 4, L.h_row0[L.depth - 1], H, 1, NT, 1);
+    add(L.dz_row0[0], H, L.enc_row0, 2 * L.NE, NT, encT, 1, TNB_DZ(0), TNB_ENC);
+    for (int l = 1; l < L.depth; ++l) add(L.dz_row0[l], H, L.h_row0[l - 1], H, NT, NT, 1, TNB_DZ(l), TNB_H(l - 1));
+    if (L.skip_at > 0) add(L.dz_row0[L.skip_at], H, L.enc_row0, 2 * L.NE, NT, encT, 0, TNB_DZ(L.skip_at), TNB_ENC);
+    add(L.dzh_row0, 4, L.h_row0[L.depth - 1], H, 1, NT, 1, TNB_DZH, TNB_H(L.depth - 1));
     if (bad_split) { tn_set_error("wgrad: no kernel for this layer-shape / wave split"); return TNERF_EUNSUPPORTED; }
     if ((int)cls.size() > TN_RED_MAXCLS) { tn_set_error("too many wgrad job classes"); return TNERF_EUNSUPPORTED; }
     const int64_t MB = (M + 31) / 32;
@@ -298,7 +300,7 @@ extern "C" int tnerf_plan_sizes_query(const tnerf_mlp_desc* d, int64_t M, int32_
     const int64_t Mp = (M + 63) / 64 * 64;
     out->n_params = L.n_params;
     out->packed_floats = L.packed_floats;
-    out->stash_floats = TN_STASH_BODY_FLOATS(L, Mp) + TN_MASK_FLOATS(L, Mp);
+    out->stash_floats = TN_BOUND_OFF(L, Mp) + TN_BOUND_FLOATS;
     out->slab_floats = slab;
     out->job_ints = jobs * TN_JOB_INTS;
     out->reduce_ints = TN_RED_HDR + 2 * L.n_params;
@@ -380,6 +382,7 @@ extern "C" int tnerf_plan_fill(const tnerf_mlp_desc* d, int64_t M, int32_t n_cu,
                 r[JOB_MBLKN] = (int32_t)std::max<int64_t>(0, std::min<int64_t>(per, MB - ch * per));
                 r[JOB_SLAB_OFF] = (int32_t)(c.slab0 + c.slab_stride * ch);
                 r[JOB_CLASS] = (int32_t)ci; r[JOB_HAS_BIAS] = c.has_bias;
+                r[JOB_A_BOUND] = c.a_bound; r[JOB_B_BOUND] = c.b_bound;
                 ++j;
             }
     }

@@ -38,7 +38,7 @@ struct TxIn { float encmax, l1; int te; };
 // the skip layer).
 template <int HID, bool TRAIN>
 __device__ __forceinline__ void tx_mlp_tile(PipeX& p, const unsigned char* lds, const FwdX3Args& a, int h, int lane, unsigned char* E, const TxIn& in,
-                                            const float (&encf)[8 * TN16_KE], int64_t m, bool valid, float (&res)[4], TxProf& pf) {
+                                            const float (&encf)[8 * TN16_KE], int64_t m, bool valid, float (&res)[4], TxProf& pf, unsigned char* lds_bnd) {
     constexpr int NT = HID / 32;
     const MlpLayout& L = a.f.L;
     const int depth = a.n.depth, skip_at = a.n.skip_at;
@@ -75,9 +75,11 @@ __device__ __forceinline__ void tx_mlp_tile(PipeX& p, const unsigned char* lds, 
         float bound = __builtin_fmaf(mt[1], l1_in, mt[2]);
         if (l + 1 == skip_at) bound = fmaxf(bound, in.encmax);     // the skip layer's input pieces share this layer's output scale
         const int t_out = tx_scale_exp(bound);
+        if constexpr (TRAIN) tx_bound_note(lds_bnd, TNB_H(l), bound);          // this layer's rows of the stash, for the weight-gradient kernel
         sc.dsc = mt[0] * tx_exp2i(-t_prev); sc.osc = tx_exp2i(t_out); sc.l1 = f32x2{0.0f, 0.0f};
         t_prev = t_out;
     };
+    if constexpr (TRAIN) tx_bound_note(lds_bnd, TNB_ENC, in.encmax);
     // steps 0..3 = part V, 4..9 = part S    (mlpx3_core.hpp)
     auto epi_full = [&](auto halfc, auto& acc, auto ic, auto kc) TN_INLINE_LAMBDA {
         constexpr int HALF = decltype(halfc)::value, I = decltype(ic)::value, K = decltype(kc)::value;
@@ -140,7 +142,9 @@ __global__ __launch_bounds__((TxCfg<HID, TRAIN>::NW * 64), 1) void k_renderx3(Fw
     if (TRAIN) tn_resolve_step(rs, sa);                            // dataset mode: this step's image and Philox counters
     const int S = sa.S, Lf = a.n.Lf;
     PipeX p;
-    tx_prologue<NW>(p, lds, a.packed3, a.n, a.packed3, a.n.n_stage, lane, wave);
+    unsigned char* lds_bnd0 = lds + TX_BND_OFF(a.n, NW, true);
+    unsigned char* lds_bnd = lds_bnd0 + lane * 4;                  // this lane's bound words (forward: TNB_H(l) = l, TNB_ENC)
+    tx_prologue<NW>(p, lds, a.packed3, a.n, a.packed3, a.n.n_stage, lane, wave, TRAIN ? lds_bnd0 : nullptr);
     unsigned char* E = lds + TX_RING + TX_CONST_BYTES(a.n) + wave * TX_ELDS_WAVE + lane * 16;      // this lane's input pieces
     TxProf pf;
 #ifdef TN_STAMPS
@@ -180,7 +184,7 @@ __global__ __launch_bounds__((TxCfg<HID, TRAIN>::NW * 64), 1) void k_renderx3(Fw
                 tx_split_input(Er, tx_exp2i(in.te), [&](auto ac) TN_INLINE_LAMBDA { return encf[decltype(ac)::value]; });
                 tx_store_input(E, Er);
                 float res[4];
-                tx_mlp_tile<HID, TRAIN>(p, lds, a, h, lane, E, in, encf, rayc * S + sc, valid, res, pf);
+                tx_mlp_tile<HID, TRAIN>(p, lds, a, h, lane, E, in, encf, rayc * S + sc, valid, res, pf, lds_bnd);
                 const bool upper = (sb & 32) != 0;                            // wave-uniform
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -219,6 +223,7 @@ __global__ __launch_bounds__((TxCfg<HID, TRAIN>::NW * 64), 1) void k_renderx3(Fw
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // no DMA may still be writing this workgroup's LDS at exit
+    if constexpr (TRAIN) tx_bound_flush<NW>(lds_bnd0, a.f.stash + TN_BOUND_OFF(a.f.L, a.f.Mp), 0, lane, wave);
 #ifdef TN_STAMPS
     if (a.f.stamps && lane == 0) {
         unsigned long long* o = a.f.stamps + (blockIdx.x * NW + wave) * 8;
@@ -258,7 +263,7 @@ template <> struct TxMask<2> {
 // dzh[4]: this lane's head gradients (r,g,b,sigma pre-activation) for sample m.
 template <int HID>
 __device__ __forceinline__ void tx_bwd_tile(PipeX& p, const unsigned char* lds, const BwdX3Args& a, const float (&dzh)[4], int64_t m, bool valid,
-                                            int lane) {
+                                            int lane, unsigned char* lds_bnd) {
     constexpr int NT = HID / 32;
     const MlpLayout& L = a.b.L;
     const int h = lane >> 5, depth = a.n.depth;
@@ -276,6 +281,7 @@ __device__ __forceinline__ void tx_bwd_tile(PipeX& p, const unsigned char* lds, 
     // scale of the head gradient: its largest magnitude; the bound on dH_{depth-1} = W_head^T dZ_head: max|W_head| ||dZ_head||_1
     const float zmax = fmaxf(fmaxf(fabsf(dzh[0]), fabsf(dzh[1])), fmaxf(fabsf(dzh[2]), fabsf(dzh[3])));
     int t_prev = tx_scale_exp(zmax);
+    tx_bound_note(lds_bnd, TNB_DZH - TNB_DZ(0), zmax);
     {
         const float zs = tx_exp2i(t_prev);
         unsigned a0, b0, a1, b1;
@@ -295,6 +301,7 @@ __device__ __forceinline__ void tx_bwd_tile(PipeX& p, const unsigned char* lds, 
     auto scale_for = [&](int l, float l1_in) TN_INLINE_LAMBDA {
         const f32x4 mt = tx_meta(lds, a.n, l);
         const int t_out = tx_scale_exp(mt[1] * l1_in);
+        tx_bound_note(lds_bnd, l - 1, mt[1] * l1_in);                          // bounds dH_{l-1}, hence dZ_{l-1} (local index of TNB_DZ(l - 1))
         sc.dsc = mt[0] * tx_exp2i(-t_prev); sc.osc = tx_exp2i(t_out); sc.l1 = f32x2{0.0f, 0.0f};
         t_prev = t_out;
     };
@@ -352,7 +359,9 @@ __global__ __launch_bounds__(TxCfg<HID>::NW * 64, 1) void k_dgradx3(BwdX3Args a)
     const int S = sa.S;
     const int nseg = (S + 63) / 64;
     PipeX p;
-    tx_prologue<NW>(p, lds, a.packed3, a.n, a.packed3 + (int64_t)a.n.n_rec * a.n.rec_frags * 1024, a.n.n_bw_stage, lane, wave);
+    unsigned char* lds_bnd0 = lds + TX_BND_OFF(a.n, NW, false);
+    unsigned char* lds_bnd = lds_bnd0 + lane * 4;                  // this lane's bound words (dgrad: TNB_DZ(l) .. TNB_DZH, minus TNB_DZ(0))
+    tx_prologue<NW>(p, lds, a.packed3, a.n, a.packed3 + (int64_t)a.n.n_rec * a.n.rec_frags * 1024, a.n.n_bw_stage, lane, wave, lds_bnd0);
     const int64_t R = a.b.R;
     const int64_t n_groups = (R + NW - 1) / NW;
     const int orow = a.b.L.out_row0 * 32; const int64_t SR = a.b.L.stash_rows;
@@ -417,11 +426,12 @@ __global__ __launch_bounds__(TxCfg<HID>::NW * 64, 1) void k_dgradx3(BwdX3Args a)
                 for (int i = 0; i < 4; ++i) dzh[i] = __shfl(d4[i], 32 * half + (lane & 31), 64);
                 const int st = sb + (lane & 31);
                 const bool valid = rvalid && st < S;
-                tx_bwd_tile<HID>(p, lds, a, dzh, rayc * S + (st < S ? st : S - 1), valid, lane);
+                tx_bwd_tile<HID>(p, lds, a, dzh, rayc * S + (st < S ? st : S - 1), valid, lane, lds_bnd);
             }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    tx_bound_flush<NW>(lds_bnd0, a.b.stash + TN_BOUND_OFF(a.b.L, a.b.Mp), TNB_DZ(0), lane, wave);
 }
 
 // ------------------------------------------------------------------------------------------------ MLP only
@@ -448,7 +458,9 @@ __global__ __launch_bounds__((TxCfg<HID, TRAIN>::NW * 64), 1) void k_mlpx3_fwd(F
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int j = lane & 31, h = lane >> 5;
     PipeX p;
-    tx_prologue<NW>(p, lds, a.packed3, a.n, a.packed3, a.n.n_stage, lane, wave);
+    unsigned char* lds_bnd0 = lds + TX_BND_OFF(a.n, NW, true);
+    unsigned char* lds_bnd = lds_bnd0 + lane * 4;                  // this lane's bound words (forward: TNB_H(l) = l, TNB_ENC)
+    tx_prologue<NW>(p, lds, a.packed3, a.n, a.packed3, a.n.n_stage, lane, wave, TRAIN ? lds_bnd0 : nullptr);
     unsigned char* E = lds + TX_RING + TX_CONST_BYTES(a.n) + wave * TX_ELDS_WAVE + lane * 16;
     TxProf pf;
     const int64_t M = a.f.M, n_tiles = (M + 31) / 32, n_groups = (n_tiles + NW - 1) / NW;
@@ -470,7 +482,7 @@ __global__ __launch_bounds__((TxCfg<HID, TRAIN>::NW * 64), 1) void k_mlpx3_fwd(F
         tx_split_input(Er, tx_exp2i(in.te), [&](auto ac) TN_INLINE_LAMBDA { return encf[decltype(ac)::value]; });
         tx_store_input(E, Er);
         float res[4];
-        tx_mlp_tile<HID, TRAIN>(p, lds, a, h, lane, E, in, encf, mc, valid, res, pf);
+        tx_mlp_tile<HID, TRAIN>(p, lds, a, h, lane, E, in, encf, mc, valid, res, pf, lds_bnd);
         if (valid && h == 0) {
             a.f.rgb_out[3 * m + 0] = res[0]; a.f.rgb_out[3 * m + 1] = res[1]; a.f.rgb_out[3 * m + 2] = res[2];
             a.f.sigma_out[m] = res[3];
@@ -481,6 +493,7 @@ __global__ __launch_bounds__((TxCfg<HID, TRAIN>::NW * 64), 1) void k_mlpx3_fwd(F
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (TRAIN) tx_bound_flush<NW>(lds_bnd0, a.f.stash + TN_BOUND_OFF(a.f.L, a.f.Mp), 0, lane, wave);
 }
 
 template <int HID>
@@ -490,7 +503,9 @@ __global__ __launch_bounds__(TxCfg<HID>::NW * 64, 1) void k_mlpx3_bwd(BwdX3Args 
     const int lane = tn_lane();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     PipeX p;
-    tx_prologue<NW>(p, lds, a.packed3, a.n, a.packed3 + (int64_t)a.n.n_rec * a.n.rec_frags * 1024, a.n.n_bw_stage, lane, wave);
+    unsigned char* lds_bnd0 = lds + TX_BND_OFF(a.n, NW, false);
+    unsigned char* lds_bnd = lds_bnd0 + lane * 4;                  // this lane's bound words (dgrad: TNB_DZ(l) .. TNB_DZH, minus TNB_DZ(0))
+    tx_prologue<NW>(p, lds, a.packed3, a.n, a.packed3 + (int64_t)a.n.n_rec * a.n.rec_frags * 1024, a.n.n_bw_stage, lane, wave, lds_bnd0);
     const int64_t M = a.b.M, n_tiles = (M + 31) / 32, n_groups = (n_tiles + NW - 1) / NW;
     for (int64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
         const int64_t m = (g * NW + wave) * 32 + (lane & 31);
@@ -504,9 +519,10 @@ __global__ __launch_bounds__(TxCfg<HID>::NW * 64, 1) void k_mlpx3_bwd(BwdX3Args 
         }
         const float sg = tn_stash_at(a.b.stash, a.b.L.stash_rows, mc)[(a.b.L.out_row0 + 3) * 32];
         dzh[3] = (valid && sg > 0.0f) ? a.b.d_sigma[mc] : 0.0f;                            // ReLU backward
-        tx_bwd_tile<HID>(p, lds, a, dzh, mc, valid, lane);
+        tx_bwd_tile<HID>(p, lds, a, dzh, mc, valid, lane, lds_bnd);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    tx_bound_flush<NW>(lds_bnd0, a.b.stash + TN_BOUND_OFF(a.b.L, a.b.Mp), TNB_DZ(0), lane, wave);
 }
 
 // units: rays (fused) or 32-sample tiles (mlp_only) — one per wave and pass
@@ -540,6 +556,10 @@ int tnx3_train_dgrad(const char* who, const BwdArgs& b, const tnerf_mlp_desc* d,
 
 int tnx3_launch_fwd(const FwdX3Args& a, bool train, hipStream_t stream, const char* who, bool mlp_only = false) {
     const int dev = tn_stream_device(stream), n_cu = tn_device_cus(dev);
+    if (train) {       // the stash's magnitude bounds start from zero with every training forward (the dgrad kernel adds its own)
+        const hipError_t e = hipMemsetAsync(a.f.stash + TN_BOUND_OFF(a.f.L, a.f.Mp), 0, TN_BOUND_FLOATS * 4, stream);
+        if (e != hipSuccess) { tn_set_error("%s: hipMemsetAsync: %s", who, hipGetErrorString(e)); return (int)e; }
+    }
     const int nw = a.n.hidden == 256 ? 4 : (train ? TxCfg<128, true>::NW : TxCfg<128, false>::NW);
     const int64_t units = mlp_only ? (a.f.M + 31) / 32 : a.f.R, groups = (units + nw - 1) / nw;
     const dim3 grid((unsigned)(groups < n_cu ? groups : n_cu)), block(nw * 64);

@@ -46,6 +46,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define TX_RING (TX_NS * TX_SLOT)              // 112 KB
 #define TX_LEAD 5                              // stages in flight behind the published one (LEAD + 2 <= NS)
 #define TX_TOP 14                              // scaled activations stay below 2^TX_TOP
+#define TX_BND_N (TN_MAXD + 1)                 // row groups whose magnitude bounds a training kernel keeps (see TX_BND_OFF)
 template <int HID, bool TRAIN_FWD = false> struct TxCfg {
     static constexpr int NW = 4;                                  // one wave per SIMD (the split accumulators need its 512 registers)
     static constexpr int DPW = TX_STAGE / NW;                     // DMA pieces per wave and stage
@@ -133,13 +134,17 @@ __device__ __forceinline__ void tx_boundary(PipeX& p) {
 // publishes stage 0.  `src` / `n_stage`: the stream this kernel walks (forward: packed, n.n_stage; dgrad: the backward stream).
 template <int NW>
 __device__ __forceinline__ void tx_prologue(PipeX& p, unsigned char* lds, const unsigned char* packed, const NetX3& n,
-                                            const unsigned char* src, int n_stage, int lane, int wave) {
+                                            const unsigned char* src, int n_stage, int lane, int wave, unsigned char* lds_bnd = nullptr) {
     constexpr int DPW = TX_STAGE / NW;
     {
         float* bl = reinterpret_cast<float*>(lds + TX_RING);
         const float* bg = reinterpret_cast<const float*>(packed + n.bias_off);
         const int nf = n.n_bias + (n.depth + 1) * TX_META;            // the scale records follow the biases
         for (int i = threadIdx.x; i < nf; i += NW * 64) bl[i] = bg[i];
+    }
+    if (lds_bnd) {                                                   // the bound words start at zero
+        for (int i = threadIdx.x; i < TX_BND_N * 64; i += NW * 64) reinterpret_cast<unsigned*>(lds_bnd)[i] = 0u;
+        __syncthreads();
     }
     p.lane16 = lane * 16;
     p.src = src; p.src_off = 0; p.stream_bytes = (uint32_t)n_stage * TX_SLOT;
@@ -155,7 +160,31 @@ __device__ __forceinline__ void tx_prologue(PipeX& p, unsigned char* lds, const 
 // Behind the ring and the constants: the network-input pieces of every wave's tile (forward kernels; [piece][k-step][lane] x 16 B).
 // They are needed by layer 0 and again by the skip layer: parked in LDS they do not hold 32 registers through the layers between.
 #define TX_ELDS_WAVE (TX_NP * TN16_KE * 1024)
-#define TX_LDS_BYTES(n, nw, fwd) ((size_t)TX_RING + TX_CONST_BYTES(n) + ((fwd) ? (size_t)(nw) * TX_ELDS_WAVE : 0))
+// ... and the workgroup's running maxima of the per-sample bounds (training kernels): what the weight-gradient kernel scales its
+// operand rows by.  TX_BND_N row groups (forward: H_0.., the input; dgrad: dZ_0.., the head gradient — TNB_* minus the kernel's
+// first index) x 64 lanes: every lane keeps its own word (ds_max_u32 on per-lane addresses: one instruction, no conflict between
+// the lanes of a wave; a wave-uniform address would make hipcc emit a 64-step scalar reduction loop and an EXEC-masked atomic in
+// the middle of the MFMA stream), reduced over lanes and added to the stash's bound words once, at the end of the kernel.
+#define TX_BND_OFF(n, nw, fwd) (TX_RING + TX_CONST_BYTES(n) + ((fwd) ? (uint32_t)(nw) * TX_ELDS_WAVE : 0u))
+#define TX_LDS_BYTES(n, nw, fwd) ((size_t)TX_BND_OFF(n, nw, fwd) + TX_BND_N * 64 * 4)
+// lds_bnd: this LANE's word of row group 0; idx: local row-group index
+__device__ __forceinline__ void tx_bound_note(unsigned char* lds_bnd, int idx, float bound) {
+#ifdef TX_NO_BOUND_NOTE
+    return;
+#endif
+    atomicMax(reinterpret_cast<unsigned*>(lds_bnd) + idx * 64, __float_as_uint(bound));      // bounds are >= 0: their bit patterns order like the values
+}
+// end of a training kernel: the workgroup's maxima -> the stash's bound words bounds[first + idx]
+template <int NW>
+__device__ __forceinline__ void tx_bound_flush(const unsigned char* lds_bnd0, float* __restrict__ bounds, int first, int lane, int wave) {
+    __syncthreads();
+    for (int idx = wave; idx < TX_BND_N; idx += NW) {
+        unsigned v = reinterpret_cast<const unsigned*>(lds_bnd0)[idx * 64 + lane];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, o, 64));
+        if (lane == 0 && v) atomicMax(reinterpret_cast<unsigned*>(bounds) + first + idx, v);
+    }
+}
 // scale record of layer l (l = depth: heads) in the LDS copy: {2^-s, max|W|, max|b|, -}
 __device__ __forceinline__ f32x4 tx_meta(const unsigned char* lds, const NetX3& n, int l) {
     return *reinterpret_cast<const f32x4*>(lds + TX_RING + (n.n_bias + l * TX_META) * 4);

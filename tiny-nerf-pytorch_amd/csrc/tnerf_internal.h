@@ -12,8 +12,18 @@
 // Record layout of one wgrad job (one workgroup).
 enum {
     JOB_A_ROW0 = 0, JOB_A_ROWS, JOB_B_ROW0, JOB_B_ROWS, JOB_N_AT, JOB_N_BT, JOB_WA,
-    JOB_MBLK0, JOB_MBLKN, JOB_SLAB_OFF, JOB_CLASS, JOB_HAS_BIAS
+    JOB_MBLK0, JOB_MBLKN, JOB_SLAB_OFF, JOB_CLASS, JOB_HAS_BIAS,
+    JOB_A_BOUND, JOB_B_BOUND        // indices into the stash's bound words (TNB_*) of the rows' magnitude bounds
 };
+// Magnitude bounds of the stash's row groups, over all samples of the batch (fp32 bit patterns, atomicMax as unsigned; they sit
+// behind the sign words of the stash: TN_BOUND_FLOATS words).  The x3 training forward / dgrad kernels maintain them (each sample's
+// activation bound is what scales its fp16 pieces, mlpx3_core.hpp), the weight-gradient kernel scales the rows it splits into
+// fp16 pieces by them.  The training forward's launcher clears them.
+#define TN_BOUND_FLOATS 64
+#define TNB_H(l) (l)                      // layer l's activations
+#define TNB_ENC TN_MAXD                   // the network input
+#define TNB_DZ(l) (TN_MAXD + 1 + (l))     // layer l's activation gradients
+#define TNB_DZH (2 * TN_MAXD + 1)         // the head gradient
 
 // Everything the kernels need to know about one model; passed by value as a kernel argument.
 struct MlpLayout {
@@ -147,6 +157,7 @@ void tn_set_error(const char* fmt, ...);
 // that no store in the hot loops needs a per-lane branch.
 #define TN_STASH_BODY_FLOATS(L, Mp) ((int64_t)(L).stash_rows * ((Mp) + 32))
 #define TN_MASK_FLOATS(L, Mp) ((int64_t)(L).depth * ((Mp) + 32) * ((L).hidden / 32))
+#define TN_BOUND_OFF(L, Mp) (TN_STASH_BODY_FLOATS(L, Mp) + TN_MASK_FLOATS(L, Mp))      // float offset of the bound words
 
 // row of a 32x32 MFMA accumulator register r (0..15) for lane-half h (0/1)
 #define TN_ACC_ROW(r, h) (((r) & 3) + 8 * ((r) >> 2) + 4 * (h))

@@ -32,7 +32,8 @@ extern "C" int tnerf_mlp_bwd(const tnerf_mlp_desc* d, const float* packed, int64
     a.packed = packed; a.stash = stash; a.Mp = Mp; a.M = M; a.d_rgb = d_rgb; a.d_sigma = d_sigma;
     hipStream_t s = (hipStream_t)stream;
     if ((rc = tn_launch_mlp_bwd(a, s))) return rc;
-    if ((rc = tn_launch_wgrad(stash, a.L.stash_rows, M, job_table, n_jobs, slabs, nullptr, s, !(a.L.flags & TNERF_FLAG_FP32_MFMA)))) return rc;
+    // (the x3 weight-gradient kernel scales its operands by bounds only the x3 chain kernels leave in the stash)
+    if ((rc = tn_launch_wgrad(stash, a.L.stash_rows, M, job_table, n_jobs, slabs, nullptr, s, false))) return rc;
     return tn_launch_reduce(slabs, reduce_table, a.L.n_params, grads, s);
 }
 
@@ -47,7 +48,7 @@ extern "C" int tnerf_mlp_bwd_x3(const tnerf_mlp_desc* d, const void* packed_x3, 
     a.packed = nullptr; a.stash = stash; a.Mp = Mp; a.M = M; a.d_rgb = d_rgb; a.d_sigma = d_sigma;
     hipStream_t s = (hipStream_t)stream;
     if ((rc = tnx3_mlp_dgrad(who, a, d, packed_x3, s))) return rc;
-    if ((rc = tn_launch_wgrad(stash, a.L.stash_rows, M, job_table, n_jobs, slabs, nullptr, s, !(a.L.flags & TNERF_FLAG_FP32_MFMA)))) return rc;
+    if ((rc = tn_launch_wgrad(stash, a.L.stash_rows, M, job_table, n_jobs, slabs, nullptr, s, !(a.L.flags & TNERF_FLAG_FP32_MFMA), stash + TN_BOUND_OFF(a.L, Mp)))) return rc;
     return tn_launch_reduce(slabs, reduce_table, a.L.n_params, grads, s);
 }
 
@@ -65,10 +66,11 @@ static int train_bwd_impl(const char* who, const tnerf_mlp_desc* d, const float*
     a.L = f.L; a.packed = packed; a.stash = stash; a.Mp = Mp; a.rs = f.rs; a.R = R; a.sa = f.sa;
     a.sa.step = sr.step; a.sa.per_step = sr.per_step;
     a.white = white; a.g_comp = g_comp; a.g_stride = g_stride;
-    if (packed3 && !(d->flags & TNERF_FLAG_FP32_MFMA)) rc = tnx3_train_dgrad(who, a, d, packed3, s);
-    else                                                rc = tn_launch_train_bwd(a, s);
+    const bool x3 = packed3 && !(d->flags & TNERF_FLAG_FP32_MFMA);
+    if (x3) rc = tnx3_train_dgrad(who, a, d, packed3, s);
+    else    rc = tn_launch_train_bwd(a, s);
     if (rc) return rc;
-    if ((rc = tn_launch_wgrad(stash, a.L.stash_rows, R * S, job_table, n_jobs, slabs, sr.step, s, !(a.L.flags & TNERF_FLAG_FP32_MFMA)))) return rc;
+    if ((rc = tn_launch_wgrad(stash, a.L.stash_rows, R * S, job_table, n_jobs, slabs, sr.step, s, x3, stash + TN_BOUND_OFF(a.L, Mp)))) return rc;
     if (!reduce_table) return TNERF_OK;
     return tn_launch_reduce(slabs, reduce_table, a.L.n_params, grads, s);
 }
@@ -115,7 +117,7 @@ extern "C" int tnerf_wgrad(const tnerf_mlp_desc* d, const float* stash, int64_t 
                            float* slabs, tnerf_stream_t stream) {
     MlpLayout L; int rc = tn_build_layout(d, &L); if (rc) return rc;
     if (!stash || Mp < M || M < 1 || !job_table || n_jobs < 1 || !slabs) { tn_set_error("tnerf_wgrad: bad arguments"); return TNERF_EINVAL; }
-    return tn_launch_wgrad(stash, L.stash_rows, M, job_table, n_jobs, slabs, nullptr, (hipStream_t)stream, !(L.flags & TNERF_FLAG_FP32_MFMA));
+    return tn_launch_wgrad(stash, L.stash_rows, M, job_table, n_jobs, slabs, nullptr, (hipStream_t)stream, !(L.flags & TNERF_FLAG_FP32_MFMA), stash + TN_BOUND_OFF(L, Mp));
 }
 
 extern "C" int tnerf_wgrad_reduce(const float* slabs, const int32_t* reduce_table, int64_t n_params, float* grads, tnerf_stream_t stream) {

@@ -16,8 +16,8 @@
 // The WX_* knobs below strip parts of the split-bf16 kernel for ablation timings (tools/wgrad_x3_probe.py) and produce WRONG
 // numerics.  They only compile in a diagnostic build (tools/build_variant.sh passes -DTN_DIAG): a stray -DWX_... on the product
 // build is a hard error instead of a library that silently ships garbage.
-#if (defined(WX_NO_SPLIT) || defined(WX_ONE_MFMA) || defined(WX_NO_CONVERT) || defined(WX_NO_PIN)) && !defined(TN_DIAG)
-#error "WX_NO_SPLIT / WX_ONE_MFMA / WX_NO_CONVERT / WX_NO_PIN are diagnostic knobs with wrong numerics: build with -DTN_DIAG (tools/build_variant.sh)"
+#if (defined(WX_ONE_MFMA) || defined(WX_NO_CONVERT) || defined(WX_NO_PIN)) && !defined(TN_DIAG)
+#error "WX_ONE_MFMA / WX_NO_CONVERT / WX_NO_PIN are diagnostic knobs with wrong numerics: build with -DTN_DIAG (tools/build_variant.sh)"
 #endif
 
 #define WG_LDS_ROWS 256                       // per operand
@@ -26,44 +26,9 @@
 // LDS image of one operand block: row r holds its 8 16-byte chunks permuted by (r>>1)&7.
 __device__ __forceinline__ int wg_lds_off(int row, int chunk) { return row * 32 + ((chunk ^ ((row >> 1) & 7)) << 2); }
 
-// fp32 products on the bf16 matrix pipe, exactly: an fp32 value is the sum of three bf16 numbers (its 24-bit mantissa cut
-// into 8 + 8 + 8 bits: x = p1 + p2 + p3 with p1 = x truncated to bf16, p2 = (x - p1) truncated, p3 = the rest — every step
-// exact), a product of two bf16 numbers is exact in fp32, so  a*b = sum_ij a_i b_j  with nothing lost but the three smallest
-// terms (a2 b3, a3 b2, a3 b3 <= 2^-24 |ab|: below one fp32 rounding).  Six v_mfma_f32_32x32x16_bf16 (fp32 accumulate) thus
-// give a dot product that is as accurate as — measured: slightly more accurate than — the fp32 MFMA's fma chain, at 6/16 of
-// its matrix-pipe time.  8 consecutive fp32 (lo, hi) -> three 8-element bf16 operand registers.
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void tn_split3(const f32x4& lo, const f32x4& hi, bf16x8_t& p1, bf16x8_t& p2, bf16x8_t& p3) {
-    u32x4_t w1, w2, w3;
-#ifdef WX_NO_SPLIT      // diagnostic build (tools/wgrad_x3_probe.py): the operand packing only, WRONG numerics
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const uint32_t u0 = __float_as_uint(e < 2 ? lo[2 * e] : hi[2 * e - 4]), u1 = __float_as_uint(e < 2 ? lo[2 * e + 1] : hi[2 * e - 3]);
-        w1[e] = __builtin_amdgcn_perm(u1, u0, 0x07060302u); w2[e] = w1[e]; w3[e] = w1[e];
-    }
-    p1 = __builtin_bit_cast(bf16x8_t, w1); p2 = __builtin_bit_cast(bf16x8_t, w2); p3 = __builtin_bit_cast(bf16x8_t, w3);
-    return;
-#endif
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        // two elements at a time: the subtractions are packed (v_pk_add_f32), the truncations are bit masks, v_perm_b32
-        // gathers the two high halves into one operand dword
-        const f32x2_t x = {e < 2 ? lo[2 * e] : hi[2 * e - 4], e < 2 ? lo[2 * e + 1] : hi[2 * e - 3]};
-        const u32x2_t u = __builtin_bit_cast(u32x2_t, x);
-        const f32x2_t r = x - __builtin_bit_cast(f32x2_t, u & 0xFFFF0000u);
-        const u32x2_t v = __builtin_bit_cast(u32x2_t, r);
-        const f32x2_t t = r - __builtin_bit_cast(f32x2_t, v & 0xFFFF0000u);
-        const u32x2_t w = __builtin_bit_cast(u32x2_t, t);                            // <= 8 significant bits left: exact
-        w1[e] = __builtin_amdgcn_perm(u[1], u[0], 0x07060302u);                       // (hi16 of x1) : (hi16 of x0)
-        w2[e] = __builtin_amdgcn_perm(v[1], v[0], 0x07060302u);
-        w3[e] = __builtin_amdgcn_perm(w[1], w[0], 0x07060302u);
-    }
-    p1 = __builtin_bit_cast(bf16x8_t, w1); p2 = __builtin_bit_cast(bf16x8_t, w2); p3 = __builtin_bit_cast(bf16x8_t, w3);
-}
-#define TN_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 
 template <int TA, int TB>
 __device__ __forceinline__ void wgrad_body(const float* __restrict__ stash, int64_t stash_rows, int64_t M, const int32_t* __restrict__ job,
@@ -215,48 +180,46 @@ __device__ __forceinline__ void wgrad_body(const float* __restrict__ stash, int6
     }
 }
 
-// ------------------------------------------------------------------------------------- split-bf16 ("x3") body
+// ------------------------------------------------------------------------------------- "x3" body: three partial products
 // The same job (an (A rows x B rows) block of <= 256 x 256 outputs for a chunk of samples, 8 waves, <= 2 x 4 tiles per wave)
-// with the products on the bf16 matrix pipe (tn_split3 above).  Its MFMA time per 32 samples is 6/16 of the fp32 form's, so
-// everything else had to shrink with it (tools/wgrad_x3_probe.py: splitting the operands in every wave that uses them — each
-// A tile in 2 waves, each B tile in 4 — made the kernel VALU-issue-bound at 10k cycles per block against 6.1k of MFMA):
+// with the products on the fp16 matrix pipe, as in the chain kernels (mlpx3_core.hpp): every fp32 operand value, scaled by a
+// power of two into the fp16 range, is two fp16 pieces (round to nearest), a product = a1 b1 + a1 b2 + a2 b1, fp32 accumulation.
+// The scales are per ROW GROUP and batch: 2^(14 - exponent(bound)) with the magnitude bounds the chain kernels left behind the
+// stash (TNB_*): dZ_l rows and H_l rows each share one scale, so a sum over samples needs no per-sample bookkeeping; elements far
+// below the bound lose relative, never absolute precision (<= 2^-39 of the bound).  ONE accumulator: unlike in the chain
+// kernels nothing here is cut by the matrix pipe's floor that the split would save (tools/microbench/split_schemes.py: the
+// weight gradients are as close to fp64 with one accumulator as with two, or with an fp32 fma chain).
 //   * every operand element is split ONCE per workgroup: the 512 threads fetch a 16-sample STAGE of the job's rows straight
-//     from the stash into registers (buffer loads, 4 lanes per 64-byte row half), two stages ahead; split it; and write the
-//     three bf16 pieces into an LDS image laid out as MFMA operands (row-piece = 16 samples = 32 B);
-//   * the MFMA phase is VALU-free: one ds_read_b128 per (tile, piece) and k-step, six MFMAs per tile pair;
+//     from the stash into registers (buffer loads, 4 lanes per 64-byte row half), two stages ahead; scale and split it; and
+//     write the two pieces into an LDS image laid out as MFMA operands (row-piece = 16 samples = 32 B);
+//   * the MFMA phase is VALU-free: one ds_read_b128 per (tile, piece) and k-step, three MFMAs per tile pair;
 //   * the image is double-buffered, so converting stage s+1 overlaps the MFMAs of stage s: one raw barrier per stage.
-// Image: [buffer 2][piece 3][row 512] x 32 B; the two 16-byte halves of a row-piece are swapped when (row >> 3) & 1 — that
+// Image: [buffer 2][piece 2][row 512] x 32 B; the two 16-byte halves of a row-piece are swapped when (row >> 3) & 1 — that
 // makes the ds_read_b128 of 16 consecutive rows conflict-free (the 8-byte writes of a wave cover 512 contiguous bytes).
-#define WX_IMG_BYTES (3 * 2 * WG_LDS_ROWS * 32)            // 48 KB per buffer
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+#define TN_MFMA16H(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+#define WX_IMG_BYTES (2 * 2 * WG_LDS_ROWS * 32)            // 32 KB per buffer
 static_assert(2 * WX_IMG_BYTES <= WG_LDS_FLOATS * 4, "the x3 operand images must fit the kernel's LDS");
 __device__ __forceinline__ uint32_t wx_img_off(int piece, int crow, int half) {
     return (uint32_t)((piece * (2 * WG_LDS_ROWS) + crow) * 32 + ((half ^ ((crow >> 3) & 1)) << 4));
 }
-// 4 fp32 -> 3 x (4 bf16 in 8 bytes), exact (see tn_split3)
-typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void tn_split3x4(const f32x4& x, u32x2_t& p1, u32x2_t& p2, u32x2_t& p3) {
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        const float x0 = x[2 * e], x1 = x[2 * e + 1];
-        const uint32_t u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
-#ifdef WX_NO_SPLIT      // diagnostic build: the operand packing only, WRONG numerics
-        p1[e] = __builtin_amdgcn_perm(u1, u0, 0x07060302u); p2[e] = p1[e]; p3[e] = p1[e];
-#else
-        const float r0 = x0 - __uint_as_float(u0 & 0xFFFF0000u), r1 = x1 - __uint_as_float(u1 & 0xFFFF0000u);
-        const uint32_t v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
-        const float s0 = r0 - __uint_as_float(v0 & 0xFFFF0000u), s1 = r1 - __uint_as_float(v1 & 0xFFFF0000u);
-        p1[e] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);                       // (hi16 of x1) : (hi16 of x0)
-        p2[e] = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
-        p3[e] = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);   // <= 8 significant bits left: exact
-#endif
-    }
+__device__ __forceinline__ unsigned wx_cvt2(float lo, float hi) {
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2_t));
 }
+// 2^(14 - exponent(bound)): bound 2^e stays below 2^14 (fp16 overflows at 2^16); bound = 0 gives a harmless finite scale
+__device__ __forceinline__ int wx_scale_exp(float bound) {
+    const int e = 14 - __builtin_amdgcn_frexp_expf(bound);
+    return e < -100 ? -100 : (e > 100 ? 100 : e);
+}
+__device__ __forceinline__ float wx_exp2i(int e) { return __uint_as_float((uint32_t)((e < -126 ? -126 : (e > 127 ? 127 : e)) + 127) << 23); }
 
 // PD = register sets of the fetch pipeline = stages between a fetch and its use: 2 for the 256 x 256 blocks (an iteration is
-// > 3k cycles of MFMA), 8 for the small, bandwidth-hungry input / head classes whose iterations are a few hundred cycles.
+// > 1.5k cycles of MFMA), 4 for the small, bandwidth-hungry input / head classes whose iterations are a few hundred cycles.
 template <int TA, int TB, int PD>
 __device__ __forceinline__ void wgrad_x3_body(const float* __restrict__ stash, int64_t stash_rows, int64_t M, const int32_t* __restrict__ job,
-                                              float* __restrict__ slabs, float* lds_f) {
+                                              float* __restrict__ slabs, float* lds_f, const float* __restrict__ bounds) {
     static_assert(PD % 2 == 0, "the image parity must follow the unrolled stage index");
     unsigned char* lds = reinterpret_cast<unsigned char*>(lds_f);
     const int tid = (int)threadIdx.x, lane = tid & 63;
@@ -269,6 +232,7 @@ __device__ __forceinline__ void wgrad_x3_body(const float* __restrict__ stash, i
     const int a_t0 = wa * TA, b_t0 = wb * TB;
     const int rows_a = n_at * 32, rows_b = n_bt * 32, rows = rows_a + rows_b;
     const bool has_bias = job[JOB_HAS_BIAS] != 0;
+    const int ea = wx_scale_exp(bounds[job[JOB_A_BOUND]]), eb = wx_scale_exp(bounds[job[JOB_B_BOUND]]);
     f32x16 acc[TA][TB];
 #pragma unroll
     for (int i = 0; i < TA; ++i)
@@ -281,18 +245,17 @@ __device__ __forceinline__ void wgrad_x3_body(const float* __restrict__ stash, i
     // Rows that do not exist (head: 4 of 32, input: 40 of 64) are clamped to a real row: they only feed slab rows / columns
     // that the reduce table never references.
     const int chunk = tid & 3;
-    int goff[4]; bool live[4], isA[4]; int crow[4];
+    int goff[4]; bool isA[4]; int crow[4]; float gsc[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         crow[k] = (tid >> 2) + 128 * k;
-        live[k] = crow[k] < rows;
         isA[k] = crow[k] < rows_a;
         const int lr = isA[k] ? crow[k] : crow[k] - rows_a;
         const int lim = (isA[k] ? a_rows : b_rows) - 1;
         const int srow_ = (isA[k] ? a_row0 : b_row0) + (lr < lim ? lr : lim);          // combined rows past the job's (dead items) land on B's last row
         goff[k] = srow_ * 128 + chunk * 16;
+        gsc[k] = wx_exp2i(isA[k] ? ea : eb);
     }
-    (void)live;
     float bs[4] = {0.f, 0.f, 0.f, 0.f};
     const int nst = 2 * nblk;                                   // stages of 16 samples
     const int64_t blk_bytes = stash_rows * 128;
@@ -307,10 +270,9 @@ __device__ __forceinline__ void wgrad_x3_body(const float* __restrict__ stash, i
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(base), 0, (int)blk_bytes, 0x00020000);
         raw[set][k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, goff[k], (st & 1) * 64, 0));
     };
-    // Conversion of one item in six small steps (so that the hot loop can place one step behind every MFMA pair):
-    //   0, 3: r = x - trunc_bf16(x) for elements (0,1) / (2,3)     1, 4: s = r - trunc_bf16(r)     2, 5: pack the three pieces;
-    //   step 5 also forms the bias row sum and stores the pieces.
-    struct Item { f32x4 x; float r[4], t[4]; u32x2_t p1, p2, p3; };
+    // Conversion of one item in three steps (so that the hot loop can place one step behind every MFMA of a group):
+    //   0: scale, first pieces     1: residuals     2: second pieces, the bias row sum, both pieces to the image
+    struct Item { f32x4 x, s; u32x2_t p1, p2; };
     auto conv_begin = [&](Item& it, int st, auto setc, auto kc, auto guardc) TN_INLINE_LAMBDA {
         constexpr int set = decltype(setc)::value, k = decltype(kc)::value;
         it.x = raw[set][k];
@@ -322,39 +284,27 @@ __device__ __forceinline__ void wgrad_x3_body(const float* __restrict__ stash, i
     };
     auto conv_step = [&](Item& it, int st, auto kc, auto stepc) TN_INLINE_LAMBDA {
         constexpr int k = decltype(kc)::value, step = decltype(stepc)::value;
-        constexpr int e = step / 3;                               // element pair
-        if constexpr (step % 3 == 0) {
-#ifndef WX_NO_SPLIT
-            it.r[2 * e] = it.x[2 * e] - __uint_as_float(__float_as_uint(it.x[2 * e]) & 0xFFFF0000u);
-            it.r[2 * e + 1] = it.x[2 * e + 1] - __uint_as_float(__float_as_uint(it.x[2 * e + 1]) & 0xFFFF0000u);
-#endif
-        } else if constexpr (step % 3 == 1) {
-#ifndef WX_NO_SPLIT
-            it.t[2 * e] = it.r[2 * e] - __uint_as_float(__float_as_uint(it.r[2 * e]) & 0xFFFF0000u);
-            it.t[2 * e + 1] = it.r[2 * e + 1] - __uint_as_float(__float_as_uint(it.r[2 * e + 1]) & 0xFFFF0000u);
-#endif
+        if constexpr (step == 0) {
+            it.s = it.x * gsc[k];
+            it.p1[0] = wx_cvt2(it.s[0], it.s[1]); it.p1[1] = wx_cvt2(it.s[2], it.s[3]);
+        } else if constexpr (step == 1) {
+            // (vector elements are copied to scalars first: __builtin_bit_cast applied directly to it.p1[i] reads element 0, hipcc 7.2)
+            const unsigned q0 = it.p1[0], q1 = it.p1[1];
+            const f16x2_t h0 = __builtin_bit_cast(f16x2_t, q0), h1 = __builtin_bit_cast(f16x2_t, q1);
+            it.s[0] -= (float)h0[0]; it.s[1] -= (float)h0[1]; it.s[2] -= (float)h1[0]; it.s[3] -= (float)h1[1];
         } else {
-            it.p1[e] = __builtin_amdgcn_perm(__float_as_uint(it.x[2 * e + 1]), __float_as_uint(it.x[2 * e]), 0x07060302u);   // (hi16 of x1) : (hi16 of x0)
-#ifndef WX_NO_SPLIT
-            it.p2[e] = __builtin_amdgcn_perm(__float_as_uint(it.r[2 * e + 1]), __float_as_uint(it.r[2 * e]), 0x07060302u);
-            it.p3[e] = __builtin_amdgcn_perm(__float_as_uint(it.t[2 * e + 1]), __float_as_uint(it.t[2 * e]), 0x07060302u);   // <= 8 significant bits left: exact
-#else
-            it.p2[e] = it.p1[e]; it.p3[e] = it.p1[e];
-#endif
-            if constexpr (step == 5) {
-                bs[k] += (it.x[0] + it.x[1]) + (it.x[2] + it.x[3]);
-                unsigned char* img = lds + (st & 1) * WX_IMG_BYTES;
-                const uint32_t o = wx_img_off(0, crow[k], chunk >> 1) + (chunk & 1) * 8;
-                *reinterpret_cast<u32x2_t*>(img + o) = it.p1;
-                *reinterpret_cast<u32x2_t*>(img + o + 2 * WG_LDS_ROWS * 32) = it.p2;
-                *reinterpret_cast<u32x2_t*>(img + o + 2 * (2 * WG_LDS_ROWS * 32)) = it.p3;
-            }
+            it.p2[0] = wx_cvt2(it.s[0], it.s[1]); it.p2[1] = wx_cvt2(it.s[2], it.s[3]);
+            bs[k] += (it.x[0] + it.x[1]) + (it.x[2] + it.x[3]);
+            unsigned char* img = lds + (st & 1) * WX_IMG_BYTES;
+            const uint32_t o = wx_img_off(0, crow[k], chunk >> 1) + (chunk & 1) * 8;
+            *reinterpret_cast<u32x2_t*>(img + o) = it.p1;
+            *reinterpret_cast<u32x2_t*>(img + o + 2 * WG_LDS_ROWS * 32) = it.p2;
         }
     };
     auto convert1 = [&](int st, auto setc, auto kc, auto guardc) TN_INLINE_LAMBDA {    // a whole item at once (prologue)
         Item it;
         conv_begin(it, st, setc, kc, guardc);
-        tn_static_for<6>([&](auto sc) TN_INLINE_LAMBDA { conv_step(it, st, kc, sc); });
+        tn_static_for<3>([&](auto sc) TN_INLINE_LAMBDA { conv_step(it, st, kc, sc); });
     };
     const int frow = lane & 31, fh = lane >> 5;
     const bool active = (a_t0 < n_at) && (b_t0 < n_bt);
@@ -375,24 +325,22 @@ __device__ __forceinline__ void wgrad_x3_body(const float* __restrict__ stash, i
         using SetC = std::integral_constant<int, set>;
         const bool conv = !GUARD || s + 1 < nst, fill = !GUARD || s + 1 + PD < nst;
         const unsigned char* img = lds + (u & 1) * WX_IMG_BYTES;
-        bf16x8_t a1[TA], a2[TA], a3[TA];
+        f16x8_t a1[TA], a2[TA];
         if constexpr (ACTIVE) {
 #pragma unroll
             for (int i = 0; i < TA; ++i) {
-                a1[i] = *reinterpret_cast<const bf16x8_t*>(img + oa[i]);
-                a2[i] = *reinterpret_cast<const bf16x8_t*>(img + oa[i] + PS);
-                a3[i] = *reinterpret_cast<const bf16x8_t*>(img + oa[i] + 2 * PS);
+                a1[i] = *reinterpret_cast<const f16x8_t*>(img + oa[i]);
+                a2[i] = *reinterpret_cast<const f16x8_t*>(img + oa[i] + PS);
             }
         }
-        // Group j: the 6 TA MFMAs of B tile j, with the conversion of items j (4/TB) .. of stage s+1 cut into six steps, one
+        // Group j: the 3 TA MFMAs of B tile j, with the conversion of items j (4/TB) .. of stage s+1 cut into three steps, one
         // behind every TA MFMAs; the order is pinned (left alone, the scheduler emits the MFMAs back to back and the whole
         // conversion after them, in the shadow of the last one only).
         constexpr int IPG = 4 / TB;                                  // items per group
-        bf16x8_t b1, b2, b3;
+        f16x8_t b1, b2;
         if constexpr (ACTIVE) {
-            b1 = *reinterpret_cast<const bf16x8_t*>(img + ob[0]);
-            b2 = *reinterpret_cast<const bf16x8_t*>(img + ob[0] + PS);
-            b3 = *reinterpret_cast<const bf16x8_t*>(img + ob[0] + 2 * PS);
+            b1 = *reinterpret_cast<const f16x8_t*>(img + ob[0]);
+            b2 = *reinterpret_cast<const f16x8_t*>(img + ob[0] + PS);
         }
         tn_static_for<TB>([&](auto jc) TN_INLINE_LAMBDA {
             constexpr int j = decltype(jc)::value;
@@ -402,17 +350,17 @@ __device__ __forceinline__ void wgrad_x3_body(const float* __restrict__ stash, i
                 conv_begin(it[decltype(qc)::value], s + 1, SetC{}, std::integral_constant<int, j * IPG + decltype(qc)::value>{}, guardc);
             });
 #endif
-            tn_static_for<6>([&](auto tc) TN_INLINE_LAMBDA {
-                constexpr int term = decltype(tc)::value;           // small terms first: a3 b1, a2 b2, a1 b3, a2 b1, a1 b2, a1 b1
+            tn_static_for<3>([&](auto tc) TN_INLINE_LAMBDA {
+                constexpr int term = decltype(tc)::value;           // small terms first: a2 b1, a1 b2, a1 b1
                 if constexpr (ACTIVE) {
 #ifdef WX_ONE_MFMA       // diagnostic build: only the leading product
-                    if constexpr (term == 5)
+                    if constexpr (term == 2)
 #endif
 #pragma unroll
                     for (int i = 0; i < TA; ++i) {
-                        const bf16x8_t& av = (term == 0) ? a3[i] : ((term == 1 || term == 3) ? a2[i] : a1[i]);
-                        const bf16x8_t& bv = (term == 2) ? b3 : ((term == 1 || term == 4) ? b2 : b1);
-                        acc[i][j] = TN_MFMA16(av, bv, acc[i][j]);
+                        const f16x8_t& av = term == 0 ? a2[i] : a1[i];
+                        const f16x8_t& bv = term == 1 ? b2 : b1;
+                        acc[i][j] = TN_MFMA16H(av, bv, acc[i][j]);
                     }
                 }
 #ifndef WX_NO_CONVERT
@@ -420,16 +368,15 @@ __device__ __forceinline__ void wgrad_x3_body(const float* __restrict__ stash, i
                     conv_step(it[decltype(qc)::value], s + 1, std::integral_constant<int, j * IPG + decltype(qc)::value>{}, tc);
                 });
 #endif
-                if constexpr (term == 5) {
+                if constexpr (term == 2) {
 #ifndef WX_NO_CONVERT
                     if (fill) tn_static_for<IPG>([&](auto qc) TN_INLINE_LAMBDA {
                         fetch1(s + 1 + PD, SetC{}, std::integral_constant<int, j * IPG + decltype(qc)::value>{});
                     });
 #endif
                     if constexpr (ACTIVE && j + 1 < TB) {            // the next group's B fragments
-                        b1 = *reinterpret_cast<const bf16x8_t*>(img + ob[j + 1]);
-                        b2 = *reinterpret_cast<const bf16x8_t*>(img + ob[j + 1] + PS);
-                        b3 = *reinterpret_cast<const bf16x8_t*>(img + ob[j + 1] + 2 * PS);
+                        b1 = *reinterpret_cast<const f16x8_t*>(img + ob[j + 1]);
+                        b2 = *reinterpret_cast<const f16x8_t*>(img + ob[j + 1] + PS);
                     }
                 }
 #ifndef WX_NO_PIN
@@ -481,17 +428,18 @@ __device__ __forceinline__ void wgrad_x3_body(const float* __restrict__ stash, i
     };
     if (active) run(T_{}); else run(F_{});
 
-    // epilogue: partial block -> this workgroup's slab  [n_at*32][n_bt*32] then bias [n_at*32]   (as wgrad_body)
+    // epilogue: partial block (scaled back) -> this workgroup's slab  [n_at*32][n_bt*32] then bias [n_at*32]   (as wgrad_body)
     float* slab = slabs + job[JOB_SLAB_OFF];
     const int ld = n_bt * 32;
     if (active) {
+        const float back = wx_exp2i(-(ea + eb));
 #pragma unroll
         for (int i = 0; i < TA; ++i)
 #pragma unroll
             for (int j = 0; j < TB; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    slab[(int64_t)((a_t0 + i) * 32 + TN_ACC_ROW(r, fh)) * ld + (b_t0 + j) * 32 + frow] = acc[i][j][r];
+                    slab[(int64_t)((a_t0 + i) * 32 + TN_ACC_ROW(r, fh)) * ld + (b_t0 + j) * 32 + frow] = acc[i][j][r] * back;
     }
     if (has_bias) {                                              // row sums of A: the 4 lanes of a row hold its 4 chunks
 #pragma unroll
@@ -507,7 +455,8 @@ __device__ __forceinline__ void wgrad_x3_body(const float* __restrict__ stash, i
 // waits for LDS fragments, the staging writes or the barrier, the other one keeps the matrix pipe busy.
 template <bool X3>
 __global__ __launch_bounds__(512, 2) void k_wgrad(const float* __restrict__ stash, int64_t stash_rows, int64_t M,
-                                                  const int32_t* __restrict__ jobs, float* __restrict__ slabs, int64_t* step_inc) {
+                                                  const int32_t* __restrict__ jobs, float* __restrict__ slabs, int64_t* step_inc,
+                                                  const float* __restrict__ bounds) {
     __shared__ __attribute__((aligned(16))) float lds[WG_LDS_FLOATS];
     // Dataset mode: the step counter advances HERE — the forward and dgrad kernels of this step (which read it) are done,
     // the finishing kernel (which needs the 1-based count for Adam's bias correction) has not started.
@@ -519,10 +468,10 @@ __global__ __launch_bounds__(512, 2) void k_wgrad(const float* __restrict__ stas
     const int n_at = job[JOB_N_AT], n_bt = job[JOB_N_BT], WA = job[JOB_WA], WB = 8 / WA;
     const int ta = (n_at + WA - 1) / WA, tb = (n_bt + WB - 1) / WB;     // the host plan only emits full-or-idle waves
     switch (ta * 8 + tb) {
-        case 2 * 8 + 4: if (X3) wgrad_x3_body<2, 4, 2>(stash, stash_rows, M, job, slabs, lds); else wgrad_body<2, 4>(stash, stash_rows, M, job, slabs, lds); break;
-        case 1 * 8 + 2: if (X3) wgrad_x3_body<1, 2, 4>(stash, stash_rows, M, job, slabs, lds); else wgrad_body<1, 2>(stash, stash_rows, M, job, slabs, lds); break;
-        case 2 * 8 + 1: if (X3) wgrad_x3_body<2, 1, 4>(stash, stash_rows, M, job, slabs, lds); else wgrad_body<2, 1>(stash, stash_rows, M, job, slabs, lds); break;
-        case 1 * 8 + 1: if (X3) wgrad_x3_body<1, 1, 4>(stash, stash_rows, M, job, slabs, lds); else wgrad_body<1, 1>(stash, stash_rows, M, job, slabs, lds); break;
+        case 2 * 8 + 4: if (X3) wgrad_x3_body<2, 4, 2>(stash, stash_rows, M, job, slabs, lds, bounds); else wgrad_body<2, 4>(stash, stash_rows, M, job, slabs, lds); break;
+        case 1 * 8 + 2: if (X3) wgrad_x3_body<1, 2, 4>(stash, stash_rows, M, job, slabs, lds, bounds); else wgrad_body<1, 2>(stash, stash_rows, M, job, slabs, lds); break;
+        case 2 * 8 + 1: if (X3) wgrad_x3_body<2, 1, 4>(stash, stash_rows, M, job, slabs, lds, bounds); else wgrad_body<2, 1>(stash, stash_rows, M, job, slabs, lds); break;
+        case 1 * 8 + 1: if (X3) wgrad_x3_body<1, 1, 4>(stash, stash_rows, M, job, slabs, lds, bounds); else wgrad_body<1, 1>(stash, stash_rows, M, job, slabs, lds); break;
         default: break;   // unreachable: shapes are validated on the host (tnerf_plan_fill)
     }
 #ifdef TN_STAMPS
@@ -535,9 +484,12 @@ __global__ __launch_bounds__(512, 2) void k_wgrad(const float* __restrict__ stas
 #endif
 }
 
-int tn_launch_wgrad(const float* stash, int64_t stash_rows, int64_t M, const int32_t* jobs, int64_t n_jobs, float* slabs, int64_t* step_inc, hipStream_t stream, bool x3) {
-    if (x3) hipLaunchKernelGGL(k_wgrad<true>, dim3((unsigned)n_jobs), dim3(512), 0, stream, stash, stash_rows, M, jobs, slabs, step_inc);
-    else    hipLaunchKernelGGL(k_wgrad<false>, dim3((unsigned)n_jobs), dim3(512), 0, stream, stash, stash_rows, M, jobs, slabs, step_inc);
+// bounds: the stash's magnitude-bound words (TN_BOUND_OFF); required by the x3 kernel
+int tn_launch_wgrad(const float* stash, int64_t stash_rows, int64_t M, const int32_t* jobs, int64_t n_jobs, float* slabs, int64_t* step_inc, hipStream_t stream, bool x3,
+                    const float* bounds) {
+    if (x3 && !bounds) { tn_set_error("wgrad: the x3 kernel needs the stash's bound words"); return TNERF_EINVAL; }
+    if (x3) hipLaunchKernelGGL(k_wgrad<true>, dim3((unsigned)n_jobs), dim3(512), 0, stream, stash, stash_rows, M, jobs, slabs, step_inc, bounds);
+    else    hipLaunchKernelGGL(k_wgrad<false>, dim3((unsigned)n_jobs), dim3(512), 0, stream, stash, stash_rows, M, jobs, slabs, step_inc, bounds);
     TN_HIP_CHECK_LAUNCH("wgrad");
     return TNERF_OK;
 }
