@@ -264,14 +264,21 @@ __device__ __forceinline__ int64_t tn_ray_pixel(const RaySource& rs, int64_t r) 
     return rs.index ? rs.index[r] : rs.first + r;
 }
 
+// (Both sources fill SCALARS and the arrays are written once behind the branch: with stores to o[c] / d[c] in both branches hipcc
+// merges them into one store with a run-time index, which keeps the two small arrays in scratch memory — 12 bytes of stack in
+// every kernel that fetches a ray.)
 __device__ __forceinline__ void tn_fetch_ray(const RaySource& rs, int64_t r, float (&o)[3], float (&d)[3]) {
+    float o0, o1, o2, d0, d1, d2;
     if (rs.c2w) {
-        tn_pixel_ray(rs.c2w, rs.H, rs.W, rs.focal, tn_ray_pixel(rs, r), o, d);
+        float po[3], pd[3];
+        tn_pixel_ray(rs.c2w, rs.H, rs.W, rs.focal, tn_ray_pixel(rs, r), po, pd);
+        o0 = po[0]; o1 = po[1]; o2 = po[2]; d0 = pd[0]; d1 = pd[1]; d2 = pd[2];
     } else {
         const int64_t i = rs.index ? rs.index[r] : r;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { o[c] = rs.rays_o[3 * i + c]; d[c] = rs.rays_d[3 * i + c]; }
+        o0 = rs.rays_o[3 * i]; o1 = rs.rays_o[3 * i + 1]; o2 = rs.rays_o[3 * i + 2];
+        d0 = rs.rays_d[3 * i]; d1 = rs.rays_d[3 * i + 1]; d2 = rs.rays_d[3 * i + 2];
     }
+    o[0] = o0; o[1] = o1; o[2] = o2; d[0] = d0; d[1] = d1; d[2] = d2;
 }
 
 // ------------------------------------------------------------------------------ loss folded into the forward

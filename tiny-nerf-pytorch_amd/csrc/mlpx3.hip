@@ -33,12 +33,24 @@ struct FwdX3Args {
 // exponent its pieces are scaled by.
 struct TxIn { float encmax, l1; int te; };
 
+// The network input rows of the training stash (the fp32 path's pairing: step st = 8u + e), written as soon as the values exist —
+// before they are split — so that no copy of them has to outlive the split.
+__device__ __forceinline__ void tx_stash_input(const FwdX3Args& a, int h, int lane, const float (&encf)[8 * TN16_KE], int64_t m, bool valid) {
+    const MlpLayout& L = a.f.L;
+    const int64_t ms = valid ? m : a.f.Mp + (lane & 31);           // padding lanes write to the dump block
+    float* __restrict__ q = tn_stash_at(a.f.stash, L.stash_rows, ms) + (int64_t)(L.enc_row0 + h) * 32;      // row enc_row0 + 2 st + h
+    tn_static_for<8 * TN16_KE>([&](auto sc) TN_INLINE_LAMBDA {
+        constexpr int st = decltype(sc)::value;
+        if (st < L.NE) TN_STASH_STORE(&q[2 * st * 32], encf[st]);
+    });
+}
+
 // The network for one 32-sample tile.  m: this lane's sample index in the stash (valid if `valid`).  res[4]: r,g,b after
 // sigmoid, sigma after ReLU (lane-half 0).  E: this lane's LDS slots of the input pieces, scaled by 2^in.te (rescaled in place for
 // the skip layer).
 template <int HID, bool TRAIN>
 __device__ __forceinline__ void tx_mlp_tile(PipeX& p, const unsigned char* lds, const FwdX3Args& a, int h, int lane, unsigned char* E, const TxIn& in,
-                                            const float (&encf)[8 * TN16_KE], int64_t m, bool valid, float (&res)[4], TxProf& pf, unsigned char* lds_bnd) {
+                                            int64_t m, bool valid, float (&res)[4], TxProf& pf, unsigned char* lds_bnd) {
     constexpr int NT = HID / 32;
     const MlpLayout& L = a.f.L;
     const int depth = a.n.depth, skip_at = a.n.skip_at;
@@ -48,12 +60,6 @@ __device__ __forceinline__ void tx_mlp_tile(PipeX& p, const unsigned char* lds, 
     const int64_t ms = valid ? m : Mp + (lane & 31);               // padding lanes write to the dump block: stores need no branch
     float* __restrict__ pl = TRAIN ? tn_stash_at(stash, L.stash_rows, ms) + 4 * h * 32 : nullptr;      // per-lane: (row 4h, sample ms)
     uint32_t* __restrict__ mrow = TRAIN ? reinterpret_cast<uint32_t*>(stash + TN_STASH_BODY_FLOATS(L, Mp)) + (2 * ms + h) * (NT / 2) : nullptr;
-    if constexpr (TRAIN) {                                         // the network input rows of the stash (the fp32 path's pairing: step st = 8u + e)
-        tn_static_for<8 * TN16_KE>([&](auto sc) TN_INLINE_LAMBDA {
-            constexpr int st = decltype(sc)::value;
-            if (st < L.NE) TN_STASH_STORE(&pl[(L.enc_row0 + 2 * st - 3 * h) * 32], encf[st]);
-        });
-    }
     constexpr int NH = NT / 2, KH = HID / 16, NP = NH * 8, NW = TxCfg<HID, TRAIN>::NW, G2 = KH / 2 * NH;
     ActX<HID> X;
     f32x16 accA[TX_ACCN(HID)], accB[TX_ACCN(HID)];
@@ -181,10 +187,11 @@ __global__ __launch_bounds__((TxCfg<HID, TRAIN>::NW * 64), 1) void k_renderx3(Fw
                 in.encmax = fmaxf(fmaxf(fabsf(px), fabsf(py)), fmaxf(fabsf(pz), 1.0f));      // |sin|, |cos| <= 1
                 in.l1 = __builtin_fmaf(3.0f, in.encmax, (float)(6 * Lf));
                 in.te = tx_scale_exp(in.encmax);
+                if constexpr (TRAIN) tx_stash_input(a, h, lane, encf, rayc * S + sc, valid);
                 tx_split_input(Er, tx_exp2i(in.te), [&](auto ac) TN_INLINE_LAMBDA { return encf[decltype(ac)::value]; });
                 tx_store_input(E, Er);
                 float res[4];
-                tx_mlp_tile<HID, TRAIN>(p, lds, a, h, lane, E, in, encf, rayc * S + sc, valid, res, pf, lds_bnd);
+                tx_mlp_tile<HID, TRAIN>(p, lds, a, h, lane, E, in, rayc * S + sc, valid, res, pf, lds_bnd);
                 const bool upper = (sb & 32) != 0;                            // wave-uniform
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -479,10 +486,11 @@ __global__ __launch_bounds__((TxCfg<HID, TRAIN>::NW * 64), 1) void k_mlpx3_fwd(F
             for (int i = 0; i < 8 * TN16_KE; ++i) { mx = fmaxf(mx, fabsf(encf[i])); l1 += fabsf(encf[i]); }
             in.encmax = fmaxf(mx, tx_partner(mx)); in.l1 = l1 + tx_partner(l1); in.te = tx_scale_exp(in.encmax);
         }
+        if constexpr (TRAIN) tx_stash_input(a, h, lane, encf, mc, valid);
         tx_split_input(Er, tx_exp2i(in.te), [&](auto ac) TN_INLINE_LAMBDA { return encf[decltype(ac)::value]; });
         tx_store_input(E, Er);
         float res[4];
-        tx_mlp_tile<HID, TRAIN>(p, lds, a, h, lane, E, in, encf, mc, valid, res, pf, lds_bnd);
+        tx_mlp_tile<HID, TRAIN>(p, lds, a, h, lane, E, in, mc, valid, res, pf, lds_bnd);
         if (valid && h == 0) {
             a.f.rgb_out[3 * m + 0] = res[0]; a.f.rgb_out[3 * m + 1] = res[1]; a.f.rgb_out[3 * m + 2] = res[2];
             a.f.sigma_out[m] = res[3];

@@ -220,13 +220,15 @@ __device__ __forceinline__ FragX tx_frag_load(const unsigned char* base, int tl)
 // RPS = records per stage (2 for 256-wide, 4 for 128-wide nets); every pass is a whole number of stages.  ZERO: the
 // accumulators start at zero.
 // hook(integral_constant<slot>) is called behind MFMA number slot = (k * NTU + tile) * 3 + j: work to issue in its shadow.
-// A (tile, k-step) GROUP is three MFMAs = 96 cycles, less than an LDS read takes to return when the other three waves and the
-// DMA are busy on the same LDS: the A fragments are read TX_FD groups ahead (behind the first MFMA of a group), and the stage
-// boundary (wait, barrier, next DMA stage named) of every stage but the pass's first is taken TX_FD groups EARLY, so that the new
-// stage's first fragments are read behind MFMAs as well.  (The ring has the spare slot this needs: TX_LEAD + 2 <= TX_NS; the
+// The A fragments of a (tile, k-step) GROUP (three MFMAs = 96 cycles) are read TX_FD groups ahead (behind the first MFMA of a
+// group), and the stage boundary (wait, barrier, next DMA stage named) of every stage but the pass's first is taken TX_FD groups
+// EARLY, so that the new stage's first fragments are read behind MFMAs as well.  TX_FD = 2 measured the same as 1 (621 / 815 /
+// 722 us against 622 / 810 / 726 for render / training forward / dgrad) and costs eight registers: 1.  (The ring has the spare slot this needs: TX_LEAD + 2 <= TX_NS; the
 // slot a boundary hands to the DMA held the stage before the one whose last TX_FD groups are still running.)
 // elds: this lane's slot of the wave's network-input pieces in LDS (KIND 0; tx_store_input), read one k-step ahead.
-#define TX_FD 2
+#ifndef TX_FD
+#define TX_FD 1
+#endif
 template <int HID, int KIND, bool ZERO, int NW, typename Hook>
 __device__ __forceinline__ void tx_pass(PipeX& p, const unsigned char* lds, const ActX<HID>& X, const unsigned char* elds,
                                         f32x16 (&acc)[TX_ACCN(HID)], Hook&& hook) {
