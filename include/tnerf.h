@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define TNERF_ABI_VERSION 2
+#define TNERF_ABI_VERSION 3
 
 #define TNERF_OK            0
 #define TNERF_EINVAL       (-1)  /* bad size / NULL pointer / inconsistent arguments        */
@@ -47,17 +47,18 @@ typedef struct tnerf_mlp_desc {
     int32_t hidden;
     int32_t depth;
     int32_t skip_at;
-    int32_t flags;           /* TNERF_FLAG_* (ABI 2); 0 = defaults                                */
+    int32_t flags;           /* TNERF_FLAG_*; 0 = defaults                                        */
 } tnerf_mlp_desc;
-/* How the fp32 kernels of the fused paths form their fp32 products: the weight-gradient kernel (tnerf_wgrad, inside
- * tnerf_mlp_bwd / tnerf_train_*) and, wherever a tnerf_mlp_pack_x3 stream is passed (the *_x3 entry points, the packed_x3
+/* Which matrix pipe the fp32 kernels of the fused paths use: the weight-gradient kernel (tnerf_wgrad with a stash written by
+ * an x3 chain, inside tnerf_train_*) and, wherever a tnerf_mlp_pack_x3 stream is passed (the *_x3 entry points, the packed_x3
  * arguments), the forward and dgrad chain kernels.
- * Default (0): on the bf16 matrix pipe by EXACT three-way splitting — an fp32 value is the sum of three bf16 numbers
- * (8+8+8 mantissa bits), a product of two bf16 numbers is exact in fp32, six v_mfma_f32_32x32x16_bf16 with fp32
- * accumulation carry a*b up to terms below 2^-24 |ab| — fp32-grade results (measured against fp64: the weight-gradient
- * GEMMs as accurate as an fp32 fma chain; the chain kernels within ~2x of the fp32-MFMA kernels' activation error after 8
- * layers, because the matrix pipe drops addends below ~1/8 ulp of its accumulator: DESIGN.md 14) at 6/16 of the fp32-MFMA
- * time (CDNA4's bf16 matrix rate is 16x its fp32 rate).
+ * Default (0), "x3": the fp16 matrix pipe with THREE partial products.  Every fp32 operand is scaled by a power of two (per
+ * layer for weights, per sample for activations / per row group in the weight-gradient GEMMs) and carried as two fp16
+ * pieces x = x1 + x2 (round-to-nearest, |x - x1 - x2| <= 2^-22 |x|); a*b is formed as a1*b1 in one fp32 accumulator and
+ * a1*b2 + a2*b1 in a second one (three v_mfma_f32_32x32x16_f16 per 16 k), a2*b2 <= 2^-22 |ab| is dropped.  This is an
+ * APPROXIMATION of fp32 arithmetic with fp32-grade error, not fp32 arithmetic: measured against fp64 the activations are
+ * closer than an fp32 fma chain's and every gradient tensor is within 2x of the reference's own CPU fp32 error (tests/
+ * test_gpu_parity.py states the bounds; DESIGN.md 3 has the pipe's accumulation model) — at 3/16 of the fp32-MFMA time.
  * TNERF_FLAG_FP32_MFMA selects v_mfma_f32_32x32x2_f32 (plain fp32 fma chains) for all of them instead; the entry points
  * that take only the fp32 pack (tnerf_render_fused, tnerf_train_fwd_fused, tnerf_mlp_fwd, ...) always run those. */
 #define TNERF_FLAG_FP32_MFMA 1
@@ -75,7 +76,8 @@ typedef struct tnerf_plan_sizes {
 } tnerf_plan_sizes;
 
 /* ---------------------------------------------------------------------------------- misc */
-int         tnerf_version(void);                 /* HOST: TNERF_ABI_VERSION                    */
+int         tnerf_version(void);                 /* HOST: TNERF_ABI_VERSION — a binding MUST compare it with the header it
+                                                    was written against before the first call (ABI 2 -> 3 changed signatures) */
 const char* tnerf_last_error_string(void);       /* HOST: thread-local, never NULL             */
 
 /* ------------------------------------------------------------------------ host-side tables */
@@ -199,8 +201,8 @@ int tnerf_train_fwd_fused(const tnerf_mlp_desc* d, const float* packed,
 
 /* Training backward: given g_comp = dL/dcomp_rgb [R,3], overwrite grads [n_params]
  * (what loss.backward() accumulates, train.py:126).  Same sampling arguments as the forward.
- * packed_x3: NULL, or the tnerf_mlp_pack_x3 stream of the same parameters — the dgrad chain then runs on the bf16 matrix
- * pipe (exact split) unless desc.flags has TNERF_FLAG_FP32_MFMA. */
+ * packed_x3: NULL, or the tnerf_mlp_pack_x3 stream of the same parameters — the dgrad chain then runs on the fp16 matrix
+ * pipe (x3) unless desc.flags has TNERF_FLAG_FP32_MFMA. */
 int tnerf_train_bwd_fused(const tnerf_mlp_desc* d, const float* packed,
                           const float* rays_o, const float* rays_d, int64_t n_rays, int32_t n_samples,
                           const float* ztab, int32_t randomized, const float* t_rand,
@@ -226,14 +228,18 @@ int tnerf_wgrad_reduce(const float* slabs, const int32_t* reduce_table, int64_t 
 /* One whole minibatch step up to (not including) the optimizer (train.py:114-126):
  * forward, loss = sum((comp-target)^2)/loss_denominator, backward -> grads (overwritten),
  * loss_out[0] = this batch's loss contribution (device scalar), comp_rgb [R,3].
- * g_comp_ws: workspace of 4*R floats (ABI 2: per ray dL/dcomp_rgb and the squared error, written by the forward kernel).
+ * g_comp_ws: per-ray workspace (dL/dcomp_rgb and the squared error of every ray, written by the forward kernel) of
+ * g_comp_ws_floats >= tnerf_train_ws_floats(n_rays) floats; a smaller capacity is refused with TNERF_ESMALL before anything
+ * is launched.  (ABI 1 needed 3*R floats, ABI 2 needs 4*R: the capacity argument exists so that a caller sized for an older
+ * library gets an error instead of an out-of-bounds write.)
  * loss_denominator = 3*R reproduces torch.mean (train.py:122); a ray shard passes the GLOBAL 3*R. */
+int64_t tnerf_train_ws_floats(int64_t n_rays);   /* HOST: floats of g_comp_ws / tnerf_step_args.ray_ws for n_rays rays; < 0: bad n_rays */
 int tnerf_train_step_fused(const tnerf_mlp_desc* d, const float* packed,
                            const float* rays_o, const float* rays_d, const float* target,
                            int64_t n_rays, int32_t n_samples,
                            const float* ztab, int32_t randomized, const float* t_rand,
                            uint64_t seed, uint64_t offset, int32_t white_bkgd, double loss_denominator,
-                           float* comp_rgb, float* g_comp_ws, float* loss_out,
+                           float* comp_rgb, float* g_comp_ws, int64_t g_comp_ws_floats, float* loss_out,
                            float* stash, int64_t stash_row_stride,
                            const int32_t* job_table, int64_t n_jobs, float* slabs,
                            const int32_t* reduce_table, float* grads,
@@ -265,7 +271,7 @@ int tnerf_train_step_fused_cam(const tnerf_mlp_desc* d, const float* packed, con
                                const float* pixels, int64_t n_rays, int32_t n_samples,
                                const float* ztab, int32_t randomized, const float* t_rand,
                                uint64_t seed, uint64_t offset, int32_t white_bkgd, double loss_denominator,
-                               float* comp_rgb, float* g_comp_ws, float* loss_out,
+                               float* comp_rgb, float* g_comp_ws, int64_t g_comp_ws_floats, float* loss_out,
                                float* stash, int64_t stash_row_stride,
                                const int32_t* job_table, int64_t n_jobs, float* slabs,
                                const int32_t* reduce_table, float* grads, const void* packed_x3, tnerf_stream_t stream);
@@ -307,10 +313,13 @@ typedef struct tnerf_step_args {
     const void* packed;
     /* workspaces */
     float* comp_rgb;              /* [n_rays,3]                                                                      */
-    float* ray_ws;                /* [n_rays,4]: dL/dcomp_rgb and the squared error of every ray                     */
+    float* ray_ws;                /* per-ray workspace: dL/dcomp_rgb and the squared error of every ray              */
+    int64_t ray_ws_floats;        /* its capacity, >= tnerf_train_ws_floats(n_rays), else TNERF_ESMALL                */
     int32_t* pix_out;             /* [n_rays] or NULL: the pixel every ray trained on                                */
     float* loss_out;              /* device scalar or NULL                                                           */
     void* stash; int64_t stash_row_stride;      /* fp32: plan stash + its row stride; bf16: the tile stash            */
+    int64_t stash_capacity;       /* capacity of `stash`: fp32 floats >= tnerf_plan_sizes.stash_floats of n_rays*n_samples,
+                                     bf16 bytes >= tnerf_bf16_train_plan.stash_bytes; smaller: TNERF_ESMALL              */
     const int32_t* job_table; int64_t n_jobs; float* slabs;
     const int32_t* reduce_table; float* grads;
     /* optimizer */
@@ -409,24 +418,25 @@ int tnerf_train_step_fused_bf16(const tnerf_mlp_desc* d, const void* packed16,
                                 int64_t n_rays, int32_t n_samples,
                                 const float* ztab, int32_t randomized, const float* t_rand,
                                 uint64_t seed, uint64_t offset, int32_t white_bkgd, double loss_denominator,
-                                float* comp_rgb, float* g_comp_ws, float* loss_out, void* stash16,
+                                float* comp_rgb, float* g_comp_ws, int64_t g_comp_ws_floats, float* loss_out, void* stash16,
                                 const int32_t* job_table, int64_t n_jobs, float* slabs,
                                 const int32_t* reduce_table, float* grads, tnerf_stream_t stream);
 int tnerf_train_step_fused_cam_bf16(const tnerf_mlp_desc* d, const void* packed16, const tnerf_camera* cam,
                                     const float* pixels, int64_t n_rays, int32_t n_samples,
                                     const float* ztab, int32_t randomized, const float* t_rand,
                                     uint64_t seed, uint64_t offset, int32_t white_bkgd, double loss_denominator,
-                                    float* comp_rgb, float* g_comp_ws, float* loss_out, void* stash16,
+                                    float* comp_rgb, float* g_comp_ws, int64_t g_comp_ws_floats, float* loss_out, void* stash16,
                                     const int32_t* job_table, int64_t n_jobs, float* slabs,
                                     const int32_t* reduce_table, float* grads, tnerf_stream_t stream);
 
-/* ------------------------------------------------------- fp32 chain on the bf16 matrix pipe ("x3", exact) */
-/* The fused fp32 paths with the MLP's fp32 products formed EXACTLY on the bf16 matrix pipe: weights and activations are
- * split into three bf16 pieces each (8+8+8 mantissa bits, every cut exact; see TNERF_FLAG_FP32_MFMA above), six
- * v_mfma_f32_32x32x16_bf16 with fp32 accumulation per k-step.  Inputs, outputs, sample bins, encoder, compositing, and the
- * training stash are those of tnerf_render_fused / tnerf_train_fwd_fused: fp32 results to fp32 accuracy.  Requires
- * in_dim = 6L+3.  packed3: the record stream of tnerf_mlp_pack_x3 (sizes / table: tnerf_x3_plan_sizes, tnerf_x3_pack_table;
- * tnerf_bf16_sizes is reused: n_fragments = n_fwd_fragments = 1 KB fragments of the stream). */
+/* ------------------------------------------------ fp32 chain on the fp16 matrix pipe ("x3": three partial products) */
+/* The fused fp32 paths with the MLP's products formed on the fp16 matrix pipe as described at TNERF_FLAG_FP32_MFMA above:
+ * weights and activations are carried as two scaled fp16 pieces each, three v_mfma_f32_32x32x16_f16 per k-step into split
+ * accumulators (leading products / corrections).  Inputs, outputs, sample bins, encoder, compositing, and the training
+ * stash are those of tnerf_render_fused / tnerf_train_fwd_fused; results carry fp32-grade error (an approximation, not
+ * bit-equal to an fp32 fma chain).  Requires in_dim = 6L+3.  packed3: the record stream of tnerf_mlp_pack_x3 (sizes / table:
+ * tnerf_x3_plan_sizes, tnerf_x3_pack_table; tnerf_bf16_sizes is reused: n_fragments = n_fwd_fragments = 1 KB fragments of
+ * the stream, which ends with the per-layer scale records the kernels read). */
 int tnerf_x3_plan_sizes(const tnerf_mlp_desc* d, tnerf_bf16_sizes* out);                     /* HOST */
 int tnerf_x3_pack_table(const tnerf_mlp_desc* d, int32_t* table);                           /* HOST: table[pack_entries] */
 int tnerf_mlp_pack_x3(const tnerf_mlp_desc* d, const float* params, const int32_t* table, void* packed3,
@@ -450,7 +460,7 @@ int tnerf_train_fwd_fused_x3(const tnerf_mlp_desc* d, const void* packed3,
                              float* comp_rgb, float* stash, int64_t stash_row_stride, tnerf_stream_t stream);
 
 /* tnerf_mlp_fwd / tnerf_mlp_bwd (TinyNeRF.forward and its backward on x[M, in_dim] in memory, src/nerf.py:29-41) on the
- * split-bf16 chain; in_dim = 6L+3 as for every x3 entry point (other input widths: the fp32-MFMA entry points).  Same
+ * x3 chain; in_dim = 6L+3 as for every x3 entry point (other input widths: the fp32-MFMA entry points).  Same
  * outputs, same stash, same gradients to fp32 rounding. */
 int tnerf_mlp_fwd_x3(const tnerf_mlp_desc* d, const void* packed_x3, const float* x, int64_t n_rows,
                      float* rgb, float* sigma, float* stash, int64_t stash_row_stride, tnerf_stream_t stream);
@@ -459,7 +469,7 @@ int tnerf_mlp_bwd_x3(const tnerf_mlp_desc* d, const void* packed_x3, int64_t n_r
                      const int32_t* job_table, int64_t n_jobs, float* slabs,
                      const int32_t* reduce_table, float* grads, tnerf_stream_t stream);
 
-/* tnerf_train_dgrad_fused on the split-bf16 chain: reads the backward record stream of `packed_x3` (heads^T and the
+/* tnerf_train_dgrad_fused on the x3 chain: reads the backward record stream of `packed_x3` (heads^T and the
  * transposed hidden layers, which tnerf_mlp_pack_x3 writes behind the forward stream) and fills the same dZ rows. */
 int tnerf_train_dgrad_fused_x3(const tnerf_mlp_desc* d, const void* packed_x3,
                                const float* rays_o, const float* rays_d, int64_t n_rays, int32_t n_samples,

@@ -37,7 +37,7 @@ for R in (2500, 5000):
     s_ = torch.cuda.current_stream(dev).cuda_stream
     st.grad.zero_()
     L.call("tnerf_train_step_fused_bf16", C.byref(st.desc), b.packed.data_ptr(), od.data_ptr(), dd.data_ptr(), tg.data_ptr(), R, S,
-           ztab.data_ptr(), 1, td.data_ptr(), 0, 0, 1, float(3 * R), comp.data_ptr(), gws.data_ptr(), loss.data_ptr(),
+           ztab.data_ptr(), 1, td.data_ptr(), 0, 0, 1, float(3 * R), comp.data_ptr(), gws.data_ptr(), gws.numel(), loss.data_ptr(),
            bp.stash.data_ptr(), bp.jobs.data_ptr(), bp.n_jobs, bp.slabs.data_ptr(), bp.reduce.data_ptr(), st.grad.data_ptr(), s_)
     torch.cuda.synchronize()
     flat = st.grad.cpu().clone()
@@ -46,7 +46,7 @@ for R in (2500, 5000):
     pix = pixels.to(dev)
     st.grad.zero_()
     L.call("tnerf_train_step_fused_cam_bf16", C.byref(st.desc), b.packed.data_ptr(), C.byref(cam), pix.data_ptr(), R, S,
-           ztab.data_ptr(), 1, td.data_ptr(), 0, 0, 1, float(3 * R), comp.data_ptr(), gws.data_ptr(), loss.data_ptr(),
+           ztab.data_ptr(), 1, td.data_ptr(), 0, 0, 1, float(3 * R), comp.data_ptr(), gws.data_ptr(), gws.numel(), loss.data_ptr(),
            bp.stash.data_ptr(), bp.jobs.data_ptr(), bp.n_jobs, bp.slabs.data_ptr(), bp.reduce.data_ptr(), st.grad.data_ptr(), s_)
     torch.cuda.synchronize()
     flat = st.grad.cpu().clone()

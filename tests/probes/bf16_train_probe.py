@@ -27,7 +27,7 @@ def grads_bf16(model, st, o, d, tgt, t, S, denom=None):
     comp = torch.empty(R, 3, device=dev); gws = torch.empty(R, 4, device=dev); loss = torch.zeros(1, device=dev)
     st.grad.zero_()
     L.call("tnerf_train_step_fused_bf16", C.byref(st.desc), b.packed.data_ptr(), o.data_ptr(), d.data_ptr(), tgt.data_ptr(), R, S,
-           ztab.data_ptr(), 1, t.data_ptr(), 0, 0, 1, float(denom or 3 * R), comp.data_ptr(), gws.data_ptr(), loss.data_ptr(),
+           ztab.data_ptr(), 1, t.data_ptr(), 0, 0, 1, float(denom or 3 * R), comp.data_ptr(), gws.data_ptr(), gws.numel(), loss.data_ptr(),
            bp.stash.data_ptr(), bp.jobs.data_ptr(), bp.n_jobs, bp.slabs.data_ptr(), bp.reduce.data_ptr(), st.grad.data_ptr(),
            torch.cuda.current_stream(dev).cuda_stream)
     torch.cuda.synchronize()
@@ -83,7 +83,7 @@ o, d = ro[idx].contiguous().to(dev), rd[idx].contiguous().to(dev)
 tgt = torch.rand(R, 3, device=dev); t = torch.rand(R, S, device=dev)
 b = st.repack_bf16(); bp = b.train_plan(R, S)
 ztab = ops.depth_table(2.0, 6.0, S, dev)
-comp = torch.empty(R, 3, device=dev); gws = torch.rand(R, 3, device=dev) * 1e-3; loss = torch.zeros(1, device=dev)
+comp = torch.empty(R, 3, device=dev); gws = torch.rand(R, 3, device=dev) * 1e-3; sws = torch.empty(4 * R, device=dev); loss = torch.zeros(1, device=dev)
 s_ = torch.cuda.current_stream(dev).cuda_stream
 calls = {
     "pack": lambda: L.call("tnerf_mlp_pack_bf16", C.byref(st.desc), st.flat.data_ptr(), b.table.data_ptr(), b.packed.data_ptr(), s_),
@@ -91,7 +91,7 @@ calls = {
     "dgrad": lambda: L.call("tnerf_train_dgrad_fused_bf16", C.byref(st.desc), b.packed.data_ptr(), o.data_ptr(), d.data_ptr(), R, S, ztab.data_ptr(), 1, t.data_ptr(), 0, 0, 1, gws.data_ptr(), bp.stash.data_ptr(), s_),
     "wgrad": lambda: L.call("tnerf_wgrad_bf16", C.byref(st.desc), bp.stash.data_ptr(), bp.n_tiles, bp.jobs.data_ptr(), bp.n_jobs, bp.slabs.data_ptr(), s_),
     "reduce": lambda: L.call("tnerf_wgrad_reduce", bp.slabs.data_ptr(), bp.reduce.data_ptr(), st.n_params, st.grad.data_ptr(), s_),
-    "step": lambda: L.call("tnerf_train_step_fused_bf16", C.byref(st.desc), b.packed.data_ptr(), o.data_ptr(), d.data_ptr(), tgt.data_ptr(), R, S, ztab.data_ptr(), 1, t.data_ptr(), 0, 0, 1, float(3 * R), comp.data_ptr(), gws.data_ptr(), loss.data_ptr(), bp.stash.data_ptr(), bp.jobs.data_ptr(), bp.n_jobs, bp.slabs.data_ptr(), bp.reduce.data_ptr(), st.grad.data_ptr(), s_),
+    "step": lambda: L.call("tnerf_train_step_fused_bf16", C.byref(st.desc), b.packed.data_ptr(), o.data_ptr(), d.data_ptr(), tgt.data_ptr(), R, S, ztab.data_ptr(), 1, t.data_ptr(), 0, 0, 1, float(3 * R), comp.data_ptr(), sws.data_ptr(), sws.numel(), loss.data_ptr(), bp.stash.data_ptr(), bp.jobs.data_ptr(), bp.n_jobs, bp.slabs.data_ptr(), bp.reduce.data_ptr(), st.grad.data_ptr(), s_),
 }
 for name, fn in calls.items():
     for _ in range(3):

@@ -17,6 +17,9 @@ S, Rg, seed = 40, 64, 9
 for arch in ((39, 200, 3, 2), (63, 64, 4, 2)):
     in_dim, hidden, depth, skip = arch; L = (in_dim - 3) // 6
     for pipe in ("x3", "fp32_mfma"):
+        if os.environ.get("POISON"):            # make every torch.empty below return NaN-filled memory: finds reads of unwritten workspace
+            junk = [torch.full((n,), float("nan"), device=dev) for n in (1 << 26, 1 << 22, 1 << 18, 1 << 14, 1 << 10)]
+            del junk
         torch.manual_seed(1)
         m = nerf.TinyNeRF(in_dim, hidden, depth, skip, matrix_pipe=pipe).to(dev)
         with torch.no_grad(): m.sigma[0].bias += 0.5
@@ -32,6 +35,9 @@ for arch in ((39, 200, 3, 2), (63, 64, 4, 2)):
             lo_, _, grads = O.loss_and_grads(ps, skip, L, ro[pix], rd[pix], pixs[s % N, pix], 2.0, 6.0, S, u)
             gh = m.hip_state().grad.cpu().clone(); go = torch.cat([x.reshape(-1) for x in grads])
             hist.append((gh, go))
+            nb = m.hip_state().flat.isnan().nonzero().flatten().cpu()
+            if bool(gh.isnan().any()) or nb.numel():
+                print(f"    step {s}: NaN gradients at {gh.isnan().nonzero().flatten()[:8].tolist()} ({int(gh.isnan().sum())}), NaN weights at {nb[:8].tolist()} ({nb.numel()}), loss {float(loss)}")
             adam.step(ps, grads)
         wh = torch.cat([p.detach().cpu().reshape(-1) for p in m.parameters()]); wo = torch.cat([q.reshape(-1) for q in ps])
         e = (wh - wo).abs(); k = int(e.argmax())

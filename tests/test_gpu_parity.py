@@ -649,7 +649,7 @@ def _bf16_step_grads(mods, dev, model, st, o, d, tgt, t, S, cam=None, pixels=Non
     comp = torch.empty(R, 3, device=dev); gws = torch.empty(R, 4, device=dev); loss = torch.zeros(1, device=dev)
     st.grad.zero_()
     s_ = torch.cuda.current_stream(dev).cuda_stream
-    tail = (comp.data_ptr(), gws.data_ptr(), loss.data_ptr(), bp.stash.data_ptr(), bp.jobs.data_ptr(), bp.n_jobs, bp.slabs.data_ptr(),
+    tail = (comp.data_ptr(), gws.data_ptr(), gws.numel(), loss.data_ptr(), bp.stash.data_ptr(), bp.jobs.data_ptr(), bp.n_jobs, bp.slabs.data_ptr(),
             bp.reduce.data_ptr(), st.grad.data_ptr(), s_)
     if cam is None:
         lib.call("tnerf_train_step_fused_bf16", C.byref(st.desc), b.packed.data_ptr(), o.data_ptr(), d.data_ptr(), tgt.data_ptr(), R, S,

@@ -481,23 +481,32 @@ def test_dataset_step_equals_the_per_call_path_bitwise(mods, dev, prec):
         m = make_model(mods, cfg, params, dev)
         o = T.FlatAdam(m, lr=5e-4)
         t = T.DatasetTrainer(m, o, images_d, poses_d, focal, Rg, S, 2.0, 6.0, seed=seed, precision=prec, graph=graph, record_pixels=True)
-        losses, pix = [], []
-        for _ in range(4):
+        losses, pix, bounds = [], [], []
+        for _ in range(6):
             l, _ = t.step()
             losses.append(l.clone()); pix.append(t.pix.clone())
-        return m, torch.stack(losses), pix, t
+            if prec == "fp32":
+                bounds.append(t._stash[-64:].clone())      # the stash's magnitude-bound words (what the weight-gradient kernel scales by)
+        return m, torch.stack(losses), pix, t, bounds
 
-    ma, la, pixa, ta = run(True)
-    mb, lb, pixb, tb = run(False)
+    ma, la, pixa, ta, ba = run(True)
+    mb, lb, pixb, tb, bb = run(False)
     assert ta._graph is not None and tb._graph is None
     assert torch.equal(la, lb) and all(torch.equal(a, b) for a, b in zip(ma.parameters(), mb.parameters()))
+    # every replay clears and refills the bound words like an eager step does (a captured hipMemsetAsync did not: from the second
+    # replay on the node wrote a stale pattern — the words are cleared by a kernel since)
+    for s, (x, y) in enumerate(zip(ba, bb)):
+        assert torch.equal(x, y), (s, x.tolist(), y.tolist())
+        used = [l for l in range(cfg["depth"])] + [16] + [17 + l for l in range(cfg["depth"])] + [33]
+        rest = torch.ones(64, dtype=torch.bool); rest[used] = False
+        assert bool((x.cpu()[rest] == 0).all()) and bool((x.cpu()[used] > 0).all()), (s, x.tolist())
     # (c) the per-call path with the same draws
     mc = make_model(mods, cfg, params, dev)
     oc = T.FlatAdam(mc, lr=5e-4)
     tc = T.FusedTrainer(mc, oc, 2.0, 6.0, S, precision=prec)
     pixels = images_d.view(N, H * W, 3)
     lc = []
-    for s in range(4):
+    for s in range(6):
         l, _ = tc.step_camera(poses_d[s % N], H, W, focal, pixa[s].long(), pixels[s % N], philox=(seed, s * Rg * S))
         lc.append(l.clone())
     assert torch.equal(torch.stack(lc), la)
@@ -599,7 +608,8 @@ def test_hidden_widths_other_than_128_and_256(mods, dev, arch):
         # the same 1e-4).  Those elements may be off by up to the three steps' 3 lr; every other element must sit on the oracle's.
         noisy = gmin < 1e-6
         assert float(err[~noisy].max()) <= (5e-5 if prec == "fp32" else 2e-3), (prec, float(err[~noisy].max()))
-        assert float(err.max()) <= 3 * 5e-4 * 1.01, (prec, float(err.max()))
+        # (bf16: the two trajectories may step in opposite directions at such an element)
+        assert float(err.max()) <= (3 if prec == "fp32" else 6) * 5e-4 * 1.01, (prec, float(err.max()))
         assert int(noisy.sum()) < 0.5 * err.numel()
 
 

@@ -34,8 +34,75 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in tnerf.h but not exported"
         assert name in tl.SIGNATURES, f"{name} has no ctypes signature"
-    assert lib.tnerf_version() == 2
+    assert lib.tnerf_version() == tl.ABI_VERSION == 3
+    assert int(re.search(r"#define TNERF_ABI_VERSION (\d+)", hdr).group(1)) == 3
     assert tl.last_error() == "ok"
+
+
+def test_step_args_struct_layout_matches_the_header(tmp_path):
+    """The ctypes mirror of tnerf_step_args / tnerf_camera / the size structs has the C compiler's layout for include/tnerf.h
+    (a binding that drifts from the header corrupts every field after the drift)."""
+    import subprocess
+    fields = [n for n, _ in tl.StepArgs._fields_]
+    src = tmp_path / "layout.c"
+    body = "".join(f'    printf("{n} %zu\\n", offsetof(tnerf_step_args, {n}));\n' for n in fields)
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "tnerf.h"\nint main(void) {\n' + body +
+                   '    printf("sizeof %zu\\n", sizeof(tnerf_step_args));\n'
+                   '    printf("camera %zu\\n", sizeof(tnerf_camera));\n'
+                   '    printf("plan %zu\\n", sizeof(tnerf_plan_sizes));\n'
+                   '    printf("bf16 %zu %zu\\n", sizeof(tnerf_bf16_sizes), sizeof(tnerf_bf16_train_plan));\n    return 0;\n}\n')
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = dict(l.split(" ", 1) for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for n in fields:
+        assert int(out[n]) == getattr(tl.StepArgs, n).offset, n
+    assert int(out["sizeof"]) == C.sizeof(tl.StepArgs)
+    assert int(out["camera"]) == C.sizeof(tl.Camera)
+    assert int(out["plan"]) == C.sizeof(tl.PlanSizes)
+    assert out["bf16"].split() == [str(C.sizeof(tl.Bf16Sizes)), str(C.sizeof(tl.Bf16TrainPlan))]
+
+
+def test_undersized_workspaces_are_refused_before_any_launch():
+    """ABI 3: the per-ray workspace and the stash carry their capacity; a buffer sized for another library version (ABI 1's
+    3*R floats, a stash without the bound words) is TNERF_ESMALL — checked on the host before the first launch, which is why
+    this runs without a GPU: were anything launched here, the call would fail with a HIP error instead."""
+    lib = tl.load()
+    assert lib.tnerf_train_ws_floats(4096) == 4 * 4096 and tl.train_ws_floats(1) == 4
+    assert lib.tnerf_train_ws_floats(0) == tl.EINVAL and "n_rays=0" in tl.last_error()
+    d = _desc(39, 256, 8, 4)
+    R, S, fake = 64, 32, 0x10000                          # never dereferenced: every call below must fail in validation
+    ws_ok = tl.train_ws_floats(R)
+    sz = tl.PlanSizes(); assert lib.tnerf_plan_sizes_query(C.byref(d), R * S, 256, C.byref(sz)) == 0
+    for name, cam in (("tnerf_train_step_fused", False), ("tnerf_train_step_fused_cam", True)):
+        for ws in (3 * R, ws_ok - 1):
+            head = (C.byref(d), fake) + ((C.byref(tl.Camera(fake, 8, 8, 10.0, fake, 0)), fake) if cam else (fake, fake, fake))
+            rc = getattr(lib, name)(*head, R, S, fake, 1, None, 0, 0, 1, float(3 * R), fake, fake, ws, fake, fake, sz.stash_row_stride,
+                                    fake, sz.n_jobs, fake, fake, fake, None, None)
+            assert rc == tl.ESMALL, (name, ws, tl.last_error())
+            assert "tnerf_train_ws_floats" in tl.last_error()
+    for name, cam in (("tnerf_train_step_fused_bf16", False), ("tnerf_train_step_fused_cam_bf16", True)):
+        head = (C.byref(d), fake) + ((C.byref(tl.Camera(fake, 8, 8, 10.0, fake, 0)), fake) if cam else (fake, fake, fake))
+        rc = getattr(lib, name)(*head, R, S, fake, 1, None, 0, 0, 1, float(3 * R), fake, fake, 3 * R, fake, fake, fake, 4, fake, fake, fake, None)
+        assert rc == tl.ESMALL, (name, tl.last_error())
+    # the dataset step: per-ray workspace, fp32 stash, bf16 stash
+    def args(precision):
+        a = tl.StepArgs()
+        a.desc, a.precision, a.phases = d, precision, tl.PHASE_GRADIENT
+        a.poses = a.pixels = a.ztab = a.step = a.packed = a.comp_rgb = a.ray_ws = a.stash = a.job_table = a.slabs = fake
+        a.n_images, a.H, a.W, a.focal = 2, 8, 8, 10.0
+        a.n_rays, a.ray_first, a.n_rays_global, a.n_samples = R, 0, R, S
+        a.loss_denominator, a.n_jobs = 3.0 * R, sz.n_jobs
+        a.ray_ws_floats, a.stash_row_stride, a.stash_capacity = ws_ok, sz.stash_row_stride, sz.stash_floats
+        return a
+    a = args(0); a.ray_ws_floats = 3 * R
+    assert lib.tnerf_train_step_dataset(C.byref(a), None) == tl.ESMALL and "per-ray workspace" in tl.last_error()
+    a = args(0); a.stash_capacity = sz.stash_floats - 1
+    assert lib.tnerf_train_step_dataset(C.byref(a), None) == tl.ESMALL and "stash_floats" in tl.last_error()
+    a = args(0); a.stash_row_stride = R * S - 64
+    assert lib.tnerf_train_step_dataset(C.byref(a), None) == tl.EINVAL and "stash_row_stride" in tl.last_error()
+    bp = tl.Bf16TrainPlan(); assert lib.tnerf_bf16_train_sizes(C.byref(d), R, S, 256, C.byref(bp)) == 0
+    a = args(1); a.stash_capacity = bp.stash_bytes - 1
+    assert lib.tnerf_train_step_dataset(C.byref(a), None) == tl.ESMALL and "stash_bytes" in tl.last_error()
 
 
 def test_error_reporting_no_throw():

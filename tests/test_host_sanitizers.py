@@ -28,9 +28,9 @@ def test_host_planner_under_asan_ubsan(tmp_path):
     env = dict(os.environ, TNERF_LIB=so, TNERF_HOST_ONLY="1", LD_PRELOAD=" ".join(p for p in (asan, ubsan) if os.path.exists(p)),
                ASAN_OPTIONS="detect_leaks=0:abort_on_error=1:verify_asan_link_order=0", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1",
                OMP_NUM_THREADS="2")
-    # every host-logic test except the one that needs the GPU symbols of the full library
+    # every host-logic test except the ones that need the GPU entry points of the full library
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_host_logic.py"), "-x", "-q", "-p", "no:cacheprovider",
-                        "-k", "not exports_every_declared_symbol and not oracle_bf16"], env=env, capture_output=True, text=True, cwd=ROOT)
+                        "-k", "not exports_every_declared_symbol and not oracle_bf16 and not undersized_workspaces"], env=env, capture_output=True, text=True, cwd=ROOT)
     tail = (r.stdout + r.stderr)[-3000:]
     assert r.returncode == 0, tail
     assert "passed" in r.stdout and "AddressSanitizer" not in tail and "runtime error" not in tail, tail

@@ -20,6 +20,38 @@ extern "C" void tn_set_error(const char* fmt, ...) {
 
 extern "C" int tnerf_version(void) { return TNERF_ABI_VERSION; }
 extern "C" const char* tnerf_last_error_string(void) { return g_err; }
+// Per-ray workspace of the fused train steps: dL/dcomp_rgb (3) and the squared error (1) of every ray, one 16-byte store per ray.
+extern "C" int64_t tnerf_train_ws_floats(int64_t n_rays) {
+    if (n_rays < 1) { tn_set_error("tnerf_train_ws_floats: n_rays=%lld", (long long)n_rays); return TNERF_EINVAL; }
+    return TN_RAY_WS_FLOATS * n_rays;
+}
+// Capacity checks of caller-allocated workspaces whose required size depends on the library version (the layout of the per-ray
+// workspace and of the stash are private to it): an undersized buffer is an error before anything is launched, not a write
+// past its end.
+extern "C" int tn_check_ray_ws(const char* who, int64_t n_rays, int64_t ws_floats) {
+    if (ws_floats >= TN_RAY_WS_FLOATS * n_rays) return TNERF_OK;
+    tn_set_error("%s: per-ray workspace of %lld floats, %lld rays need tnerf_train_ws_floats() = %lld", who, (long long)ws_floats,
+                 (long long)n_rays, (long long)(TN_RAY_WS_FLOATS * n_rays));
+    return TNERF_ESMALL;
+}
+extern "C" int tn_check_stash32(const char* who, const tnerf_mlp_desc* d, int64_t M, int64_t stride, int64_t capacity) {
+    MlpLayout L; int rc = tn_build_layout(d, &L); if (rc) return rc;
+    if (stride < M || (stride & 63)) { tn_set_error("%s: stash_row_stride=%lld for %lld samples (tnerf_plan_sizes.stash_row_stride: a multiple of 64 >= the samples)", who,
+                                                     (long long)stride, (long long)M); return TNERF_EINVAL; }
+    const int64_t need = TN_BOUND_OFF(L, stride) + TN_BOUND_FLOATS;                  // = tnerf_plan_sizes.stash_floats of `stride` samples
+    if (capacity >= need) return TNERF_OK;
+    tn_set_error("%s: stash of %lld floats, row stride %lld needs tnerf_plan_sizes.stash_floats = %lld", who, (long long)capacity, (long long)stride, (long long)need);
+    return TNERF_ESMALL;
+}
+extern "C" int tn_check_stash16(const char* who, const tnerf_mlp_desc* d, int64_t n_rays, int32_t n_samples, int64_t capacity) {
+    Net16 n; int rc = tn_build_net16(d, &n); if (rc) return rc;
+    const int64_t tiles = n_rays * ((n_samples + 31) / 32);
+    const int64_t need = TN16_STASH_FRAG_BYTES(n, tiles) + TN16_STASH_MASK_BYTES(n, tiles) + TN16_STASH_OUT_BYTES(n, tiles);
+    if (capacity >= need) return TNERF_OK;
+    tn_set_error("%s: bf16 stash of %lld bytes, %lld rays x %d samples need tnerf_bf16_train_plan.stash_bytes = %lld", who, (long long)capacity,
+                 (long long)n_rays, n_samples, (long long)need);
+    return TNERF_ESMALL;
+}
 
 // ---------------------------------------------------------------------------- depth tables
 // torch.linspace(0,1,S) on CPU fp32 (ATen RangeFactories): step = (end-start)/(S-1) in fp32,

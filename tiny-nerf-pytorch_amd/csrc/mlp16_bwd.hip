@@ -402,7 +402,7 @@ int tn_step16_core(const char* who, const tnerf_mlp_desc* d, const void* packed1
 static int train16_step_impl(const char* who, const tnerf_mlp_desc* d, const void* packed16, const RaySource& rs, const float* target,
                              const int64_t* target_index, int64_t R, int32_t S, const float* ztab, int32_t randomized,
                              const float* t_rand, uint64_t seed, uint64_t offset, int32_t white, double loss_denominator,
-                             float* comp_rgb, float* g_comp_ws, float* loss_out, void* stash16, const int32_t* job_table,
+                             float* comp_rgb, float* g_comp_ws, int64_t ws_floats, float* loss_out, void* stash16, const int32_t* job_table,
                              int64_t n_jobs, float* slabs, const int32_t* reduce_table, float* grads, hipStream_t stream) {
     if (!target || !comp_rgb || !g_comp_ws || !loss_out || !(loss_denominator > 0.0) || R < 1 || !job_table || n_jobs < 1 || !slabs ||
         !reduce_table || !grads) {
@@ -411,8 +411,9 @@ static int train16_step_impl(const char* who, const tnerf_mlp_desc* d, const voi
                      (const void*)job_table, (long long)n_jobs, (void*)slabs, (const void*)reduce_table, (void*)grads);
         return TNERF_EINVAL;
     }
+    int rc = tn_check_ray_ws(who, R, ws_floats); if (rc) return rc;
     const LossArgs loss{target, target_index, (float)(1.0 / loss_denominator), g_comp_ws, nullptr};
-    int rc = tn_step16_core(who, d, packed16, rs, TnStepRef{}, loss, R, S, ztab, randomized, t_rand, seed, offset, white, comp_rgb, stash16,
+    rc = tn_step16_core(who, d, packed16, rs, TnStepRef{}, loss, R, S, ztab, randomized, t_rand, seed, offset, white, comp_rgb, stash16,
                             job_table, n_jobs, slabs, stream);
     if (rc) return rc;
     FinishArgs f{};
@@ -424,22 +425,22 @@ static int train16_step_impl(const char* who, const tnerf_mlp_desc* d, const voi
 extern "C" int tnerf_train_step_fused_bf16(const tnerf_mlp_desc* d, const void* packed16, const float* rays_o, const float* rays_d,
                                            const float* target, int64_t R, int32_t S, const float* ztab, int32_t randomized,
                                            const float* t_rand, uint64_t seed, uint64_t offset, int32_t white, double loss_denominator,
-                                           float* comp_rgb, float* g_comp_ws, float* loss_out, void* stash16, const int32_t* job_table,
+                                           float* comp_rgb, float* g_comp_ws, int64_t g_comp_ws_floats, float* loss_out, void* stash16, const int32_t* job_table,
                                            int64_t n_jobs, float* slabs, const int32_t* reduce_table, float* grads, tnerf_stream_t stream) {
     return train16_step_impl("tnerf_train_step_fused_bf16", d, packed16, tn_table_source(rays_o, rays_d), target, nullptr, R, S, ztab,
-                             randomized, t_rand, seed, offset, white, loss_denominator, comp_rgb, g_comp_ws, loss_out, stash16, job_table,
+                             randomized, t_rand, seed, offset, white, loss_denominator, comp_rgb, g_comp_ws, g_comp_ws_floats, loss_out, stash16, job_table,
                              n_jobs, slabs, reduce_table, grads, (hipStream_t)stream);
 }
 
 extern "C" int tnerf_train_step_fused_cam_bf16(const tnerf_mlp_desc* d, const void* packed16, const tnerf_camera* cam, const float* pixels,
                                                int64_t R, int32_t S, const float* ztab, int32_t randomized, const float* t_rand,
                                                uint64_t seed, uint64_t offset, int32_t white, double loss_denominator, float* comp_rgb,
-                                               float* g_comp_ws, float* loss_out, void* stash16, const int32_t* job_table, int64_t n_jobs,
+                                               float* g_comp_ws, int64_t g_comp_ws_floats, float* loss_out, void* stash16, const int32_t* job_table, int64_t n_jobs,
                                                float* slabs, const int32_t* reduce_table, float* grads, tnerf_stream_t stream) {
     RaySource rs;
     int rc = tn_camera_source("tnerf_train_step_fused_cam_bf16", cam, R, &rs); if (rc) return rc;
     if (!cam->pix_index) { tn_set_error("tnerf_train_step_fused_cam_bf16: pix_index is required (it also selects the target pixels)"); return TNERF_EINVAL; }
     return train16_step_impl("tnerf_train_step_fused_cam_bf16", d, packed16, rs, pixels, cam->pix_index, R, S, ztab, randomized, t_rand, seed,
-                             offset, white, loss_denominator, comp_rgb, g_comp_ws, loss_out, stash16, job_table, n_jobs, slabs, reduce_table,
+                             offset, white, loss_denominator, comp_rgb, g_comp_ws, g_comp_ws_floats, loss_out, stash16, job_table, n_jobs, slabs, reduce_table,
                              grads, (hipStream_t)stream);
 }

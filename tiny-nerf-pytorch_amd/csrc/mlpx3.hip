@@ -562,11 +562,18 @@ int tnx3_train_dgrad(const char* who, const BwdArgs& b, const tnerf_mlp_desc* d,
     return tnx3_launch_dgrad(a, false, stream, who);
 }
 
+// Clears a few words.  A kernel, NOT hipMemsetAsync: these launches are captured into the train step's hipGraph, and on ROCm 7.0 a
+// captured memset node writes a stale 16-byte pattern instead of its value from the second replay on (measured: tests/probes/
+// bound_words_probe.py; eager launches and the first replay are fine) — the bound words then carry garbage, NaN bit patterns included.
+__global__ void k_zero_words(unsigned* __restrict__ w, int n) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) w[i] = 0u;
+}
+
 int tnx3_launch_fwd(const FwdX3Args& a, bool train, hipStream_t stream, const char* who, bool mlp_only = false) {
     const int dev = tn_stream_device(stream), n_cu = tn_device_cus(dev);
     if (train) {       // the stash's magnitude bounds start from zero with every training forward (the dgrad kernel adds its own)
-        const hipError_t e = hipMemsetAsync(a.f.stash + TN_BOUND_OFF(a.f.L, a.f.Mp), 0, TN_BOUND_FLOATS * 4, stream);
-        if (e != hipSuccess) { tn_set_error("%s: hipMemsetAsync: %s", who, hipGetErrorString(e)); return (int)e; }
+        hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, stream, reinterpret_cast<unsigned*>(a.f.stash + TN_BOUND_OFF(a.f.L, a.f.Mp)), TN_BOUND_FLOATS);
+        TN_HIP_CHECK_LAUNCH(who);
     }
     const int nw = a.n.hidden == 256 ? 4 : (train ? TxCfg<128, true>::NW : TxCfg<128, false>::NW);
     const int64_t units = mlp_only ? (a.f.M + 31) / 32 : a.f.R, groups = (units + nw - 1) / nw;
@@ -742,8 +749,8 @@ __global__ __launch_bounds__(64) void k_x3stats_final(int n_layers, float* __res
 int tnx3_launch_stats(const NetX3& n, const float* params, const int32_t* table, void* packed3, int post, hipStream_t stream) {
     float* meta = reinterpret_cast<float*>(static_cast<unsigned char*>(packed3) + n.meta_off);
     if (!post) {                                                               // full scan (the buffer may be fresh memory: clear first)
-        const hipError_t e = hipMemsetAsync(meta, 0, (size_t)(n.depth + 1) * TX_META * 4, stream);
-        if (e != hipSuccess) { tn_set_error("x3 weight statistics: hipMemsetAsync: %s", hipGetErrorString(e)); return (int)e; }
+        hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, stream, reinterpret_cast<unsigned*>(meta), (n.depth + 1) * TX_META);
+        TN_HIP_CHECK_LAUNCH("x3 weight statistics (clear)");
         hipLaunchKernelGGL(k_x3stats_scan, dim3((unsigned)((n.depth + 1) * TX_SCAN_NB)), dim3(256), 0, stream, params, table, n, meta);
         TN_HIP_CHECK_LAUNCH("x3 weight statistics (scan)");
     }

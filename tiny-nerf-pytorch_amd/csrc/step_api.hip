@@ -24,6 +24,12 @@ static int check_step_args(const tnerf_step_args* a) {
                      (const void*)a->job_table, (long long)a->n_jobs, (void*)a->slabs, a->loss_denominator);
         return TNERF_EINVAL;
     }
+    if (p1) {
+        int rc = tn_check_ray_ws("tnerf_train_step_dataset", a->n_rays, a->ray_ws_floats); if (rc) return rc;
+        rc = a->precision == 0 ? tn_check_stash32("tnerf_train_step_dataset", &a->desc, a->n_rays * a->n_samples, a->stash_row_stride, a->stash_capacity)
+                               : tn_check_stash16("tnerf_train_step_dataset", &a->desc, a->n_rays, a->n_samples, a->stash_capacity);
+        if (rc) return rc;
+    }
     if (p2 && (!a->slabs || !a->reduce_table || !a->grads)) { tn_set_error("tnerf_train_step_dataset: reduce phase needs slabs, reduce_table, grads"); return TNERF_EINVAL; }
     if (p3 && (!a->grads || !a->params || !a->exp_avg || !a->exp_avg_sq || !a->step || !(a->lr >= 0.0f) ||
                (a->scatter_table && (a->scatter_width < 1 || !a->packed)) ||

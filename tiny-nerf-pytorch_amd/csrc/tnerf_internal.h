@@ -142,6 +142,9 @@ int  tn_build_netx3(const tnerf_mlp_desc* d, NetX3* n);        // 0 or TNERF_E*
 int  tn_build_layout(const tnerf_mlp_desc* d, MlpLayout* L);   // 0 or TNERF_E*
 int  tn_build_net16(const tnerf_mlp_desc* d, Net16* n);        // 0 or TNERF_E*
 void tn_set_error(const char* fmt, ...);
+int  tn_check_ray_ws(const char* who, int64_t n_rays, int64_t ws_floats);                        // 0 or TNERF_ESMALL
+int  tn_check_stash32(const char* who, const tnerf_mlp_desc* d, int64_t n_samples_total, int64_t stride, int64_t capacity_floats);
+int  tn_check_stash16(const char* who, const tnerf_mlp_desc* d, int64_t n_rays, int32_t n_samples, int64_t capacity_bytes);
 #ifdef __cplusplus
 }
 #endif
@@ -155,6 +158,7 @@ void tn_set_error(const char* fmt, ...);
 //   word index ((l*(Mp+32) + m)*2 + h) * (hidden/64) + t/2,  bit (t&1)*16 + r   <->  feature 32t + TN_ACC_ROW(r,h)
 // One extra ("dump") block / sample slot follows the Mp real ones: lanes that pad a ragged tile store there, so
 // that no store in the hot loops needs a per-lane branch.
+#define TN_RAY_WS_FLOATS 4                               // floats per ray of the train steps' workspace (tnerf_train_ws_floats)
 #define TN_STASH_BODY_FLOATS(L, Mp) ((int64_t)(L).stash_rows * ((Mp) + 32))
 #define TN_MASK_FLOATS(L, Mp) ((int64_t)(L).depth * ((Mp) + 32) * ((L).hidden / 32))
 #define TN_BOUND_OFF(L, Mp) (TN_STASH_BODY_FLOATS(L, Mp) + TN_MASK_FLOATS(L, Mp))      // float offset of the bound words

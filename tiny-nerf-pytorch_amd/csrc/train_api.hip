@@ -156,7 +156,7 @@ int tn_step32_core(const char* who, const tnerf_mlp_desc* d, const float* packed
 static int train_step_impl(const char* who, const tnerf_mlp_desc* d, const float* packed, const RaySource& rs, const float* target,
                            const int64_t* target_index, int64_t R, int32_t S, const float* ztab, int32_t randomized,
                            const float* t_rand, uint64_t seed, uint64_t offset, int32_t white, double loss_denominator,
-                           float* comp_rgb, float* g_comp_ws, float* loss_out, float* stash, int64_t Mp,
+                           float* comp_rgb, float* g_comp_ws, int64_t ws_floats, float* loss_out, float* stash, int64_t Mp,
                            const int32_t* job_table, int64_t n_jobs, float* slabs, const int32_t* reduce_table,
                            float* grads, const void* packed_x3, hipStream_t stream) {
     if (!target || !comp_rgb || !g_comp_ws || !loss_out || !(loss_denominator > 0.0) || R < 1) {
@@ -165,8 +165,9 @@ static int train_step_impl(const char* who, const tnerf_mlp_desc* d, const float
         return TNERF_EINVAL;
     }
     if (!reduce_table || !grads) { tn_set_error("%s: reduce_table=%p grads=%p", who, (const void*)reduce_table, (void*)grads); return TNERF_EINVAL; }
+    int rc = tn_check_ray_ws(who, R, ws_floats); if (rc) return rc;
     const LossArgs loss{target, target_index, (float)(1.0 / loss_denominator), g_comp_ws, nullptr};
-    int rc = tn_step32_core(who, d, packed, packed_x3, rs, TnStepRef{}, loss, R, S, ztab, randomized, t_rand, seed, offset, white, comp_rgb, stash, Mp,
+    rc = tn_step32_core(who, d, packed, packed_x3, rs, TnStepRef{}, loss, R, S, ztab, randomized, t_rand, seed, offset, white, comp_rgb, stash, Mp,
                             job_table, n_jobs, slabs, stream);
     if (rc) return rc;
     FinishArgs f{};
@@ -178,25 +179,25 @@ static int train_step_impl(const char* who, const tnerf_mlp_desc* d, const float
 extern "C" int tnerf_train_step_fused(const tnerf_mlp_desc* d, const float* packed, const float* rays_o, const float* rays_d,
                                       const float* target, int64_t R, int32_t S, const float* ztab, int32_t randomized,
                                       const float* t_rand, uint64_t seed, uint64_t offset, int32_t white, double loss_denominator,
-                                      float* comp_rgb, float* g_comp_ws, float* loss_out, float* stash, int64_t Mp,
+                                      float* comp_rgb, float* g_comp_ws, int64_t g_comp_ws_floats, float* loss_out, float* stash, int64_t Mp,
                                       const int32_t* job_table, int64_t n_jobs, float* slabs, const int32_t* reduce_table,
                                       float* grads, const void* packed_x3, tnerf_stream_t stream) {
     return train_step_impl("tnerf_train_step_fused", d, packed, tn_table_source(rays_o, rays_d), target, nullptr, R, S, ztab, randomized,
-                           t_rand, seed, offset, white, loss_denominator, comp_rgb, g_comp_ws, loss_out, stash, Mp, job_table, n_jobs,
+                           t_rand, seed, offset, white, loss_denominator, comp_rgb, g_comp_ws, g_comp_ws_floats, loss_out, stash, Mp, job_table, n_jobs,
                            slabs, reduce_table, grads, packed_x3, (hipStream_t)stream);
 }
 
 extern "C" int tnerf_train_step_fused_cam(const tnerf_mlp_desc* d, const float* packed, const tnerf_camera* cam, const float* pixels,
                                           int64_t R, int32_t S, const float* ztab, int32_t randomized, const float* t_rand,
                                           uint64_t seed, uint64_t offset, int32_t white, double loss_denominator, float* comp_rgb,
-                                          float* g_comp_ws, float* loss_out, float* stash, int64_t Mp, const int32_t* job_table,
+                                          float* g_comp_ws, int64_t g_comp_ws_floats, float* loss_out, float* stash, int64_t Mp, const int32_t* job_table,
                                           int64_t n_jobs, float* slabs, const int32_t* reduce_table, float* grads,
                                           const void* packed_x3, tnerf_stream_t stream) {
     RaySource rs;
     int rc = tn_camera_source("tnerf_train_step_fused_cam", cam, R, &rs); if (rc) return rc;
     if (!cam->pix_index) { tn_set_error("tnerf_train_step_fused_cam: pix_index is required (it also selects the target pixels)"); return TNERF_EINVAL; }
     return train_step_impl("tnerf_train_step_fused_cam", d, packed, rs, pixels, cam->pix_index, R, S, ztab, randomized, t_rand, seed,
-                           offset, white, loss_denominator, comp_rgb, g_comp_ws, loss_out, stash, Mp, job_table, n_jobs, slabs,
+                           offset, white, loss_denominator, comp_rgb, g_comp_ws, g_comp_ws_floats, loss_out, stash, Mp, job_table, n_jobs, slabs,
                            reduce_table, grads, packed_x3, (hipStream_t)stream);
 }
 

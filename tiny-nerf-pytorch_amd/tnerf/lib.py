@@ -43,8 +43,8 @@ class StepArgs(C.Structure):
                 ("n_rays", C.c_int64), ("ray_first", C.c_int64), ("n_rays_global", C.c_int64), ("n_samples", C.c_int32), ("white_bkgd", C.c_int32),
                 ("ztab", C.c_void_p), ("seed", C.c_uint64), ("loss_denominator", C.c_double), ("step", C.c_void_p),
                 ("packed", C.c_void_p),
-                ("comp_rgb", C.c_void_p), ("ray_ws", C.c_void_p), ("pix_out", C.c_void_p), ("loss_out", C.c_void_p),
-                ("stash", C.c_void_p), ("stash_row_stride", C.c_int64),
+                ("comp_rgb", C.c_void_p), ("ray_ws", C.c_void_p), ("ray_ws_floats", C.c_int64), ("pix_out", C.c_void_p), ("loss_out", C.c_void_p),
+                ("stash", C.c_void_p), ("stash_row_stride", C.c_int64), ("stash_capacity", C.c_int64),
                 ("job_table", C.c_void_p), ("n_jobs", C.c_int64), ("slabs", C.c_void_p), ("reduce_table", C.c_void_p), ("grads", C.c_void_p),
                 ("params", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
                 ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
@@ -54,7 +54,7 @@ class StepArgs(C.Structure):
 
 
 PHASE_GRADIENT, PHASE_REDUCE, PHASE_UPDATE = 1, 2, 4
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _P = C.c_void_p           # device pointers travel as integers (tensor.data_ptr())
 _I32, _I64, _U64, _F, _D = C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_double
@@ -86,11 +86,12 @@ SIGNATURES = {
     "tnerf_train_dgrad_fused": (C.c_int, [_DESC, _P, _P, _P, _I64, _I32, _P, _I32, _P, _U64, _U64, _I32, _P, _P, _I64, _P]),
     "tnerf_wgrad": (C.c_int, [_DESC, _P, _I64, _I64, _P, _I64, _P, _P]),
     "tnerf_wgrad_reduce": (C.c_int, [_P, _P, _I64, _P, _P]),
+    "tnerf_train_ws_floats": (C.c_int64, [_I64]),
     "tnerf_train_step_fused": (C.c_int, [_DESC, _P, _P, _P, _P, _I64, _I32, _P, _I32, _P, _U64, _U64, _I32, _D,
-                                         _P, _P, _P, _P, _I64, _P, _I64, _P, _P, _P, _P, _P]),
+                                         _P, _P, _I64, _P, _P, _I64, _P, _I64, _P, _P, _P, _P, _P]),
     "tnerf_render_fused_cam": (C.c_int, [_DESC, _P, C.POINTER(Camera), _I64, _I32, _P, _I32, _P, _U64, _U64, _I32, _P, _P, _P, _P]),
     "tnerf_train_step_fused_cam": (C.c_int, [_DESC, _P, C.POINTER(Camera), _P, _I64, _I32, _P, _I32, _P, _U64, _U64, _I32, _D,
-                                             _P, _P, _P, _P, _I64, _P, _I64, _P, _P, _P, _P, _P]),
+                                             _P, _P, _I64, _P, _P, _I64, _P, _I64, _P, _P, _P, _P, _P]),
     "tnerf_bf16_plan_sizes": (C.c_int, [_DESC, C.POINTER(Bf16Sizes)]),
     "tnerf_bf16_pack_table": (C.c_int, [_DESC, _P]),
     "tnerf_mlp_pack_bf16": (C.c_int, [_DESC, _P, _P, _P, _P]),
@@ -102,9 +103,9 @@ SIGNATURES = {
     "tnerf_train_dgrad_fused_bf16": (C.c_int, [_DESC, _P, _P, _P, _I64, _I32, _P, _I32, _P, _U64, _U64, _I32, _P, _P, _P]),
     "tnerf_wgrad_bf16": (C.c_int, [_DESC, _P, _I64, _P, _I64, _P, _P]),
     "tnerf_train_step_fused_bf16": (C.c_int, [_DESC, _P, _P, _P, _P, _I64, _I32, _P, _I32, _P, _U64, _U64, _I32, _D,
-                                              _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P]),
+                                              _P, _P, _I64, _P, _P, _P, _I64, _P, _P, _P, _P]),
     "tnerf_train_step_fused_cam_bf16": (C.c_int, [_DESC, _P, C.POINTER(Camera), _P, _I64, _I32, _P, _I32, _P, _U64, _U64, _I32, _D,
-                                                  _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P]),
+                                                  _P, _P, _I64, _P, _P, _P, _I64, _P, _P, _P, _P]),
     "tnerf_adam_step": (C.c_int, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _I64, _F, _P]),
     "tnerf_x3_plan_sizes": (C.c_int, [_DESC, C.POINTER(Bf16Sizes)]),
     "tnerf_x3_pack_table": (C.c_int, [_DESC, _P]),
@@ -166,6 +167,14 @@ def check(rc: int, what: str = "") -> None:
     if rc < 0:
         raise ValueError(f"{what}: {msg} (code {rc})")
     raise RuntimeError(f"{what}: HIP/RCCL error {rc}: {msg}")
+
+
+def train_ws_floats(n_rays: int) -> int:
+    """tnerf_train_ws_floats: floats of the per-ray workspace (g_comp_ws / tnerf_step_args.ray_ws) for n_rays rays."""
+    n = int(load().tnerf_train_ws_floats(int(n_rays)))
+    if n < 0:
+        raise TnerfError(n, "tnerf_train_ws_floats", last_error())
+    return n
 
 
 def call(name: str, *args) -> None:

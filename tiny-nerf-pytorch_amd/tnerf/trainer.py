@@ -118,7 +118,7 @@ class FusedTrainer:
         R = rays_o.shape[0]
         if self._comp is None or self._comp.shape[0] != R:
             self._comp = torch.empty(R, 3, dtype=torch.float32, device=dev)
-            self._gws = torch.empty(R, 4, dtype=torch.float32, device=dev)      # per ray: dL/dcomp_rgb + squared error (ABI 2)
+            self._gws = torch.empty(_l.train_ws_floats(R), dtype=torch.float32, device=dev)      # per ray: dL/dcomp_rgb + squared error
         ztab = _ops.depth_table(self.near, self.far, self.S, dev)
         rnd, tr, seed, off = _ops._rng_args(randomized, t_rand, philox)
         if tr is not None:
@@ -129,7 +129,7 @@ class FusedTrainer:
             bp = b.train_plan(R, self.S)
             _l.call("tnerf_train_step_fused_bf16", C.byref(st.desc), b.packed.data_ptr(), rays_o.data_ptr(), rays_d.data_ptr(),
                     target.data_ptr(), R, self.S, ztab.data_ptr(), rnd, _ops._ptr(tr), seed, off, self.white, denom,
-                    self._comp.data_ptr(), self._gws.data_ptr(), self.loss.data_ptr(), bp.stash.data_ptr(),
+                    self._comp.data_ptr(), self._gws.data_ptr(), self._gws.numel(), self.loss.data_ptr(), bp.stash.data_ptr(),
                     bp.jobs.data_ptr(), bp.n_jobs, bp.slabs.data_ptr(), bp.reduce.data_ptr(), st.grad.data_ptr(),
                     torch.cuda.current_stream(dev).cuda_stream)
             _dist.all_reduce_sum_(st.grad)
@@ -140,7 +140,7 @@ class FusedTrainer:
         with plan.lease() as stash:               # not the buffer a pending autograd node of the same size may still hold
             _l.call("tnerf_train_step_fused", C.byref(st.desc), st.packed.data_ptr(), rays_o.data_ptr(), rays_d.data_ptr(),
                     target.data_ptr(), R, self.S, ztab.data_ptr(), rnd, _ops._ptr(tr), seed, off, self.white, denom,
-                    self._comp.data_ptr(), self._gws.data_ptr(), self.loss.data_ptr(), stash.data_ptr(), plan.Mp,
+                    self._comp.data_ptr(), self._gws.data_ptr(), self._gws.numel(), self.loss.data_ptr(), stash.data_ptr(), plan.Mp,
                     plan.jobs.data_ptr(), plan.n_jobs, plan.slabs.data_ptr(), plan.reduce.data_ptr(), st.grad.data_ptr(),
                     self._x3_ptr(), torch.cuda.current_stream(dev).cuda_stream)
         _dist.all_reduce_sum_(st.grad)
@@ -165,7 +165,7 @@ class FusedTrainer:
         R = int(inds.shape[0])
         if self._comp is None or self._comp.shape[0] != R:
             self._comp = torch.empty(R, 3, dtype=torch.float32, device=dev)
-            self._gws = torch.empty(R, 4, dtype=torch.float32, device=dev)      # per ray: dL/dcomp_rgb + squared error (ABI 2)
+            self._gws = torch.empty(_l.train_ws_floats(R), dtype=torch.float32, device=dev)      # per ray: dL/dcomp_rgb + squared error
         ztab = _ops.depth_table(self.near, self.far, self.S, dev)
         rnd, tr, seed, off = _ops._rng_args(randomized, t_rand, philox)
         if tr is not None:
@@ -177,7 +177,7 @@ class FusedTrainer:
             b = st.repack_bf16(tuple(p._version for p in self.model._param_list()))
             bp = b.train_plan(R, self.S)
             _l.call("tnerf_train_step_fused_cam_bf16", C.byref(st.desc), b.packed.data_ptr(), C.byref(cam), pixels.data_ptr(), R, self.S,
-                    ztab.data_ptr(), rnd, _ops._ptr(tr), seed, off, self.white, denom, self._comp.data_ptr(), self._gws.data_ptr(),
+                    ztab.data_ptr(), rnd, _ops._ptr(tr), seed, off, self.white, denom, self._comp.data_ptr(), self._gws.data_ptr(), self._gws.numel(),
                     self.loss.data_ptr(), bp.stash.data_ptr(), bp.jobs.data_ptr(), bp.n_jobs, bp.slabs.data_ptr(),
                     bp.reduce.data_ptr(), st.grad.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
             _dist.all_reduce_sum_(st.grad)
@@ -187,7 +187,7 @@ class FusedTrainer:
         plan = st.plan(R * self.S)
         with plan.lease() as stash:
             _l.call("tnerf_train_step_fused_cam", C.byref(st.desc), st.packed.data_ptr(), C.byref(cam), pixels.data_ptr(), R, self.S,
-                    ztab.data_ptr(), rnd, _ops._ptr(tr), seed, off, self.white, denom, self._comp.data_ptr(), self._gws.data_ptr(),
+                    ztab.data_ptr(), rnd, _ops._ptr(tr), seed, off, self.white, denom, self._comp.data_ptr(), self._gws.data_ptr(), self._gws.numel(),
                     self.loss.data_ptr(), stash.data_ptr(), plan.Mp, plan.jobs.data_ptr(), plan.n_jobs, plan.slabs.data_ptr(),
                     plan.reduce.data_ptr(), st.grad.data_ptr(), self._x3_ptr(), torch.cuda.current_stream(dev).cuda_stream)
         _dist.all_reduce_sum_(st.grad)
@@ -254,7 +254,7 @@ class DatasetTrainer:
         self.step_dev = torch.tensor([int(start_step)], dtype=torch.int64, device=dev)
         self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
         self.comp = torch.empty(self.R, 3, dtype=torch.float32, device=dev)
-        self.ray_ws = torch.empty(self.R, 4, dtype=torch.float32, device=dev)
+        self.ray_ws = torch.empty(_l.train_ws_floats(self.R), dtype=torch.float32, device=dev)
         self.pix = torch.empty(self.R, dtype=torch.int32, device=dev) if record_pixels else None
         self._graph = None
         self._graph_key = None
@@ -297,8 +297,10 @@ class DatasetTrainer:
         a.ztab, a.seed, a.loss_denominator = self.ztab.data_ptr(), self.seed, 3.0 * self.R_global
         a.step, a.packed = self.step_dev.data_ptr(), self._packed.data_ptr()
         a.comp_rgb, a.ray_ws, a.loss_out = self.comp.data_ptr(), self.ray_ws.data_ptr(), self.loss.data_ptr()
+        a.ray_ws_floats = self.ray_ws.numel()
         a.pix_out = self.pix.data_ptr() if self.pix is not None else None
         a.stash, a.stash_row_stride = self._stash.data_ptr(), self._stride
+        a.stash_capacity = self._stash.numel()                # fp32: floats, bf16: bytes (a uint8 buffer)
         a.job_table, a.n_jobs, a.slabs = plan.jobs.data_ptr(), plan.n_jobs, plan.slabs.data_ptr()
         a.reduce_table, a.grads = plan.reduce.data_ptr(), st.grad.data_ptr()
         a.params, a.exp_avg, a.exp_avg_sq = st.flat.data_ptr(), self.opt._m.data_ptr(), self.opt._v.data_ptr()

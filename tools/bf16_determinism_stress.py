@@ -27,7 +27,7 @@ for (L_, hidden, depth, skip, R, S) in ((6, 256, 8, 4, 4096, 64), (10, 128, 4, 2
     ref = None; bad = 0
     for i in range(N):
         L.call("tnerf_train_step_fused_bf16", C.byref(st.desc), b.packed.data_ptr(), o.data_ptr(), d.data_ptr(), tgt.data_ptr(), R, S,
-               ztab.data_ptr(), 1, t.data_ptr(), 0, 0, 1, float(3 * R), comp.data_ptr(), gws.data_ptr(), loss.data_ptr(), bp.stash.data_ptr(),
+               ztab.data_ptr(), 1, t.data_ptr(), 0, 0, 1, float(3 * R), comp.data_ptr(), gws.data_ptr(), gws.numel(), loss.data_ptr(), bp.stash.data_ptr(),
                bp.jobs.data_ptr(), bp.n_jobs, bp.slabs.data_ptr(), bp.reduce.data_ptr(), st.grad.data_ptr(), s_)
         g = st.grad.clone(); c = comp.clone()
         if ref is None:

@@ -20,7 +20,7 @@ o, d = ro[idx].contiguous(), rd[idx].contiguous()
 tgt = torch.rand(R, 3, device=dev); t = torch.rand(R, S, device=dev)
 b = st.repack_bf16(); bp = b.train_plan(R, S)
 ztab = ops.depth_table(2.0, 6.0, S, dev)
-comp = torch.empty(R, 3, device=dev); gws = torch.rand(R, 3, device=dev) * 1e-3; loss = torch.zeros(1, device=dev)
+comp = torch.empty(R, 3, device=dev); gws = torch.rand(R, 3, device=dev) * 1e-3; sws = torch.empty(4 * R, device=dev); loss = torch.zeros(1, device=dev)
 dep = torch.empty(R, 1, device=dev); acc = torch.empty(R, 1, device=dev)
 s_ = torch.cuda.current_stream(dev).cuda_stream
 calls = {
@@ -28,7 +28,7 @@ calls = {
     "fwd": lambda: L.call("tnerf_train_fwd_fused_bf16", C.byref(st.desc), b.packed.data_ptr(), o.data_ptr(), d.data_ptr(), R, S, ztab.data_ptr(), 1, t.data_ptr(), 0, 0, 1, comp.data_ptr(), bp.stash.data_ptr(), s_),
     "dgrad": lambda: L.call("tnerf_train_dgrad_fused_bf16", C.byref(st.desc), b.packed.data_ptr(), o.data_ptr(), d.data_ptr(), R, S, ztab.data_ptr(), 1, t.data_ptr(), 0, 0, 1, gws.data_ptr(), bp.stash.data_ptr(), s_),
     "wgrad": lambda: L.call("tnerf_wgrad_bf16", C.byref(st.desc), bp.stash.data_ptr(), bp.n_tiles, bp.jobs.data_ptr(), bp.n_jobs, bp.slabs.data_ptr(), s_),
-    "step": lambda: L.call("tnerf_train_step_fused_bf16", C.byref(st.desc), b.packed.data_ptr(), o.data_ptr(), d.data_ptr(), tgt.data_ptr(), R, S, ztab.data_ptr(), 1, t.data_ptr(), 0, 0, 1, float(3 * R), comp.data_ptr(), gws.data_ptr(), loss.data_ptr(), bp.stash.data_ptr(), bp.jobs.data_ptr(), bp.n_jobs, bp.slabs.data_ptr(), bp.reduce.data_ptr(), st.grad.data_ptr(), s_),
+    "step": lambda: L.call("tnerf_train_step_fused_bf16", C.byref(st.desc), b.packed.data_ptr(), o.data_ptr(), d.data_ptr(), tgt.data_ptr(), R, S, ztab.data_ptr(), 1, t.data_ptr(), 0, 0, 1, float(3 * R), comp.data_ptr(), sws.data_ptr(), sws.numel(), loss.data_ptr(), bp.stash.data_ptr(), bp.jobs.data_ptr(), bp.n_jobs, bp.slabs.data_ptr(), bp.reduce.data_ptr(), st.grad.data_ptr(), s_),
 }
 out = []
 for name, fn in calls.items():

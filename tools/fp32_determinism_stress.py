@@ -27,7 +27,7 @@ for (L_, hidden, depth, skip, R, S) in ((6, 256, 8, 4, 4096, 64), (10, 128, 4, 2
     ref = None; bad = 0
     for i in range(N):
         L.call("tnerf_train_step_fused", C.byref(st.desc), st.packed.data_ptr(), o.data_ptr(), d.data_ptr(), tgt.data_ptr(), R, S,
-               ztab.data_ptr(), 1, t.data_ptr(), 0, 0, 1, float(3 * R), comp.data_ptr(), gws.data_ptr(), loss.data_ptr(), plan.stash.data_ptr(), plan.Mp,
+               ztab.data_ptr(), 1, t.data_ptr(), 0, 0, 1, float(3 * R), comp.data_ptr(), gws.data_ptr(), gws.numel(), loss.data_ptr(), plan.stash.data_ptr(), plan.Mp,
                plan.jobs.data_ptr(), plan.n_jobs, plan.slabs.data_ptr(), plan.reduce.data_ptr(), st.grad.data_ptr(),
                st.repack_x3(1).packed.data_ptr() if st.x3_capable else None, s_)       # forward on the x3 chain kernel
         g = st.grad.clone()
