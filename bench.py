@@ -17,13 +17,17 @@ synthetic scene (the dataset blob is not available offline), resident in HBM bef
 process per GPU, rays sharded over ranks, one all-reduce(SUM) of the 1.93 MB flat gradient per step.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline     — the dominant kernel's algorithmic FLOP/s against the fp32 MFMA peak (157.3 TFLOP/s),
-                 kernel time measured live with HIP events on the launch stream,
+  roofline     — the dominant chain kernel's algorithmic fp32 FLOP/s against the ceiling of the pipe it runs on (x3: the dense
+                 fp16 MFMA peak / 3, three partial products per fp32 product), kernel time measured live with HIP events on the
+                 launch stream,
   cpu_baseline — the CPU oracle (a port of the reference's fp32 CPU path) timed on this box's host cores on a
                  bounded sample (rank 0, N=1 only): all cores and one thread,
   kernels / psnr — per-kernel times and the PSNR reached (context, not part of the contract),
   rccl_ranks / allreduce — the size of the process group after a real all-reduce and the measured cost of the
                  gradient all-reduce (N>1, or TNERF_FORCE_DIST=1 with one rank),
+  fp32_mfma_step — the same step with TNERF_FLAG_FP32_MFMA (plain fp32 fma chains on v_mfma_f32_32x32x2_f32), driver-timed,
+  small_batch  — the step at 2048 / 1024 / 512 rays per GPU (the strong-scaling loads of N = 2 / 4 / 8) with per-kernel times, the
+                 one-rank RCCL all-reduce of the flat gradient, and the efficiency those two predict,
   bf16         — BASELINE.json configs[3]: the same step with bf16 weights/activations on MFMA,
   ref_default  — the reference's hard-coded model (L=10, 4x128, skip 2, 2048 rays; reference src/train.py:78-79),
   cfg3 / cfg5  — BASELINE.json configs[2] / [4]: 400x400 S=128 (full-image render + train step) and 800x800 S=256
@@ -45,10 +49,10 @@ for p in (ROOT, PKG, os.path.join(PKG, "src")):
 L_FREQS, HIDDEN, DEPTH, SKIP = 6, 256, 8, 4
 RAYS, SAMPLES, NEAR, FAR, LR = 4096, 64, 2.0, 6.0, 5e-4
 PEAK_F32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: 256 CU x 2.4 GHz x 256 FLOP/clk/CU
-PEAK_BF16_MFMA_TFLOPS = 2516.6      # 16x the fp32 MFMA rate (v_mfma_f32_32x32x16_bf16: 32 cycles per 32768 FLOP per SIMD)
-PEAK_X3_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6      # an exact fp32 product = 6 bf16 MFMA partial products
+PEAK_BF16_MFMA_TFLOPS = 2516.6      # 16x the fp32 MFMA rate (v_mfma_f32_32x32x16_bf16 / _f16: 32 cycles per 32768 FLOP per SIMD)
+PEAK_X3_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 3      # an fp32-grade product = 3 fp16 MFMA partial products of two-piece operands
 PEAK_HBM_GBS = 8000.0
-# what the fp32 fused paths are priced against: the split-bf16 chain unless TNERF_FP32_PIPE selects the plain fp32 MFMA kernels
+# what the fp32 fused paths are priced against: the x3 (two-piece fp16) chain unless TNERF_FP32_PIPE selects the plain fp32 MFMA kernels
 FP32_PATH_PEAK = PEAK_F32_MFMA_TFLOPS if os.environ.get("TNERF_FP32_PIPE", "").lower() in ("mfma32", "fp32", "mfma") else PEAK_X3_TFLOPS
 
 
@@ -228,9 +232,9 @@ def run(args):
 
     encoder = PositionalEncoding(L_FREQS, True).to(dev)
 
-    def make_trainer(precision, L=L_FREQS, hidden=HIDDEN, depth=DEPTH, skip=SKIP, samples=SAMPLES, scene_t=None, rays_global=None):
+    def make_trainer(precision, L=L_FREQS, hidden=HIDDEN, depth=DEPTH, skip=SKIP, samples=SAMPLES, scene_t=None, rays_global=None, matrix_pipe=None):
         torch.manual_seed(0)                               # identical initial weights on every rank (and in both modes)
-        mdl = nerf_mod.TinyNeRF(6 * L + 3, hidden, depth, skip).to(dev)
+        mdl = nerf_mod.TinyNeRF(6 * L + 3, hidden, depth, skip, matrix_pipe=matrix_pipe).to(dev)
         with torch.no_grad():
             # nn.Linear's default init leaves the sigma head at exactly 0 after its ReLU for this 8x256 model
             # (SURVEY.md §7-7): every weight and every gradient would be a zero and the MFMA kernels would be
@@ -309,11 +313,12 @@ def run(args):
     out = {"metric": "rays/s (train step)", "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling,
            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "dtype_note": ("fp32 values in, out and in every accumulator; the matrix products are formed EXACTLY from three bf16 pieces per "
-                          "fp32 operand (8+8+8 mantissa bits, 6 partial products on the bf16 MFMA pipe); measured against fp64: whole-gradient error equal "
-                          "to the reference's CPU fp32 path, activations within ~2x of the fp32-MFMA kernels' error after 8 layers, single "
-                          "hidden-layer gradient tensors up to 10x (the pipe drops addends below 1/8 ulp of its accumulator: DESIGN.md 14); "
-                          "TNERF_FP32_PIPE=mfma32 runs the plain fp32-MFMA kernels instead")
+           "dtype_note": ("fp32 values in, out and in every accumulator; the matrix products are APPROXIMATED to fp32 grade on the fp16 "
+                          "matrix pipe: every fp32 operand is scaled by a power of two and carried as two fp16 pieces, a*b = a1*b1 (one "
+                          "accumulator) + a1*b2 + a2*b1 (a second one), three v_mfma_f32_32x32x16_f16 per 16 k; measured against fp64: "
+                          "activations closer than an fp32 fma chain's, every gradient tensor within 2x of the reference's own CPU fp32 error "
+                          "(tests/test_gpu_parity.py); the plain fp32-MFMA kernels (TNERF_FP32_PIPE=mfma32 / TinyNeRF(matrix_pipe='fp32_mfma')) "
+                          "are timed in fp32_mfma_step")
                          if FP32_PATH_PEAK == PEAK_X3_TFLOPS else "fp32 MFMA (v_mfma_f32_32x32x2_f32)",
            "config": {"workload": "train step: 100x100 synthetic Lego stand-in, 106 views, L=6 posenc, 8x256 ReLU MLP (skip 4), "
                                   f"64 samples/ray, {'4096 rays per GPU' if args.scaling == 'weak' else '4096 rays in total'} per step, "
@@ -364,7 +369,7 @@ def run(args):
                 "reduce": lambda: lib.call("tnerf_wgrad_reduce", plan.slabs.data_ptr(), plan.reduce.data_ptr(), st.n_params, st.grad.data_ptr(), sp),
             }
             if st.x3_capable and not (st.desc.flags & lib.FLAG_FP32_MFMA):
-                # the chain kernels the step actually launches: fp32 products formed exactly on the bf16 matrix pipe
+                # the chain kernels the step actually launches: fp32-grade products on the fp16 matrix pipe (x3)
                 for k_ in ("render_fwd", "train_fwd", "dgrad"):
                     calls[k_ + "_fp32_mfma"] = calls[k_]
                 x3 = st.repack_x3(("bench", id(st)))
@@ -411,15 +416,15 @@ def run(args):
         dom = max(chain, key=lambda k: kern[k])                      # the MFMA-bound kernels of the step (wgrad is HBM-bound, below)
         ach = fl[dom] / (kern[dom] * 1e-3) / 1e12
         peak = PEAK_X3_TFLOPS if x3 else PEAK_F32_MFMA_TFLOPS
-        cap = measured_traffic("r02_traffic.json")
+        cap = measured_traffic("r03_traffic.json")
         out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                            "frac": ach / peak,
                            "traffic": cap[dom]["hbm_bytes"] if cap and dom in cap else None,
-                           "traffic_source": f"profiles/r02_traffic.json (PMC passes on kernel sources {cap['kernel_source_sha']})" if cap and dom in cap else None,
+                           "traffic_source": f"profiles/r03_traffic.json (PMC passes on kernel sources {cap['kernel_source_sha']})" if cap and dom in cap else None,
                            "flops_per_launch": fl[dom], "ms_per_launch": kern[dom],
                            "frac_of_fp32_mfma_peak": ach / PEAK_F32_MFMA_TFLOPS,      # north_star's yardstick (157.3 TFLOP/s): > 1 on the bf16 pipe
-                           "note": ("algorithmic fp32 FLOP per launch; each product runs as 6 bf16 MFMA partial products (exact 3-way split), "
-                                    "so the ceiling is the dense bf16 MFMA peak / 6 = %.1f TFLOP/s; executed bf16 rate = 6 x achieved" % PEAK_X3_TFLOPS)
+                           "note": ("algorithmic fp32 FLOP per launch; each product runs as 3 fp16 MFMA partial products (two-piece operands), "
+                                    "so the ceiling is the dense fp16 MFMA peak / 3 = %.1f TFLOP/s; executed fp16 rate = 3 x achieved" % PEAK_X3_TFLOPS)
                                    if x3 else "fp32 MFMA"}
         for k_ in list(kern):
             if k_.endswith("_fp32_mfma"):
@@ -434,14 +439,14 @@ def run(args):
                 out["kernels"][k_]["traffic"] = cap[k_]["hbm_bytes"]
         out["kernels"]["_timing"] = ("ms: HIP events between the launches of train_fwd -> dgrad -> wgrad -> reduce issued back to back in step "
                                      "order (the other entries: alone); ms_alone: the same launch repeated on its own")
-        # the weight-gradient kernel runs its products on the bf16 matrix pipe (exact 3-way split): it is HBM-bound — its own roofline
+        # the weight-gradient kernel runs its products on the fp16 matrix pipe too (3 partial products): priced against both of its bounds
         m_ = RAYS * SAMPLES
         wg_bytes = m_ * 4 * ((HIDDEN + 64) * 2 + (DEPTH - 1) * 2 * HIDDEN + 32 + HIDDEN)        # every job class reads its A and B rows of the stash once
         for k_ in ("wgrad", "wgrad_fp32_mfma"):
             out["kernels"][k_].update(algorithmic_hbm_bytes=wg_bytes, hbm_gbs=wg_bytes / (kern[k_] * 1e-3) / 1e9,
                                       hbm_frac=wg_bytes / (kern[k_] * 1e-3) / 1e9 / PEAK_HBM_GBS,
                                       traffic=cap[k_]["hbm_bytes"] if cap and k_ in cap else None)
-        out["kernels"]["wgrad"]["matrix_pipe"] = "bf16 MFMA, fp32 operands split exactly in three (6 of 9 partial products), fp32 accumulate"
+        out["kernels"]["wgrad"]["matrix_pipe"] = "fp16 MFMA, fp32 operands as two scaled fp16 pieces (3 of 4 partial products), fp32 accumulate"
         out["kernels"]["wgrad_fp32_mfma"]["matrix_pipe"] = "fp32 MFMA (TNERF_FLAG_FP32_MFMA)"
         if args.scaling == "weak" or world == 1:
             step_flops = sum(fl[k] for k in step_kernels)
@@ -470,6 +475,71 @@ def run(args):
         if r:
             out["psnr"] = r[0]; img_f32 = r[1]
 
+    # ---- the same step on the plain fp32-MFMA kernels (TNERF_FLAG_FP32_MFMA): what the x3 pipe buys, driver-timed like `value`
+    if not args.no_extra and FP32_PATH_PEAK == PEAK_X3_TFLOPS:
+        m32, o32, t32 = make_trainer("fp32", matrix_pipe="fp32_mfma")
+        run_["tr"] = t32
+        gen.manual_seed(1234); state["step"] = 0
+        d32 = timed(args.warmup, args.steps)
+        f_, dg_, wg_ = mlp_macs(6 * L_FREQS + 3, HIDDEN, DEPTH, SKIP)
+        out["fp32_mfma_step"] = {"matrix_pipe": "v_mfma_f32_32x32x2_f32: fp32 fma chains in the chain kernels and the weight-gradient kernel",
+                                 "ms_per_step": d32 / args.steps * 1e3, "value": R_global * args.steps / d32, "unit": "rays/s",
+                                 "mfma_frac": 2 * (f_ + dg_ + wg_) * R_local * SAMPLES / (d32 / args.steps) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                                 "mfma_peak": PEAK_F32_MFMA_TFLOPS, "x3_speedup": d32 / dt}
+        run_["tr"] = tr
+        del m32, o32, t32
+
+    # ---- strong-scaling loads on one GPU: the step at 2048 / 1024 / 512 rays (what each of N = 2 / 4 / 8 ranks runs when 4096 rays are
+    # sharded) + the cost of an RCCL all-reduce of the flat gradient in a one-rank group -> the efficiency these predict
+    if not args.no_extra and world == 1 and rank == 0:
+        def small_batch():
+            own_group = False
+            if not dist.is_initialized():
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                os.environ["MASTER_PORT"] = str(launch.free_port())
+                os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+                dist.init_process_group("nccl", device_id=dev)
+                own_group = True
+            g = model.hip_state().grad
+            keep = g.clone()
+            ar_us = event_ms(lambda: dist.all_reduce(g), 50) * 1e3
+            g.copy_(keep)
+            nbytes = int(g.numel() * 4)
+            res = {"allreduce_one_rank": {"bytes": nbytes, "us": ar_us,
+                                          "how": "50 back-to-back RCCL all-reduces of the flat gradient in a one-rank group between HIP events: "
+                                                 "the launch + kernel floor, no link traffic"},
+                   "rays_per_gpu": {}}
+            base_ms = ms_per_step
+            for n_ranks, rays in ((2, 2048), (4, 1024), (8, 512)):
+                mdl, op, t_ = make_trainer("fp32", rays_global=rays)
+                run_.update(tr=t_, R_global=rays, lo=0, hi=rays)
+                d_ = timed(10, max(50, args.steps))
+                ms = d_ / max(50, args.steps) * 1e3
+                mdl._ensure_packed()
+                kern_, _ = kernel_section(mdl.hip_state(), rays, SAMPLES, "fp32")
+                # ring all-reduce of `nbytes` over n_ranks on xGMI: 2 (n-1)/n of the bytes cross each link; one link ~ 153 GB/s peak, 70 % assumed
+                link_us = 2.0 * (n_ranks - 1) / n_ranks * nbytes / (153e9 * 0.7) * 1e6
+                ar_pred = ar_us + link_us
+                res["rays_per_gpu"][str(rays)] = {
+                    "ms_per_step": ms, "kernels_ms": {k: kern_[k] for k in ("train_fwd", "dgrad", "wgrad", "reduce") if k in kern_},
+                    "for_n_gpus": n_ranks, "allreduce_us_model": ar_pred,
+                    "predicted_strong_efficiency": base_ms / (n_ranks * (ms + ar_pred * 1e-3)),
+                    "predicted_strong_efficiency_allreduce_hidden": base_ms / (n_ranks * ms)}
+                del mdl, op, t_
+            res["weak_predicted_efficiency"] = {str(n): base_ms / (base_ms + (ar_us + 2.0 * (n - 1) / n * nbytes / (153e9 * 0.7) * 1e6) * 1e-3) for n in (2, 4, 8)}
+            res["model"] = ("t_N = t_step(4096/N rays, measured here) + all-reduce(N) with all-reduce(N) = one-rank RCCL floor (measured here) + "
+                            "2 (N-1)/N x bytes / (0.7 x 153 GB/s) ring term; efficiency = t_1(4096 rays) / (N t_N).  The step at N > 1 runs as two "
+                            "captured graphs around one eager all-reduce (tnerf/trainer.py)")
+            run_.update(tr=tr, R_global=R_global, lo=lo, hi=hi)
+            if own_group:
+                dist.destroy_process_group()
+            return res
+        try:
+            out["small_batch"] = small_batch()
+        except Exception as e:
+            out["small_batch"] = {"error": f"{type(e).__name__}: {e}"}
+            run_.update(tr=tr, R_global=R_global, lo=lo, hi=hi)
+
     # ---- bf16 mode (BASELINE.json configs[3]): same initial weights, same pixel / jitter stream, same step counts
     if not args.no_bf16:
         model16, opt16, tr16 = make_trainer("bf16")
@@ -490,7 +560,7 @@ def run(args):
             hbm = {"train_fwd": tiles * ((2 + DEPTH * NT) * 2048 + DEPTH * (HIDDEN // 64) * 256 + 512),
                    "dgrad": tiles * (DEPTH * NT + 1) * 2048,
                    "wgrad": tiles * wg_tiles * 2048}
-            cap16 = measured_traffic("r02_traffic_bf16.json") or {}
+            cap16 = measured_traffic("r03_traffic_bf16.json") or {}
             kern16 = {}
             for name, ms in k16.items():
                 kern16[name] = {"ms": ms, "ms_alone": k16_alone[name], "tflops": fl[name] / (ms * 1e-3) / 1e12,

@@ -19,8 +19,8 @@ def pytest_configure(config):
 
 
 def pytest_collection_modifyitems(config, items):
-    if torch.cuda.is_available():
-        return
+    if torch.cuda.device_count() > 0:          # counting devices does not initialise HIP in this process (is_available() does):
+        return                                 # tests that start rank processes must be able to do so from a GPU-clean parent
     skip = pytest.mark.skip(reason="no GPU visible")
     for it in items:
         if "gpu" in it.keywords:

@@ -192,3 +192,12 @@ def test_bench_and_train_cli_spawn_before_touching_the_gpu():
         for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
             os.environ.pop(k, None)
         os.environ.update(saved)
+
+
+def test_spawn_ranks_refuses_under_a_profiler(monkeypatch):
+    """Under rocprofv3 the tool library preloaded into the parent has already initialised the GPU: starting ranks from there is the
+    fork/exec-after-HIP-init the launcher exists to avoid."""
+    from tnerf import launch
+    monkeypatch.setenv("LD_PRELOAD", "/opt/rocm/lib/librocprofiler-sdk-tool.so")
+    with pytest.raises(RuntimeError, match="rocprofv3"):
+        launch.spawn_ranks(2, ["-c", "pass"])

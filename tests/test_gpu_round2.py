@@ -535,6 +535,37 @@ def test_dataset_step_equals_the_per_call_path_bitwise(mods, dev, prec):
     assert float((parts[0] + parts[1] - g_full).abs().max()) <= (2e-5 if prec == "fp32" else 2e-3) * float(g_full.abs().max())
 
 
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_dataset_trainer_follows_caller_side_parameter_edits(mods, dev, prec):
+    """A parameter the caller writes between two steps (its _version moves) is packed again before the next step, graph or not; an
+    optimizer stepped behind the trainer's back is refused (one device counter serves the loop and Adam)."""
+    cfg, params = golden_params("4x128")
+    images, poses, focal = _small_scene(mods, dev)
+    images_d, poses_d = images.to(dev), poses.to(dev)
+    T = mods["trainer"]
+    m = make_model(mods, cfg, params, dev)
+    o = T.FlatAdam(m, lr=5e-4)
+    t = T.DatasetTrainer(m, o, images_d, poses_d, focal, 64, 40, 2.0, 6.0, seed=3, precision=prec)
+    for _ in range(3):
+        t.step()
+    assert t._graph is not None
+    with torch.no_grad():
+        m.layers[1].weight.mul_(0.75); m.rgb[0].bias.add_(0.1)
+    # the same state rebuilt from scratch: weights after the edit, Adam moments and step count copied
+    m2 = make_model(mods, cfg, [p.detach().clone() for p in m.parameters()], dev)
+    o2 = T.FlatAdam(m2, lr=5e-4)
+    o2._m.copy_(o._m); o2._v.copy_(o._v); o2._t = o._t
+    t2 = T.DatasetTrainer(m2, o2, images_d, poses_d, focal, 64, 40, 2.0, 6.0, seed=3, precision=prec, graph=False, start_step=3)
+    for _ in range(2):
+        la, _ = t.step(); lb, _ = t2.step()
+        assert torch.equal(la, lb)
+    for a, b in zip(m.parameters(), m2.parameters()):
+        assert torch.equal(a, b)
+    o._t += 1                                             # "someone called optimizer.step() outside"
+    with pytest.raises(RuntimeError, match="step count"):
+        t.step()
+
+
 # ------------------------------------------------------------------------------- any hidden width up to 256
 @pytest.mark.parametrize("arch", [(39, 200, 3, 2), (63, 64, 4, 2), (39, 100, 2, 0), (27, 31, 3, 1)])
 def test_hidden_widths_other_than_128_and_256(mods, dev, arch):

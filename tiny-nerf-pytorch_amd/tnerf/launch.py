@@ -58,6 +58,12 @@ def spawn_ranks(world: int, argv: Sequence[str], port: Optional[int] = None, tim
     Returns the first non-zero exit code (the other ranks are terminated), else 0."""
     if world < 1:
         raise ValueError("spawn_ranks: world must be >= 1")
+    preload = " ".join(os.environ.get(k, "") for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB"))
+    if "rocprof" in preload:
+        # a profiler's preloaded tool library has initialised the GPU in THIS process before main() ran: starting ranks from here
+        # is the fork/exec-after-HIP-init this module exists to avoid (on this pool it takes the node down)
+        raise RuntimeError("spawn_ranks: this process runs under rocprofv3 (preloaded tool library); profile one rank directly "
+                           "(`rocprofv3 ... -- python bench.py --gpus 1`) or start the ranks with torch.distributed.run outside the profiler")
     port = free_port() if port is None else port
     procs: List[subprocess.Popen] = []
     try:

@@ -15,7 +15,7 @@ class MlpDesc(C.Structure):
     _fields_ = [("in_dim", C.c_int32), ("hidden", C.c_int32), ("depth", C.c_int32), ("skip_at", C.c_int32), ("flags", C.c_int32)]
 
 
-FLAG_FP32_MFMA = 1        # fp32 products on v_mfma_f32_32x32x2_f32 instead of the exact bf16x3 split (include/tnerf.h)
+FLAG_FP32_MFMA = 1        # fp32 products on v_mfma_f32_32x32x2_f32 instead of the x3 scheme (three fp16 partial products; include/tnerf.h)
 
 
 class Camera(C.Structure):

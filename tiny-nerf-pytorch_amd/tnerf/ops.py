@@ -257,7 +257,7 @@ class ModelState:
             _l.check(_l.EUNSUPPORTED, "TinyNeRF (HIP)")
         self.n_params = int(n)
         self.n_cu = torch.cuda.get_device_properties(device).multi_processor_count
-        # the x3 chain kernels (fp32 products on the bf16 matrix pipe, exact) cover the fused paths: in_dim = 6L+3
+        # the x3 chain kernels (fp32-grade products on the fp16 matrix pipe) cover the fused paths: in_dim = 6L+3
         self.x3_capable = in_dim >= 9 and (in_dim - 3) % 6 == 0
         k = 2 * depth + 4
         off = np.zeros(k, np.int64); rows = np.zeros(k, np.int64); cols = np.zeros(k, np.int64)
@@ -327,7 +327,7 @@ class ModelState:
         return b
 
     def repack_x3(self, key=None) -> "_X3State":
-        """x3 chain (fp32 products on the bf16 matrix pipe, exact): (re)build the three-piece record stream + fp32 biases."""
+        """x3 chain (fp32-grade products on the fp16 matrix pipe): (re)build the two-piece record stream, its scale records and the fp32 biases."""
         if self.x3 is None:
             self.x3 = _X3State(self)
         b = self.x3
@@ -409,7 +409,7 @@ class _MlpFn(torch.autograd.Function):
         sigma = torch.empty(M, 1, dtype=torch.float32, device=dev)
         plan = st.plan(M) if train else None
         lease = plan.lease() if train else None
-        # the x3 chain (same fp32 results, products on the bf16 matrix pipe) whenever the input is a 6L+3 encoding
+        # the x3 chain (fp32-grade results, products on the fp16 matrix pipe) whenever the input is a 6L+3 encoding
         x3 = None
         if st.x3_capable and not (st.desc.flags & _l.FLAG_FP32_MFMA):
             x3 = st.repack_x3(("pack", st.packed_key) if st.packed_key is not None else None)
@@ -461,7 +461,7 @@ class _FusedRaysFn(torch.autograd.Function):
         dev = st.device
         R = rays_o.shape[0]
         comp = torch.empty(R, 3, dtype=torch.float32, device=dev)
-        # the x3 chain (same fp32 results, products on the bf16 matrix pipe) whenever the model allows it; its record stream
+        # the x3 chain (fp32-grade results, products on the fp16 matrix pipe) whenever the model allows it; its record stream
         # follows the fp32 pack's key (the caller packed for the current parameter versions)
         x3 = None
         if st.x3_capable and not (st.desc.flags & _l.FLAG_FP32_MFMA):
@@ -559,7 +559,7 @@ def render_camera_fused(st: ModelState, c2w, H, W, focal, pix_first, n_rays, nea
     if st.x3_capable and not (st.desc.flags & _l.FLAG_FP32_MFMA):
         if x3_key is None and st.packed_key is not None:
             x3_key = ("pack", st.packed_key)
-        b = st.repack_x3(x3_key)              # fp32 results, products formed exactly on the bf16 matrix pipe
+        b = st.repack_x3(x3_key)              # fp32-grade results, products on the fp16 matrix pipe (x3)
         _l.call("tnerf_render_fused_cam_x3", C.byref(st.desc), b.packed.data_ptr(), C.byref(cam), int(n_rays), S, ztab.data_ptr(), rnd,
                 _ptr(tr), seed, off, int(bool(white_bkgd)), comp.data_ptr(), depth.data_ptr(), acc.data_ptr(), _stream(dev))
         return comp, depth, acc
@@ -613,8 +613,8 @@ def render_camera_fused_bf16(st: ModelState, c2w, H, W, focal, pix_first, n_rays
 @torch.no_grad()
 def render_rays_fused_x3(st: ModelState, rays_o, rays_d, near, far, n_samples, randomized=False, white_bkgd=True,
                          t_rand=None, philox=None, key=None):
-    """render_rays_fused (inference) with the MLP's fp32 products formed exactly on the bf16 matrix pipe (three-way operand
-    split): fp32 results.  Returns (comp_rgb [R,3], depth [R,1], acc [R,1])."""
+    """render_rays_fused (inference) with the MLP's products on the fp16 matrix pipe (x3: two-piece operands, three partial
+    products): fp32-grade results.  Returns (comp_rgb [R,3], depth [R,1], acc [R,1])."""
     dev = _need_cuda(rays_o, rays_d, t_rand)
     rays_o, rays_d = _f32c(rays_o), _f32c(rays_d)
     R, S = rays_o.shape[0], int(n_samples)

@@ -148,7 +148,7 @@ class FusedTrainer:
         return self.loss, self._comp
 
     def _x3_ptr(self):
-        """The x3 record stream of the current weights (the forward runs on the bf16 matrix pipe with exact fp32 products), or
+        """The x3 record stream of the current weights (the chains then run on the fp16 matrix pipe, three partial products), or
         None for models the x3 kernels do not cover / when the fp32-MFMA kernels were asked for."""
         st = self.st
         if (st.desc.flags & _l.FLAG_FP32_MFMA) or not st.x3_capable:
@@ -216,9 +216,9 @@ class DatasetTrainer:
     The dataset (poses, pixels) lives in HBM; which image (step % N), which pixels (the reference's torch.randint) and
     which jitter (its rand_like) are drawn inside the kernels from a device-side step counter (Philox, include/tnerf.h
     "the whole step on device-resident state"); Adam and the re-packing of the updated weights finish the same call.
-    On one GPU the 4 launches of a step are captured once into a hipGraph and replayed (graph=True).  With
+    On one GPU the launches of a step are captured once into a hipGraph and replayed (graph=True).  With
     torch.distributed initialised the rows of the global batch are sharded (dist.shard_bounds) and the flat gradient is
-    all-reduced between the gradient and the update phase (no graph: a collective sits in the middle).
+    all-reduced between the gradient and the update phase: two captured graphs around one eager collective.
 
     This is the speed path; FusedTrainer.step / step_camera with torch-drawn `inds` / `t_rand` is the parity path."""
 
@@ -259,7 +259,9 @@ class DatasetTrainer:
         self._graph = None
         self._graph_key = None
         self._x3_packed = self._x3_scatter = None
-        self._want_graph = bool(graph) and world == 1
+        self._want_graph = bool(graph)
+        self._graph_update = None
+        self._start_step = int(start_step)
         self._calls = 0
         self._own_stream = None
         self._args_keep = None
@@ -282,6 +284,7 @@ class DatasetTrainer:
             self._stash, self._stride = self._plan.stash, 0
             tab = b.table.cpu().numpy()
         self._scatter = torch.from_numpy(_scatter_table(tab, st.n_params)).to(dev)
+        self._param_key = tuple(p._version for p in model._param_list())
 
     # ------------------------------------------------------------------ one step
     def _args(self, phases: int) -> "_l.StepArgs":
@@ -323,45 +326,38 @@ class DatasetTrainer:
             self._own_stream = torch.cuda.Stream(self.st.device)
         return self._own_stream, True
 
-    @torch.no_grad()
-    def step(self):
-        """One training step.  Returns (loss [device scalar: this rank's share of the batch MSE], comp_rgb [R,3])."""
+    def _sync_params(self):
+        """The kernels keep the packed copies current themselves; a parameter the CALLER wrote between two steps (p.copy_(), an
+        in-place edit: its _version moved) is packed again here, into the same buffers (captured graphs stay valid)."""
+        key = tuple(p._version for p in self.model._param_list())
+        if key == self._param_key:
+            return
         st = self.st
-        if not st.owns(self.model._param_list()):
-            raise RuntimeError("DatasetTrainer: a model parameter was rebound; build a new trainer")
-        if self.world > 1:                          # gradient -> all-reduce -> update
-            self.gradient_phase()
-            _dist.all_reduce_sum_(st.grad)
-            return self.update_phase()
-        elif not self._want_graph:
-            a = self._args(_l.PHASE_GRADIENT | _l.PHASE_REDUCE | _l.PHASE_UPDATE)
-            _l.call("tnerf_train_step_dataset", C.byref(a), torch.cuda.current_stream(st.device).cuda_stream)
+        if self.precision == "fp32":
+            st.packed_key = None
+            self.model._ensure_packed()
+            if self._x3_packed is not None:
+                st.repack_x3(None)
         else:
-            stream, own = self._stream()
-            if own:
-                stream.wait_stream(torch.cuda.current_stream(st.device))
-            if self._graph is not None and self._graph_key != self._hyper_key():
-                self._drop_graph()                 # lr / betas changed: the captured kernel arguments are stale
-            if self._graph is None and self._calls >= 1:
-                # capture (the first call ran eagerly: every kernel is loaded, every buffer exists)
-                a = self._args(_l.PHASE_GRADIENT | _l.PHASE_REDUCE | _l.PHASE_UPDATE)
-                _l.call("tnerf_graph_begin", stream.cuda_stream)
-                try:
-                    _l.call("tnerf_train_step_dataset", C.byref(a), stream.cuda_stream)
-                finally:
-                    gx = C.c_void_p()
-                    rc = _l.load().tnerf_graph_end(stream.cuda_stream, C.byref(gx))
-                _l.check(rc, "tnerf_graph_end")
-                self._graph, self._graph_key, self._args_keep = gx, self._hyper_key(), a
-            if self._graph is not None:
-                _l.call("tnerf_graph_launch", self._graph, stream.cuda_stream)
-            else:
-                a = self._args(_l.PHASE_GRADIENT | _l.PHASE_REDUCE | _l.PHASE_UPDATE)
-                _l.call("tnerf_train_step_dataset", C.byref(a), stream.cuda_stream)
-            if own:
-                torch.cuda.current_stream(st.device).wait_stream(stream)
+            st.repack_bf16(None)
+        self._param_key = key
+
+    def _capture(self, stream, phases: int):
+        """One tnerf_train_step_dataset call with `phases`, captured on `stream` -> (graph exec handle, the argument block it keeps)."""
+        a = self._args(phases)
+        _l.call("tnerf_graph_begin", stream.cuda_stream)
+        try:
+            _l.call("tnerf_train_step_dataset", C.byref(a), stream.cuda_stream)
+        finally:
+            gx = C.c_void_p()
+            rc = _l.load().tnerf_graph_end(stream.cuda_stream, C.byref(gx))
+        _l.check(rc, "tnerf_graph_end")
+        return gx, a
+
+    def _after_update(self):
         self._calls += 1
         self.opt._t += 1
+        st = self.st
         # the finishing kernel re-packed THIS precision's copies of the weights; the others are stale now
         if self.precision == "fp32":
             if st.bf16 is not None:
@@ -372,6 +368,66 @@ class DatasetTrainer:
             st.packed_key = None
             if st.x3 is not None:
                 st.x3.key = None
+
+    @torch.no_grad()
+    def step(self):
+        """One training step.  Returns (loss [device scalar: this rank's share of the batch MSE], comp_rgb [R,3]).
+        One GPU: the whole step is one hipGraph replay.  N ranks: two replays — GRADIENT|REDUCE, then UPDATE — around one eager
+        all-reduce(SUM) of the flat gradient on the same stream (a collective cannot sit inside the captured region: torch's
+        process group owns its launch), so the host still issues three calls per step instead of six launches."""
+        st = self.st
+        if not st.owns(self.model._param_list()):
+            raise RuntimeError("DatasetTrainer: a model parameter was rebound; build a new trainer")
+        if int(self.opt._t) != self._calls + self._start_step:
+            raise RuntimeError(f"DatasetTrainer: Adam's step count ({self.opt._t}) no longer equals the loop's ({self._calls + self._start_step}): "
+                               "the optimizer was stepped outside this trainer; one device counter serves both")
+        self._sync_params()
+        full = _l.PHASE_GRADIENT | _l.PHASE_REDUCE | _l.PHASE_UPDATE
+        if not self._want_graph:
+            if self.world > 1:                      # gradient -> all-reduce -> update, six eager launches
+                self.gradient_phase()
+                _dist.all_reduce_sum_(st.grad)
+                return self.update_phase()
+            a = self._args(full)
+            _l.call("tnerf_train_step_dataset", C.byref(a), torch.cuda.current_stream(st.device).cuda_stream)
+            self._after_update()
+            return self.loss, self.comp
+        stream, own = self._stream()
+        if own:
+            stream.wait_stream(torch.cuda.current_stream(st.device))
+        if self._graph is not None and self._graph_key != self._hyper_key():
+            self._drop_graph()                 # lr / betas changed: the captured kernel arguments are stale
+        if self._graph is None and self._calls >= 1:
+            # capture (the first call ran eagerly: every kernel is loaded, every buffer exists)
+            if self.world == 1:
+                self._graph, self._args_keep = self._capture(stream, full)
+            else:
+                self._graph, keep_g = self._capture(stream, _l.PHASE_GRADIENT | _l.PHASE_REDUCE)
+                self._graph_update, keep_u = self._capture(stream, _l.PHASE_UPDATE)
+                self._args_keep = (keep_g, keep_u)
+            self._graph_key = self._hyper_key()
+        with torch.cuda.stream(stream):
+            if self.world == 1:
+                if self._graph is not None:
+                    _l.call("tnerf_graph_launch", self._graph, stream.cuda_stream)
+                else:
+                    a = self._args(full)
+                    _l.call("tnerf_train_step_dataset", C.byref(a), stream.cuda_stream)
+            else:
+                if self._graph is not None:
+                    _l.call("tnerf_graph_launch", self._graph, stream.cuda_stream)
+                else:
+                    a = self._args(_l.PHASE_GRADIENT | _l.PHASE_REDUCE)
+                    _l.call("tnerf_train_step_dataset", C.byref(a), stream.cuda_stream)
+                _dist.all_reduce_sum_(st.grad)          # ordered on `stream` (torch's collective waits for / is waited on by the current stream)
+                if self._graph is not None:
+                    _l.call("tnerf_graph_launch", self._graph_update, stream.cuda_stream)
+                else:
+                    a = self._args(_l.PHASE_UPDATE)
+                    _l.call("tnerf_train_step_dataset", C.byref(a), stream.cuda_stream)
+        if own:
+            torch.cuda.current_stream(st.device).wait_stream(stream)
+        self._after_update()
         return self.loss, self.comp
 
     @torch.no_grad()
@@ -386,17 +442,7 @@ class DatasetTrainer:
         """Adam on whatever model.hip_state().grad holds now (the all-reduced gradient) + re-pack."""
         a = self._args(_l.PHASE_UPDATE)
         _l.call("tnerf_train_step_dataset", C.byref(a), torch.cuda.current_stream(self.st.device).cuda_stream)
-        self._calls += 1
-        self.opt._t += 1
-        if self.precision == "fp32":
-            if self.st.bf16 is not None:
-                self.st.bf16.key = None
-            if self.st.x3 is not None and self._x3_packed is None:
-                self.st.x3.key = None
-        else:
-            self.st.packed_key = None
-            if self.st.x3 is not None:
-                self.st.x3.key = None
+        self._after_update()
         return self.loss, self.comp
 
     @property
@@ -404,9 +450,11 @@ class DatasetTrainer:
         return int(self.step_dev.item())
 
     def _drop_graph(self):
-        if self._graph is not None:
-            _l.call("tnerf_graph_destroy", self._graph)
-            self._graph = None
+        for name in ("_graph", "_graph_update"):
+            g = getattr(self, name, None)
+            if g is not None:
+                _l.call("tnerf_graph_destroy", g)
+                setattr(self, name, None)
 
     def __del__(self):
         try:
