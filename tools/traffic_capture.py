@@ -8,7 +8,7 @@ On the GPU box (the profiler's program goes straight after `--`):
     rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python3 bench.py --steps 5 --warmup 3 --psnr-steps 0 --no-cpu-baseline --no-extra
     rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python3 bench.py --steps 5 --warmup 3 --psnr-steps 0 --no-cpu-baseline --no-extra
     python3 tools/traffic_capture.py gpurun_out/pmc_fetch gpurun_out/pmc_write
-writes profiles/r02_traffic.json and profiles/r02_traffic_bf16.json tagged with the sha of csrc/ (bench.py reports them only
+writes profiles/r03_traffic.json and profiles/r03_traffic_bf16.json tagged with the sha of csrc/ (bench.py reports them only
 while the kernel sources are the ones that were profiled)."""
 import csv
 import glob
@@ -82,7 +82,7 @@ def main():
             "--psnr-steps 0 --no-cpu-baseline --no-extra; mean per dispatch.  gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE "
             "counts half the bytes of a 16-B-per-lane coalesced read stream -> x2 where fetch_correction = 2 (the weight-gradient kernels' "
             "operand streams); the 4-B-per-lane stores/loads of the chain kernels are uncalibrated (raw values kept).")
-    for fam, name in (("fp32", "r02_traffic.json"), ("bf16", "r02_traffic_bf16.json")):
+    for fam, name in (("fp32", "r03_traffic.json"), ("bf16", "r03_traffic_bf16.json")):
         d = {"_note": note, "kernel_source_sha": sha}
         d.update(out[fam])
         with open(os.path.join(ROOT, "profiles", name), "w") as fh:

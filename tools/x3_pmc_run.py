@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Diagnostic: launches each x3 chain kernel a few times (8x256, 4096 x 64) so that a rocprofv3 --pmc pass sees them alone:
+"""Diagnostic: launches each x3 chain kernel and the x3 weight-gradient kernel a few times (8x256, 4096 x 64) so that a rocprofv3 --pmc pass sees them alone:
    rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d out -- python3 tools/x3_pmc_run.py"""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -22,4 +22,5 @@ for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 5):
     lib.call("tnerf_render_fused_x3", *cx, comp.data_ptr(), dep.data_ptr(), acc.data_ptr(), sp)
     lib.call("tnerf_train_fwd_fused_x3", *cx, comp.data_ptr(), plan.stash.data_ptr(), plan.Mp, sp)
     lib.call("tnerf_train_dgrad_fused_x3", *cx, gws.data_ptr(), plan.stash.data_ptr(), plan.Mp, sp)
+    lib.call("tnerf_wgrad", C.byref(st.desc), plan.stash.data_ptr(), plan.Mp, R * S, plan.jobs.data_ptr(), plan.n_jobs, plan.slabs.data_ptr(), sp)
 torch.cuda.synchronize()
