@@ -41,7 +41,8 @@ typedef void* tnerf_stream_t;    /* hipStream_t */
 /* TinyNeRF(in_dim, hidden, depth, skip_at)                       [src/nerf.py:10-27]
  * skip_at: the input is concatenated after layer index skip_at-1 (cat([h, x]), nerf.py:37-38);
  * 1 <= skip_at <= depth-1, or 0 for "no skip".  1 <= hidden <= 256 (widths other than 128 / 256 run zero-padded on the
- * 128- / 256-wide kernels: the host tables embed the model, the padding units stay exactly 0); in_dim <= 64. */
+ * 128- / 256-wide kernels: the host tables embed the model, the padding units stay exactly 0); in_dim <= 64.  Wider models and the
+ * gradient w.r.t. the input: the tnerf_mlp_*_generic entry points near the end of this header. */
 typedef struct tnerf_mlp_desc {
     int32_t in_dim;
     int32_t hidden;
@@ -483,6 +484,28 @@ int tnerf_train_dgrad_fused_x3(const tnerf_mlp_desc* d, const void* packed_x3,
 int tnerf_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                     int64_t n, float lr, float beta1, float beta2, float eps, int64_t step,
                     float grad_scale, tnerf_stream_t stream);
+
+/* ------------------------------------------- any width, and the gradient w.r.t. the input: layer by layer */
+/* TinyNeRF.forward and its backward for the shapes the register-resident kernels above do not cover (hidden > 256, in_dim > 64;
+ * the reference's constructor takes any, src/nerf.py:10-27) and, for ANY shape, with the gradient w.r.t. the network input
+ * (src/nerf.py:29-41 is differentiable in x although the reference's training never asks: its points carry no grad).  Not the hot
+ * path: one fp32 library SGEMM per layer (hipBLAS, atomics off: deterministic) between small elementwise kernels.
+ *   d            : in_dim, hidden <= 4096, depth <= 64, skip_at as above (flags ignored)
+ *   blas_handle  : a hipblasHandle_t of the CALLER (the library creates none); its stream / atomics / pointer mode are set for the
+ *                  call and restored.  libhipblas.so is dlopen'ed on first use.
+ *   params/grads : HOST arrays of 2*depth+4 device pointers in state_dict order (layers.i.weight [out,in], layers.i.bias, sigma.0.*,
+ *                  rgb.0.*), each tensor contiguous — no flat buffer, no packed copy.  grads are OVERWRITTEN.
+ *   acts         : [depth][n_rows][hidden] post-ReLU activations, filled by the forward, read by the backward
+ *   scratch      : the backward's gradient buffers; dx: NULL or [n_rows, in_dim] (overwritten with dL/dx)
+ * Undersized acts / scratch: TNERF_ESMALL. */
+int64_t tnerf_mlp_generic_acts_floats(const tnerf_mlp_desc* d, int64_t n_rows);      /* HOST */
+int64_t tnerf_mlp_generic_scratch_floats(const tnerf_mlp_desc* d, int64_t n_rows);   /* HOST */
+int tnerf_mlp_fwd_generic(const tnerf_mlp_desc* d, void* blas_handle, const float* const* params, const float* x, int64_t n_rows,
+                          float* rgb, float* sigma, float* acts, int64_t acts_floats, tnerf_stream_t stream);
+int tnerf_mlp_bwd_generic(const tnerf_mlp_desc* d, void* blas_handle, const float* const* params, const float* x, int64_t n_rows,
+                          const float* rgb, const float* sigma, const float* d_rgb, const float* d_sigma,
+                          const float* acts, int64_t acts_floats, float* scratch, int64_t scratch_floats,
+                          float* const* grads, float* dx, tnerf_stream_t stream);
 
 /* --------------------------------------------------------------------------- RCCL (optional) */
 /* Sum the flat gradient over ranks with RCCL (ncclAllReduce, ncclSum) on `stream`.

@@ -219,8 +219,70 @@ def test_mlp_rejects_what_it_cannot_do(mods, dev):
     m = m.to(dev)
     with pytest.raises(RuntimeError):
         m(torch.zeros(4, 40, device=dev))
+    wide = mods["nerf"].TinyNeRF(39, 512, 8, 4).to(dev)
+    assert wide(torch.zeros(4, 39, device=dev))[0].shape == (4, 3)     # widths above 256: the layer-by-layer path (test below) ...
     with pytest.raises(NotImplementedError):
-        mods["nerf"].TinyNeRF(39, 512, 8, 4).to(dev)(torch.zeros(4, 39, device=dev))      # widths above 256: no kernel
+        wide.hip_state()                                             # ... but no fused kernels, no fused trainer
+
+
+@pytest.mark.parametrize("arch", [(39, 512, 4, 2), (129, 300, 3, 1), (63, 384, 3, 0), (39, 256, 8, 4), (63, 128, 4, 2)])
+def test_any_width_and_input_gradient_layer_by_layer(mods, dev, arch):
+    """TinyNeRF(in_dim, hidden, ...) beyond what the chain kernels cover (hidden > 256, in_dim > 64; reference src/nerf.py:10 takes
+    any) and, for every shape, the gradient w.r.t. the encoded input (src/nerf.py:29-41 is differentiable in x): tnerf_mlp_fwd_generic
+    / tnerf_mlp_bwd_generic against the oracle's autograd; deterministic."""
+    in_dim, hidden, depth, skip = arch
+    torch.manual_seed(3)
+    model = mods["nerf"].TinyNeRF(in_dim, hidden, depth, skip).to(dev)
+    with torch.no_grad():
+        model.sigma[0].bias += 0.5
+    params = [p.detach().cpu().clone() for p in model.parameters()]
+    g = torch.Generator().manual_seed(4)
+    M = 1111
+    x = torch.randn(M, in_dim, generator=g)
+    gr, gs = torch.randn(M, 3, generator=g) * 0.1, torch.randn(M, 1, generator=g) * 0.1
+    leaves = [p.clone().requires_grad_(True) for p in params]
+    xo = x.clone().requires_grad_(True)
+    ro, so = O.mlp_forward(leaves, xo, skip)
+    go = torch.autograd.grad((ro * gr).sum() + (so * gs).sum(), leaves + [xo])
+
+    def run():
+        for p in model.parameters():
+            p.grad = None
+        xd = x.to(dev).requires_grad_(True)
+        rgb, sig = model(xd)
+        ((rgb * gr.to(dev)).sum() + (sig * gs.to(dev)).sum()).backward()
+        return rgb.detach(), sig.detach(), [p.grad.clone() for p in model.parameters()], xd.grad.clone()
+
+    rgb, sig, pg, dx = run()
+    assert float((rgb.cpu() - ro.detach()).abs().max()) <= 2e-6
+    assert float((sig.cpu() - so.detach()).abs().max()) <= 1e-5 * max(1.0, float(so.abs().max()))
+    # gradients: as close to an fp64 evaluation as the reference's own fp32 evaluation is (x2; deep random-init nets flip ReLUs of
+    # samples that sit within rounding of 0, which moves single fp32 evaluations apart by far more than 2e-5)
+    l64 = [p.double().requires_grad_(True) for p in params]
+    x64 = x.double().requires_grad_(True)
+    r64, s64 = O.mlp_forward(l64, x64, skip)
+    g64 = torch.autograd.grad((r64 * gr.double()).sum() + (s64 * gs.double()).sum(), l64 + [x64])
+    for i, (a, b, c) in enumerate(zip(pg + [dx], go, g64)):
+        t_hip, t_ref = relmax(a.cpu().double(), c), relmax(b.double(), c)
+        assert t_hip <= 2.0 * t_ref + 2e-5, (i, t_hip, t_ref)      # + the 2e-5 gate of the fixture tests: bias gradients are cancelling sums of M terms
+    rgb2, sig2, pg2, dx2 = run()
+    assert torch.equal(rgb, rgb2) and torch.equal(dx, dx2) and all(torch.equal(a, b) for a, b in zip(pg, pg2))
+    if hidden <= 256 and in_dim <= 64:
+        # the same model without an input gradient runs on the chain kernels: same function
+        with torch.no_grad():
+            r3, s3 = model(x.to(dev))
+        assert float((r3 - rgb).abs().max()) <= 2e-6 and float((s3 - sig).abs().max()) <= 1e-5 * max(1.0, float(sig.abs().max()))
+    else:
+        # a plain torch optimizer trains it (no flat buffer behind these parameters)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+        tgt = torch.rand(M, 3, generator=g).to(dev)
+        l0 = None
+        for _ in range(20):
+            opt.zero_grad()
+            loss = ((model(x.to(dev))[0] - tgt) ** 2).mean()
+            loss.backward(); opt.step()
+            l0 = float(loss) if l0 is None else l0
+        assert float(loss) < l0
 
 
 # -------------------------------------------------------------------------- fused render / train

@@ -64,9 +64,21 @@ class TinyNeRF(nn.Module):
         return st
 
     # ------------------------------------------------------------------ reference surface
+    def _chain_kernels_cover(self) -> bool:
+        """The register-resident MFMA kernels take hidden <= 256 and in_dim <= 64 (L <= 10); anything else the constructor accepts
+        (reference src/nerf.py:10) runs layer by layer (ops.mlp_forward_generic: one library SGEMM per layer)."""
+        return self.hidden <= 256 and self.in_dim <= 64
+
     def forward(self, x):
-        """x: (N, in_dim) encoded coordinates -> rgb (N,3) in [0,1], sigma (N,1) >= 0."""
-        st = self._ensure_packed()
+        """x: (N, in_dim) encoded coordinates -> rgb (N,3) in [0,1], sigma (N,1) >= 0.  Differentiable in the parameters and in x."""
         lead = x.shape[:-1]
-        rgb, sigma = ops.mlp_forward(st, x.reshape(-1, x.shape[-1]), self._param_list())
+        x2 = x.reshape(-1, x.shape[-1])
+        if not self._chain_kernels_cover() or (x2.requires_grad and torch.is_grad_enabled()):
+            if self.skip_at == self.depth:
+                raise RuntimeError("TinyNeRF: skip_at == depth feeds hidden+in_dim features to the heads")
+            skip = self.skip_at if 1 <= self.skip_at <= self.depth - 1 else 0
+            rgb, sigma = ops.mlp_forward_generic(self.in_dim, self.hidden, self.depth, skip, x2, self._param_list())
+        else:
+            st = self._ensure_packed()
+            rgb, sigma = ops.mlp_forward(st, x2, self._param_list())
         return rgb.reshape(*lead, 3), sigma.reshape(*lead, 1)

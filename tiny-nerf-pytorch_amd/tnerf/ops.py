@@ -443,13 +443,68 @@ class _MlpFn(torch.autograd.Function):
 
 def mlp_forward(st: ModelState, x: torch.Tensor, params) -> Tuple[torch.Tensor, torch.Tensor]:
     _need_cuda(x)
-    if x.requires_grad:
-        raise NotImplementedError("TinyNeRF (HIP): gradient w.r.t. the encoded input is not implemented "
-                                  "(the reference's points carry no grad)")
+    if x.requires_grad:      # the chain kernels form no dL/dx (the reference's points carry no grad); nerf.TinyNeRF.forward routes
+        raise NotImplementedError("mlp_forward: no gradient w.r.t. x on the chain kernels; use mlp_forward_generic")   # such calls there
     if x.dim() != 2 or x.shape[1] != st.desc.in_dim:
         raise RuntimeError(f"TinyNeRF (HIP): expected x of shape (N, {st.desc.in_dim}), got {tuple(x.shape)}")
     train = torch.is_grad_enabled() and any(p.requires_grad for p in params)
     return _MlpFn.apply(st, _f32c(x), train, *params)
+
+
+# ----------------------------------------------------------- any width / gradient w.r.t. the input: layer by layer
+class _MlpGenericFn(torch.autograd.Function):
+    """TinyNeRF.forward through tnerf_mlp_fwd_generic / tnerf_mlp_bwd_generic (one hipBLAS SGEMM per layer): the shapes the chain
+    kernels do not cover (hidden > 256, in_dim > 64) and, for any shape, the gradient w.r.t. x.  The parameter tensors are used
+    where they are (no flat buffer, no packed copy); torch lends its hipBLAS handle."""
+
+    @staticmethod
+    def forward(ctx, desc, x: torch.Tensor, train: bool, *params):
+        dev = x.device
+        M = x.shape[0]
+        ps = [_f32c(p.detach()) for p in params]
+        ptrs = (C.c_void_p * len(ps))(*[p.data_ptr() for p in ps])
+        rgb = torch.empty(M, 3, dtype=torch.float32, device=dev)
+        sigma = torch.empty(M, 1, dtype=torch.float32, device=dev)
+        n_acts = int(_l.load().tnerf_mlp_generic_acts_floats(C.byref(desc), M))
+        if n_acts < 0:
+            _l.check(n_acts, "tnerf_mlp_generic_acts_floats")
+        acts = torch.empty(n_acts, dtype=torch.float32, device=dev)
+        _l.call("tnerf_mlp_fwd_generic", C.byref(desc), torch.cuda.current_blas_handle(), ptrs, x.data_ptr(), M, rgb.data_ptr(),
+                sigma.data_ptr(), acts.data_ptr(), n_acts, _stream(dev))
+        if train:
+            ctx.desc, ctx.M = desc, M
+            ctx.save_for_backward(x, rgb, sigma, acts, *ps)
+            ctx.need_dx = bool(x.requires_grad)
+        return rgb, sigma
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_sigma):
+        x, rgb, sigma, acts, *ps = ctx.saved_tensors
+        desc, M, dev = ctx.desc, ctx.M, x.device
+        g_rgb = torch.zeros(M, 3, dtype=torch.float32, device=dev) if g_rgb is None else _f32c(g_rgb)
+        g_sigma = torch.zeros(M, 1, dtype=torch.float32, device=dev) if g_sigma is None else _f32c(g_sigma)
+        n_scr = int(_l.load().tnerf_mlp_generic_scratch_floats(C.byref(desc), M))
+        scratch = torch.empty(n_scr, dtype=torch.float32, device=dev)
+        grads = [torch.empty_like(p) for p in ps]
+        pptr = (C.c_void_p * len(ps))(*[p.data_ptr() for p in ps])
+        gptr = (C.c_void_p * len(ps))(*[g.data_ptr() for g in grads])
+        dx = torch.empty_like(x) if ctx.need_dx else None
+        _l.call("tnerf_mlp_bwd_generic", C.byref(desc), torch.cuda.current_blas_handle(), pptr, x.data_ptr(), M, rgb.data_ptr(),
+                sigma.data_ptr(), g_rgb.data_ptr(), g_sigma.data_ptr(), acts.data_ptr(), acts.numel(), scratch.data_ptr(), n_scr, gptr,
+                _ptr(dx), _stream(dev))
+        return (None, dx, None, *grads)
+
+
+def mlp_forward_generic(in_dim: int, hidden: int, depth: int, skip_at: int, x: torch.Tensor, params):
+    """rgb [M,3], sigma [M,1] of TinyNeRF(in_dim, hidden, depth, skip_at) on x [M, in_dim]; gradients w.r.t. the parameters and,
+    when x.requires_grad, w.r.t. x."""
+    _need_cuda(x, *params)
+    if x.dim() != 2 or x.shape[1] != in_dim:
+        raise RuntimeError(f"TinyNeRF (HIP): expected x of shape (N, {in_dim}), got {tuple(x.shape)}")
+    desc = _l.MlpDesc(int(in_dim), int(hidden), int(depth), int(skip_at), 0)
+    train = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
+    xc = x if (x.dtype == torch.float32 and x.is_contiguous()) else x.float().contiguous()
+    return _MlpGenericFn.apply(desc, xc, train, *params)
 
 
 # ------------------------------------------------------------------------------- fused rays op

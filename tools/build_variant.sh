@@ -9,7 +9,7 @@ bash build.sh >/dev/null
 OBJ=build; V=build/variant_$NAME; mkdir -p "$V"
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wno-unused-result -DTN_DIAG "$@" -c "$SRC.hip" -o "$V/$SRC.o"
 objs=""
-for f in stage_kernels mlp_fwd mlp_bwd mlp16_fwd mlp16_bwd mlpx3 wgrad train_api step_api host_plan; do
+for f in stage_kernels mlp_fwd mlp_bwd mlp16_fwd mlp16_bwd mlpx3 wgrad train_api step_api mlp_generic host_plan; do
   if [ "$f" = "$SRC" ]; then objs="$objs $V/$f.o"; else objs="$objs $OBJ/$f.o"; fi
 done
 hipcc --offload-arch=gfx950 -shared -fPIC -o ../tnerf/libtnerf_variant_$NAME.so $objs -ldl
