@@ -325,7 +325,8 @@ def run(args):
                                   "Adam, fp32 (BASELINE.json configs[1])",
                       "rays_per_step_global": R_global, "rays_per_gpu": R_local, "samples_per_ray": SAMPLES,
                       "rng": "torch.randint + torch.rand per step (parity path)" if args.parity_rng else
-                             "Philox in the kernels from a device-side step counter; step = one hipGraph replay" + (" (graph off)" if args.no_graph or world > 1 else ""),
+                             "Philox in the kernels from a device-side step counter; step = " + ("eager launches (graph off)" if args.no_graph else
+                                                                                                    ("one hipGraph replay" if world == 1 else "two hipGraph replays around one eager all-reduce")),
                       "rays": "precomputed tables + gather" if args.ray_tables else "generated in-kernel from pose + pixel index",
                       "parallelism": f"rays sharded x{world} ({args.scaling}), 1 all-reduce of {opt._st.n_params * 4} B per step" if world > 1 else "single GPU"}}
 

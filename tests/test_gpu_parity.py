@@ -273,6 +273,15 @@ def test_any_width_and_input_gradient_layer_by_layer(mods, dev, arch):
             r3, s3 = model(x.to(dev))
         assert float((r3 - rgb).abs().max()) <= 2e-6 and float((s3 - sig).abs().max()) <= 1e-5 * max(1.0, float(sig.abs().max()))
     else:
+        if (in_dim - 3) % 6 == 0:
+            # render_one takes such a model through the per-function kernels (rays, bins, encoding, layer-by-layer MLP, compositing)
+            L = (in_dim - 3) // 6
+            enc = mods["encoding"].PositionalEncoding(L, True).to(dev)
+            pose = torch.eye(4); pose[2, 3] = 4.0
+            img = mods["train"].render_one(model, enc, 12, 10, 15.0, pose, dev, n_samples=24, near=2.0, far=6.0, chunk=50)
+            ro_, rd_ = O.pinhole_rays(12, 10, 15.0, pose)
+            co = O.render_rays(params, skip, L, ro_, rd_, 2.0, 6.0, 24, None)[0]
+            assert float((img.cpu().reshape(-1, 3) - co.clamp(0, 1)).abs().max()) <= RGB_TOL
         # a plain torch optimizer trains it (no flat buffer behind these parameters)
         opt = torch.optim.Adam(model.parameters(), lr=1e-3)
         tgt = torch.rand(M, 3, generator=g).to(dev)

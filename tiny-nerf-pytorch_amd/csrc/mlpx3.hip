@@ -99,6 +99,10 @@ __device__ __forceinline__ void tx_mlp_tile(PipeX& p, const unsigned char* lds, 
     auto epiA_split = [&](auto ic, auto kc) TN_INLINE_LAMBDA { tx_epi_split<HID, 0, decltype(ic)::value, decltype(kc)::value, TRAIN, true, true>(accA, X, es, sc, srow, mword); };
     // 256-wide: one pair per group, the chain pipelined over the gaps (SPS 1); 128-wide: two pairs per group, chains inside the group
     constexpr int SPF = HID == 256 ? 1 : 4, SPV = HID == 256 ? 1 : 4, SPS_ = HID == 256 ? 1 : 2;
+    // groups of pass A over which half B's epilogue is spread: its pieces are read from the middle of the pass on, tile by tile, so
+    // the window may reach past the middle as long as every pair stays ahead of its first reader (tx_spread_ok)
+    constexpr int GB = HID == 256 ? TX_GB256 : G2;
+    static_assert(HID != 256 || tx_spread_ok<HID, GB>(), "half B's epilogue window overruns the first read of its pieces");
     auto none = [](auto) TN_INLINE_LAMBDA {};
     TX_PROF_BEGIN(pf);
     TX_PROF_MARK(pf);
@@ -111,7 +115,7 @@ __device__ __forceinline__ void tx_mlp_tile(PipeX& p, const unsigned char* lds, 
     // layer l: half B's epilogue of layer l-1 behind the first half of pass A, half A's of layer l behind the second half of pass B
     for (int l = 1; l < depth; ++l) {
         if (l == skip_at) tx_rescale_input(E, t_prev - in.te);     // the skip layer consumes the input at its own input's scale
-        tx_pass<HID, 1, true, NW>(p, lds, X, E, accA, tx_window<0, G2, NP, 0, TX_NSTEP, SPF>(epiB));
+        tx_pass<HID, 1, true, NW>(p, lds, X, E, accA, tx_window<0, GB, NP, 0, TX_NSTEP, SPF>(epiB));
         if (l == skip_at) tx_pass<HID, 0, false, NW>(p, lds, X, E, accA, none);                    // + W_l[:, hidden:] . encoding
         TX_PROF_MARK(pf);
         point_at(l);
@@ -323,6 +327,8 @@ __device__ __forceinline__ void tx_bwd_tile(PipeX& p, const unsigned char* lds, 
     auto epiA_value = [&](auto ic, auto kc) TN_INLINE_LAMBDA { tx_epi_bwd_value<HID, 0, decltype(ic)::value, decltype(kc)::value, true>(accA, es, sc, mw); };
     auto epiA_split = [&](auto ic, auto kc) TN_INLINE_LAMBDA { tx_epi_split<HID, 0, decltype(ic)::value, decltype(kc)::value, true, false, true>(accA, X, es, sc, zrow, nullptr); };
     constexpr int SPF = HID == 256 ? 1 : 4, SPV = HID == 256 ? 1 : 4, SPS_ = HID == 256 ? 1 : 2;
+    constexpr int GB = HID == 256 ? TX_GB256 : G2;                 // see tx_mlp_tile
+    static_assert(HID != 256 || tx_spread_ok<HID, GB>(), "half B's epilogue window overruns the first read of its pieces");
     // dH_{depth-1} = W_head^T dZ_head: both halves; half A's epilogue has nothing to hide behind
     mk.fetch(mrow + (int64_t)(depth - 1) * (Mp + 32) * NT);
     tx_pass_headsT<HID, NW>(p, lds, Z, accA, accB);
@@ -337,7 +343,7 @@ __device__ __forceinline__ void tx_bwd_tile(PipeX& p, const unsigned char* lds, 
     // begins: part V (mask) in the first half of pass B, part S in the second
     for (int l = depth - 1; l >= 1; --l) {
         mk.fetch(mrow + (int64_t)(l - 1) * (Mp + 32) * NT);
-        tx_pass<HID, 1, true, NW>(p, lds, X, nullptr, accA, tx_window<0, G2, NP, 0, TX_NSTEP, SPF>(epiB));
+        tx_pass<HID, 1, true, NW>(p, lds, X, nullptr, accA, tx_window<0, GB, NP, 0, TX_NSTEP, SPF>(epiB));
         auto w1 = tx_window<0, G2, NP, 0, TX_VSTEPS, SPV>(epiA_value);
         auto w2 = tx_window<(G2 - (HID == 256 ? 1 : 0)) * TX_SPG, G2, NP, TX_VSTEPS, TX_NSTEP, SPS_>(epiA_split);
         tx_pass<HID, 1, true, NW>(p, lds, X, nullptr, accB, [&](auto sc_) TN_INLINE_LAMBDA {

@@ -338,6 +338,9 @@ struct TxEpi { f32x2 v[4], c[4], f[4]; unsigned p1[4]; f32x2 b[4]; uint32_t msk;
 //           the second half of pass B (the slots it overwrites are dead there), from the parked values; for half B both parts run
 //           back to back in the first half of the next layer's pass A.
 #define TX_NSTEP 10
+#ifndef TX_GB256
+#define TX_GB256 44                              // 256-wide: groups over which half B's epilogue is spread in the next pass A (32 = its first half)
+#endif
 #define TX_VSTEPS 4
 
 // steps 4..9 (part S).  FWD: the values are ReLU outputs (sign words are recorded, the L1 norm needs no abs).  PARKED: step 4 first
@@ -422,16 +425,18 @@ __device__ __forceinline__ void tx_epi_bwd_value(f32x16 (&acc)[TX_ACCN(HID)], Tx
 }
 
 // Epilogue steps [K0, K1) of NP pairs over the slots of a pass from W0 on, SPS consecutive steps per slot.  G = groups in which
-// pairs start, PPG = ceil(NP / G) pairs start per group; pair i runs steps K0 + q SPS .. behind MFMA slot W0 + 3 (i / PPG) + q.
-// SPS = 1 is the software pipeline of the comment above (PPG = 1: four pairs in flight); SPS = 4 runs a pair's chain inside its
+// pairs start: G <= NP: PPG = ceil(NP / G) pairs start per group; G > NP ("spread"): pair i starts in group floor(i G / NP), some
+// groups start none.  Pair i runs steps K0 + q SPS .. behind MFMA slot W0 + 3 start(i) + q.
+// SPS = 1 is the software pipeline of the comment above (four pairs in flight); SPS = 4 runs a pair's chain inside its
 // own group (several pairs per group interleave instead).  f(integral_constant<I>, integral_constant<K>).
 // The caller checks that the last pair's last step (slot W0 + 3 (G - 1) + ceil((K1 - K0) / SPS) - 1) lies inside the pass and
-// before the first read of what it writes.
+// before the first read of what it writes (tx_spread_ok for the spread windows).
 template <int W0, int G, int NP, int K0, int K1, int SPS, typename F>
 __device__ __forceinline__ auto tx_window(F&& f) {
     return [&f](auto sc) TN_INLINE_LAMBDA {
         constexpr int s = decltype(sc)::value;
-        constexpr int PPG = (NP + G - 1) / G, NQ = (K1 - K0 + SPS - 1) / SPS, DEPTH = (NQ + TX_SPG - 1) / TX_SPG;
+        constexpr bool SPREAD = G > NP;
+        constexpr int PPG = SPREAD ? 1 : (NP + G - 1) / G, NQ = (K1 - K0 + SPS - 1) / SPS, DEPTH = (NQ + TX_SPG - 1) / TX_SPG;
         static_assert(PPG * DEPTH <= 4, "more pairs in flight than TxEpi holds");
 #ifdef TX_NO_EPI
         return;
@@ -443,15 +448,33 @@ __device__ __forceinline__ auto tx_window(F&& f) {
                 if constexpr (g >= 0 && g < G && q < NQ)
                     tn_static_for<SPS>([&](auto kc) TN_INLINE_LAMBDA {
                         constexpr int k = K0 + q * SPS + decltype(kc)::value;
-                        if constexpr (k < K1)
-                            tn_static_for<PPG>([&](auto uc) TN_INLINE_LAMBDA {
-                                constexpr int i = g * PPG + decltype(uc)::value;
-                                if constexpr (i < NP) f(std::integral_constant<int, i>{}, std::integral_constant<int, k>{});
-                            });
+                        if constexpr (k < K1) {
+                            if constexpr (SPREAD) {
+                                constexpr int i = (g * NP + G - 1) / G;             // the pair that starts in group g, if any
+                                if constexpr (i < NP && (i * G) / NP == g) f(std::integral_constant<int, i>{}, std::integral_constant<int, k>{});
+                            } else {
+                                tn_static_for<PPG>([&](auto uc) TN_INLINE_LAMBDA {
+                                    constexpr int i = g * PPG + decltype(uc)::value;
+                                    if constexpr (i < NP) f(std::integral_constant<int, i>{}, std::integral_constant<int, k>{});
+                                });
+                            }
+                        }
                     });
             });
         }
     };
+}
+// Half B's epilogue rides on the next layer's pass A, whose k-steps KH/2 .. KH-1 read the pieces it writes: pair i (TxPair: tile,
+// register pair -> activation k-step xs) must be through one group before group NH xs starts.  True if a spread window of G groups
+// (SPS = 1, all TX_NSTEP steps) meets that for every pair.
+template <int HID, int G> constexpr bool tx_spread_ok() {
+    constexpr int NH = HID / 64, NP = NH * 8;
+    for (int i = 0; i < NP; ++i) {
+        const int tl = 2 * (i / 16) + (1 - (i % 16) / 8), t = NH + tl, pr = 7 - i % 8, xs = 2 * t + pr / 4;
+        const int last = TX_SPG * ((i * G) / NP) + TX_NSTEP - 1;
+        if (last + TX_SPG >= TX_SPG * NH * xs) return false;
+    }
+    return true;
 }
 // A whole epilogue with nothing to hide behind (steps 0 .. NJ-1 of every pair).
 template <int NP, int NJ, typename F>

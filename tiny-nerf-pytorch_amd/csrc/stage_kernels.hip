@@ -95,7 +95,7 @@ extern "C" int tnerf_sample_encode_fwd(const float* rays_o, const float* rays_d,
                      (const void*)rays_o, (const void*)rays_d, (const void*)ztab);
         return TNERF_EINVAL;
     }
-    if (enc && (L < 0 || L > 16 || 6 * L + (include_input ? 3 : 0) < 1)) { tn_set_error("tnerf_sample_encode_fwd: num_freqs=%d", L); return TNERF_EINVAL; }
+    if (enc && (L < 0 || L > 24 || 6 * L + (include_input ? 3 : 0) < 1)) { tn_set_error("tnerf_sample_encode_fwd: num_freqs=%d", L); return TNERF_EINVAL; }
     if (R == 0) return TNERF_OK;
     SampleArgs sa{ztab, t_rand, seed, offset, S, randomized ? 1 : 0};
     const int64_t M = R * S;
@@ -155,7 +155,7 @@ extern "C" int tnerf_sample_per_ray_fwd(const float* rays_o, const float* rays_d
 
 extern "C" int tnerf_posenc_fwd(const float* x, int64_t n, int32_t L, int32_t include_input, float* out, tnerf_stream_t stream) {
     if (n == 0) return TNERF_OK;
-    if (n < 0 || !x || !out || L < 0 || L > 16 || 6 * L + (include_input ? 3 : 0) < 1) {
+    if (n < 0 || !x || !out || L < 0 || L > 24 || 6 * L + (include_input ? 3 : 0) < 1) {
         tn_set_error("tnerf_posenc_fwd: n=%lld L=%d x=%p out=%p", (long long)n, L, (const void*)x, (void*)out);
         return TNERF_EINVAL;
     }

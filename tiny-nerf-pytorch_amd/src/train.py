@@ -81,7 +81,7 @@ def write_png(path: str, img_u8: np.ndarray) -> None:
 
 def _fusable(model, encoder) -> bool:
     return (isinstance(model, TinyNeRF) and isinstance(encoder, PositionalEncoding) and encoder.include_input
-            and encoder.out_dim == model.in_dim and encoder.num_freqs <= 10)
+            and encoder.out_dim == model.in_dim and encoder.num_freqs <= 10 and model._chain_kernels_cover())
 
 
 @torch.no_grad()
