@@ -126,7 +126,28 @@ def test_two_forwards_of_equal_size_then_one_backward(mods, dev, tag):
     worst = max(relmax(p.grad.cpu(), q) for p, q in zip(plist, go))
     assert worst <= 5e-3, worst
     with pytest.raises(RuntimeError):
-        loss.backward()                                                   # the stash is released after backward
+        loss.backward()                                                   # autograd freed the graph (no retain_graph)
+    # backward(retain_graph=True) more than once (the reference's ops are ordinary autograd): the node keeps its stash, the second
+    # pass gives the same gradients bit for bit; a parameter edited in place in between is refused like autograd refuses it
+    for kind in ("fused", "module"):
+        m2 = make_model(mods, cfg, params, dev)
+        pl2 = m2._param_list()
+        if kind == "fused":
+            out = mods["ops"].render_rays_fused(m2._ensure_packed(), pl2, ro_all[i1].to(dev), rd_all[i1].to(dev), 2.0, 6.0, S, True, t_rand=u[:128].to(dev))[0]
+            l2 = ((out - tgt[i1].to(dev)) ** 2).mean()
+        else:
+            r_, s_ = m2(xa.to(dev))
+            l2 = (r_ * wa.to(dev)).sum() + (s_ * sa.to(dev)).sum()
+        l2.backward(retain_graph=True)
+        g1 = [p.grad.clone() for p in pl2]
+        for p in pl2:
+            p.grad = None
+        l2.backward(retain_graph=True)
+        assert all(torch.equal(a, p.grad) for a, p in zip(g1, pl2)), kind
+        with torch.no_grad():
+            pl2[2].mul_(1.0)
+        with pytest.raises(RuntimeError, match="modified by an inplace"):
+            l2.backward()
 
 
 def test_rebinding_an_interior_parameter_is_noticed(mods, dev):

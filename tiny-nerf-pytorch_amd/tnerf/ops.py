@@ -398,6 +398,14 @@ class _Bf16TrainPlan:
 
 
 # ---------------------------------------------------------------------------------- MLP op
+def _check_versions(ctx, who: str) -> None:
+    """The backward reads the packed weights of NOW against the activations of the forward: refuse, like autograd does for saved
+    tensors, when a parameter was modified in place in between (an optimizer step before a second backward(retain_graph=True))."""
+    if tuple(p._version for p in ctx.params) != ctx.versions:
+        raise RuntimeError(f"{who}: one of the parameters needed for gradient computation has been modified by an inplace operation "
+                           "since the forward (e.g. optimizer.step() between two backward passes over the same graph)")
+
+
 class _MlpFn(torch.autograd.Function):
     """TinyNeRF.forward on x[M, in_dim] with parameter gradients (no gradient w.r.t. x)."""
 
@@ -418,6 +426,7 @@ class _MlpFn(torch.autograd.Function):
                 lease.buf.data_ptr() if train else None, plan.Mp if train else 0, _stream(dev))
         ctx.st, ctx.plan, ctx.M, ctx.lease, ctx.x3 = st, plan, M, lease, x3
         ctx.shapes = [p.shape for p in params]
+        ctx.params, ctx.versions = params, tuple(p._version for p in params)
         return rgb, sigma
 
     @staticmethod
@@ -425,9 +434,7 @@ class _MlpFn(torch.autograd.Function):
         st, plan, M, lease = ctx.st, ctx.plan, ctx.M, ctx.lease
         if plan is None:
             raise RuntimeError("TinyNeRF (HIP): backward through a forward that ran without grad enabled")
-        if lease.buf is None:
-            raise RuntimeError("TinyNeRF (HIP): backward called twice on the same forward (its activation stash was released; "
-                               "retain_graph is not supported)")
+        _check_versions(ctx, "TinyNeRF (HIP)")
         dev = st.device
         g_rgb = torch.zeros(M, 3, dtype=torch.float32, device=dev) if g_rgb is None else _f32c(g_rgb)
         g_sigma = torch.zeros(M, 1, dtype=torch.float32, device=dev) if g_sigma is None else _f32c(g_sigma)
@@ -437,8 +444,7 @@ class _MlpFn(torch.autograd.Function):
                 lease.buf.data_ptr(), plan.Mp, plan.jobs.data_ptr(), plan.n_jobs, plan.slabs.data_ptr(), plan.reduce.data_ptr(),
                 st.grad.data_ptr(), _stream(dev))
         grads = [st.grad[o:o + int(np.prod(s))].view(s).clone() for s, o in zip(ctx.shapes, st.offsets)]
-        lease.release()
-        return (None, None, None, *grads)
+        return (None, None, None, *grads)          # the stash stays leased until this node dies: backward(retain_graph=True) may come again
 
 
 def mlp_forward(st: ModelState, x: torch.Tensor, params) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -537,6 +543,7 @@ class _FusedRaysFn(torch.autograd.Function):
             ctx.x3 = x3
             ctx.lease = lease
             ctx.shapes = [p.shape for p in params]
+            ctx.params, ctx.versions = params, tuple(p._version for p in params)
             return comp, None, None
         depth = torch.empty(R, 1, dtype=torch.float32, device=dev)
         acc = torch.empty(R, 1, dtype=torch.float32, device=dev)
@@ -555,15 +562,13 @@ class _FusedRaysFn(torch.autograd.Function):
         dev = st.device
         g_comp = _f32c(g_comp)
         lease = ctx.lease
-        if lease.buf is None:
-            raise RuntimeError("fused render (HIP): backward called twice on the same forward (retain_graph is not supported)")
+        _check_versions(ctx, "fused render (HIP)")
         _l.call("tnerf_train_bwd_fused", C.byref(st.desc), st.packed.data_ptr(), rays_o.data_ptr(), rays_d.data_ptr(), R, S,
                 ztab.data_ptr(), rnd, t_rand.data_ptr() if has_tr else None, seed, off, white, g_comp.data_ptr(),
                 lease.buf.data_ptr(), plan.Mp, plan.jobs.data_ptr(), plan.n_jobs, plan.slabs.data_ptr(), plan.reduce.data_ptr(),
                 st.grad.data_ptr(), ctx.x3.packed.data_ptr() if ctx.x3 is not None else None, _stream(dev))
         grads = [st.grad[o:o + int(np.prod(s))].view(s).clone() for s, o in zip(ctx.shapes, st.offsets)]
-        lease.release()
-        return (None,) * 11 + tuple(grads)
+        return (None,) * 11 + tuple(grads)         # the stash stays leased until this node dies (retain_graph)
 
 
 def render_rays_fused(st: ModelState, params, rays_o, rays_d, near, far, n_samples, randomized, white_bkgd=True,
