@@ -160,6 +160,21 @@ int tnerf_composite_bwd(const float* rgb, const float* sigma, const float* z_val
                         const float* g_comp, const float* g_depth, const float* g_acc, const float* g_weights,
                         float* d_rgb, float* d_sigma, tnerf_stream_t stream);
 
+/* The geometry side of the same chain — what the reference's autograd would also give (its training never asks: the points carry
+ * no grad, train.py:114-117), for callers that learn poses or resample:
+ *   tnerf_composite_bwd_geom: tnerf_composite_bwd + d_z [R,S] (dL/dz_vals) and d_rays_d [R,3] (either may be NULL)   [volume.py:18-44]
+ *   tnerf_sample_bwd        : pts = o + d z  ->  dL/drays_o [R,3], dL/drays_d [R,3], dL/dz [R,S] from g_pts [R,S,3]; z_row_stride 0 =
+ *                             one shared row of depths (the non-randomized table)                                   [sampling.py:27]
+ *   tnerf_posenc_bwd        : dL/dx [n,3] from g_out [n, 6L(+3)]                                                    [encoding.py:27-33] */
+int tnerf_composite_bwd_geom(const float* rgb, const float* sigma, const float* z_vals, const float* rays_d,
+                             int64_t n_rays, int32_t n_samples, int32_t white_bkgd,
+                             const float* g_comp, const float* g_depth, const float* g_acc, const float* g_weights,
+                             float* d_rgb, float* d_sigma, float* d_z, float* d_rays_d, tnerf_stream_t stream);
+int tnerf_sample_bwd(const float* rays_d, const float* z_vals, int64_t z_row_stride, const float* g_pts, int64_t n_rays, int32_t n_samples,
+                     float* d_rays_o, float* d_rays_d, float* d_z, tnerf_stream_t stream);
+int tnerf_posenc_bwd(const float* x, int64_t n, int32_t num_freqs, int32_t include_input, const float* g_out, float* d_x,
+                     tnerf_stream_t stream);
+
 /* ------------------------------------------------------------------------------- MLP (MFMA) */
 /* Re-order the flat parameters into MFMA fragment order: packed[i] = params[pack_table[i]]. */
 int tnerf_mlp_pack(const float* params, const int32_t* pack_table, int64_t packed_floats,

@@ -587,6 +587,59 @@ def test_dataset_trainer_follows_caller_side_parameter_edits(mods, dev, prec):
         t.step()
 
 
+# ------------------------------------------------------------------ gradients w.r.t. rays and depths (per-function ops)
+@pytest.mark.parametrize("S", [40, 150])
+def test_geometry_gradients_through_the_per_function_ops(mods, dev, S):
+    """The reference's ops are ordinary autograd (src/volume.py:18-44, src/sampling.py:27, src/encoding.py:27-33, src/nerf.py:29-41):
+    a caller that learns poses differentiates the rendered colour / depth / opacity w.r.t. ray origins, directions and depths.
+    Through the per-function HIP ops (tnerf_composite_bwd_geom, tnerf_sample_bwd, tnerf_posenc_bwd, tnerf_mlp_bwd_generic) against
+    the oracle's autograd, with an fp64 evaluation as the yardstick; S = 150 walks three 64-sample segments per ray."""
+    cfg, params = golden_params("4x128")
+    L, skip = cfg["L"], cfg["skip_at"]
+    g = torch.Generator().manual_seed(11)
+    R = 70
+    d0 = torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=-1) * (0.8 + 0.4 * torch.rand(R, 1, generator=g))
+    o0 = -4.0 * torch.nn.functional.normalize(d0, dim=-1) + 0.2 * torch.randn(R, 3, generator=g)
+    u = torch.rand(R, S, generator=g)
+    wc, wd, wa = torch.randn(R, 3, generator=g), torch.randn(R, 1, generator=g) * 0.1, torch.randn(R, 1, generator=g)
+
+    def oracle(dtype):
+        ps = [p.to(dtype) for p in params]
+        o, d = o0.to(dtype).clone().requires_grad_(True), d0.to(dtype).clone().requires_grad_(True)
+        comp, depth, acc, _ = O.render_rays(ps, skip, L, o, d, 2.0, 6.0, S, u.to(dtype))
+        loss = (comp * wc.to(dtype)).sum() + (depth * wd.to(dtype)).sum() + (acc * wa.to(dtype)).sum()
+        return torch.autograd.grad(loss, [o, d]), (comp.detach(), depth.detach())
+
+    (go32, gd32), (c32, dep32) = oracle(torch.float32)
+    (go64, gd64), _ = oracle(torch.float64)
+    model = make_model(mods, cfg, params, dev)
+    enc = mods["encoding"].PositionalEncoding(L, True).to(dev)
+    o, d = o0.clone().to(dev).requires_grad_(True), d0.clone().to(dev).requires_grad_(True)
+    z, pts, _ = mods["ops"].sample_along_rays(2.0, 6.0, S, o.detach(), d.detach(), True, t_rand=u.to(dev))
+    pts = mods["ops"].attach_points_grad(o, d, z, pts)
+    rgb, sigma = model(enc(pts.reshape(-1, 3)))
+    comp, depth, acc, _ = mods["volume"].volume_render(rgb.reshape(R, S, 3), sigma.reshape(R, S, 1), z, d)
+    assert float((comp.detach().cpu() - c32).abs().max()) <= RGB_TOL and float((depth.detach().cpu() - dep32).abs().max()) <= 1e-3
+    ((comp * wc.to(dev)).sum() + (depth * wd.to(dev)).sum() + (acc * wa.to(dev)).sum()).backward()
+    for name, a, b, c in (("rays_o", o.grad, go32, go64), ("rays_d", d.grad, gd32, gd64)):
+        t_hip, t_ref = relmax(a.cpu().double(), c), relmax(b.double(), c)
+        assert t_hip <= 2.0 * t_ref + 2e-5, (name, t_hip, t_ref)
+    # volume_render alone, depths as a leaf (a resampling / hierarchical term differentiates w.r.t. z_vals)
+    rg, sg = torch.rand(R, S, 3, generator=g), torch.rand(R, S, 1, generator=g) * 3.0
+    zs = (2.0 + 4.0 * torch.sort(torch.rand(R, S, generator=g), dim=-1).values)
+
+    def comp_loss(fn, dtype, device):
+        zz, dd = zs.to(dtype).clone().to(device).requires_grad_(True), d0.to(dtype).clone().to(device).requires_grad_(True)
+        c_, dp_, ac_, w_ = fn(rg.to(dtype).to(device), sg.to(dtype).to(device), zz, dd)
+        loss = (c_ * wc.to(dtype).to(device)).sum() + (dp_ * wd.to(dtype).to(device)).sum() + (ac_ * wa.to(dtype).to(device)).sum() + (w_ * w_).sum()
+        return torch.autograd.grad(loss, [zz, dd])
+    h = comp_loss(mods["volume"].volume_render, torch.float32, dev)
+    r32, r64 = comp_loss(O.composite, torch.float32, "cpu"), comp_loss(O.composite, torch.float64, "cpu")
+    for name, a, b, c in zip(("z_vals", "rays_d"), h, r32, r64):
+        t_hip, t_ref = relmax(a.cpu().double(), c), relmax(b.double(), c)
+        assert t_hip <= 2.0 * t_ref + 2e-5, (name, t_hip, t_ref)
+
+
 # ------------------------------------------------------------------------------- any hidden width up to 256
 @pytest.mark.parametrize("arch", [(39, 200, 3, 2), (63, 64, 4, 2), (39, 100, 2, 0), (27, 31, 3, 1)])
 def test_hidden_widths_other_than_128_and_256(mods, dev, arch):

@@ -215,12 +215,17 @@ __global__ __launch_bounds__(256) void k_composite_fwd(const float* __restrict__
 //   dL/dc_i   = w_i g_C
 //   dL/da_i   = T_i dL/dw_i - (sum_{k>i} w_k dL/dw_k) / om_i
 //   dL/dsig_i = dL/da_i * delta_i * exp(-sig_i delta_i)
+// GEOM: also dL/dz_vals and dL/drays_d (the reference's volume_render is ordinary autograd, volume.py:18-44; its training never asks):
+//   delta_i = (z_{i+1} - z_i) |d|  (1e10 |d| for the last sample), dL/ddelta_i = dL/da_i exp(-sig_i delta_i) sig_i
+//   dL/dz_i = g_depth w_i + |d| (dL/ddelta_{i-1} - dL/ddelta_i [i < S-1]),   dL/d|d| = sum_i dL/ddelta_i gap_i,   dL/dd = dL/d|d| d / |d|
+template <bool GEOM>
 __global__ __launch_bounds__(256) void k_composite_bwd(const float* __restrict__ rgb, const float* __restrict__ sigma,
                                                        const float* __restrict__ z_vals, const float* __restrict__ rays_d,
                                                        int64_t R, int S, int white,
                                                        const float* __restrict__ g_comp, const float* __restrict__ g_depth,
                                                        const float* __restrict__ g_acc, const float* __restrict__ g_w,
-                                                       float* __restrict__ d_rgb, float* __restrict__ d_sigma) {
+                                                       float* __restrict__ d_rgb, float* __restrict__ d_sigma,
+                                                       float* __restrict__ d_z, float* __restrict__ d_rays_d) {
     const int lane = tn_lane();
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -247,6 +252,7 @@ __global__ __launch_bounds__(256) void k_composite_bwd(const float* __restrict__
         float seg_T = __shfl_up(seg_incl, 1, 64);
         if (lane == 0) seg_T = 1.0f;
         float tail = 0.0f;                                   // sum of w_k dL/dw_k over later segments
+        float dnorm_acc = 0.0f;                              // GEOM: this lane's share of dL/d|d|
         for (int g = nseg - 1; g >= 0; --g) {
             const int s = g * 64 + lane; const bool ok = s < S;
             const int64_t m = r * S + (ok ? s : S - 1);
@@ -266,14 +272,86 @@ __global__ __launch_bounds__(256) void k_composite_bwd(const float* __restrict__
             const float v = ok ? w * dw : 0.f;
             const float suf_incl = tn_wave_suffix_sum(v, lane);
             const float after = (suf_incl - v) + tail;
+            float dd = 0.0f;                                 // dL/ddelta_i
             if (ok) {
                 const float da = T * dw - after / om;
                 d_sigma[m] = (da * t.e) * t.delta;          // autograd's order: exp-backward, then * delta
                 d_rgb[3 * m] = w * gr; d_rgb[3 * m + 1] = w * gg; d_rgb[3 * m + 2] = w * gb;
+                dd = (da * t.e) * sg;
+            }
+            if constexpr (GEOM) {
+                const bool last = s == S - 1;
+                const float gap = last ? 1e10f : __fsub_rn(zn, z);
+                dnorm_acc += ok ? dd * gap : 0.0f;
+                float from_prev = __shfl_up(dd, 1, 64);      // dL/ddelta_{i-1} (lane 0: from the previous segment, added below)
+                if (lane == 0) from_prev = 0.0f;
+                if (ok && d_z) d_z[m] = gd * w + dn * (from_prev - (last ? 0.0f : dd));
+                // S > 64 only: the first sample of the NEXT segment (stored one iteration ago) still lacks this segment's last
+                // dL/ddelta.  Its store has been acknowledged (vmcnt 0) before the ONE add per address goes to L2: order-independent,
+                // deterministic.
+                if (nseg > 1) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (d_z && lane == 63 && s + 1 < S) atomicAdd(&d_z[m + 1], dn * dd);
+                }
             }
             tail += __shfl(suf_incl, 0, 64);
         }
+        if constexpr (GEOM) {
+            const float dnrm = tn_wave_sum(dnorm_acc);
+            if (d_rays_d && lane < 3) {
+                const float c = rays_d[3 * r + lane];
+                d_rays_d[3 * r + lane] = dn > 0.0f ? dnrm * (c / dn) : 0.0f;
+            }
+        }
     }
+}
+
+// stratified_samples backward: pts = o + d z (sampling.py:27), so dL/do = sum_s dL/dpts, dL/dd = sum_s z dL/dpts, dL/dz = d . dL/dpts.
+// One ray per wavefront.  Any output may be NULL.
+__global__ __launch_bounds__(256) void k_sample_bwd(const float* __restrict__ rays_d, const float* __restrict__ z_vals, int64_t z_row_stride,
+                                                    const float* __restrict__ g_pts, int64_t R, int S,
+                                                    float* __restrict__ d_o, float* __restrict__ d_d, float* __restrict__ d_z) {
+    const int lane = tn_lane();
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t r = wave; r < R; r += nwaves) {
+        const float dx = rays_d[3 * r], dy = rays_d[3 * r + 1], dz_ = rays_d[3 * r + 2];
+        float ox = 0.f, oy = 0.f, oz = 0.f, ax = 0.f, ay = 0.f, az = 0.f;
+        for (int s = lane; s < S; s += 64) {
+            const int64_t m = r * S + s;
+            const float gx = g_pts[3 * m], gy = g_pts[3 * m + 1], gz = g_pts[3 * m + 2];
+            const float z = z_vals[r * z_row_stride + s];
+            ox += gx; oy += gy; oz += gz;
+            ax += z * gx; ay += z * gy; az += z * gz;
+            if (d_z) d_z[m] = dx * gx + dy * gy + dz_ * gz;
+        }
+        ox = tn_wave_sum(ox); oy = tn_wave_sum(oy); oz = tn_wave_sum(oz);
+        ax = tn_wave_sum(ax); ay = tn_wave_sum(ay); az = tn_wave_sum(az);
+        if (lane == 0) {
+            if (d_o) { d_o[3 * r] = ox; d_o[3 * r + 1] = oy; d_o[3 * r + 2] = oz; }
+            if (d_d) { d_d[3 * r] = ax; d_d[3 * r + 1] = ay; d_d[3 * r + 2] = az; }
+        }
+    }
+}
+
+// PositionalEncoding backward (encoding.py:27-33): dL/dx_c = [g_x_c] + sum_k 2^k (cos(2^k x_c) g_sin_kc - sin(2^k x_c) g_cos_kc).
+__global__ __launch_bounds__(256) void k_posenc_bwd(const float* __restrict__ x, int64_t n, int L, int include_input,
+                                                    const float* __restrict__ g_out, float* __restrict__ d_x) {
+    const int D = 6 * L + (include_input ? 3 : 0);
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 3 * n) return;
+    const int64_t m = i / 3; const int c = (int)(i % 3);
+    const float xv = x[i];
+    const float* g = g_out + m * D;
+    float acc = include_input ? g[c] : 0.0f;
+    const int base = include_input ? 3 : 0;
+    for (int k = 0; k < L; ++k) {
+        const float f = (float)(1u << k);
+        float sn, cs;
+        tn_sincos(xv * f, sn, cs);
+        acc += f * (cs * g[base + 6 * k + c] - sn * g[base + 6 * k + 3 + c]);
+    }
+    d_x[i] = acc;
 }
 
 static int composite_check(const char* who, const float* rgb, const float* sigma, const float* z, const float* rd, int64_t R, int S) {
@@ -306,8 +384,47 @@ extern "C" int tnerf_composite_bwd(const float* rgb, const float* sigma, const f
     int rc = composite_check("tnerf_composite_bwd", rgb, sigma, z_vals, rays_d, R, S); if (rc) return rc;
     if (R == 0) return TNERF_OK;
     if (!d_rgb || !d_sigma) { tn_set_error("tnerf_composite_bwd: NULL output"); return TNERF_EINVAL; }
-    hipLaunchKernelGGL(k_composite_bwd, dim3(ray_grid(R)), dim3(256), 0, (hipStream_t)stream, rgb, sigma, z_vals, rays_d, R, S, white,
-                       g_comp, g_depth, g_acc, g_w, d_rgb, d_sigma);
+    hipLaunchKernelGGL(k_composite_bwd<false>, dim3(ray_grid(R)), dim3(256), 0, (hipStream_t)stream, rgb, sigma, z_vals, rays_d, R, S, white,
+                       g_comp, g_depth, g_acc, g_w, d_rgb, d_sigma, (float*)nullptr, (float*)nullptr);
     TN_HIP_CHECK_LAUNCH("tnerf_composite_bwd");
+    return TNERF_OK;
+}
+
+extern "C" int tnerf_composite_bwd_geom(const float* rgb, const float* sigma, const float* z_vals, const float* rays_d,
+                                        int64_t R, int32_t S, int32_t white, const float* g_comp, const float* g_depth,
+                                        const float* g_acc, const float* g_w, float* d_rgb, float* d_sigma, float* d_z, float* d_rays_d,
+                                        tnerf_stream_t stream) {
+    int rc = composite_check("tnerf_composite_bwd_geom", rgb, sigma, z_vals, rays_d, R, S); if (rc) return rc;
+    if (R == 0) return TNERF_OK;
+    if (!d_rgb || !d_sigma) { tn_set_error("tnerf_composite_bwd_geom: NULL output"); return TNERF_EINVAL; }
+    hipLaunchKernelGGL(k_composite_bwd<true>, dim3(ray_grid(R)), dim3(256), 0, (hipStream_t)stream, rgb, sigma, z_vals, rays_d, R, S, white,
+                       g_comp, g_depth, g_acc, g_w, d_rgb, d_sigma, d_z, d_rays_d);
+    TN_HIP_CHECK_LAUNCH("tnerf_composite_bwd_geom");
+    return TNERF_OK;
+}
+
+extern "C" int tnerf_sample_bwd(const float* rays_d, const float* z_vals, int64_t z_row_stride, const float* g_pts, int64_t R, int32_t S,
+                                float* d_rays_o, float* d_rays_d, float* d_z, tnerf_stream_t stream) {
+    if (R == 0 && S >= 1) return TNERF_OK;
+    if (R < 0 || S < 1 || !rays_d || !z_vals || !g_pts || (z_row_stride != 0 && z_row_stride < S)) {
+        tn_set_error("tnerf_sample_bwd: R=%lld S=%d rays_d=%p z=%p (row stride %lld) g_pts=%p", (long long)R, S, (const void*)rays_d,
+                     (const void*)z_vals, (long long)z_row_stride, (const void*)g_pts);
+        return TNERF_EINVAL;
+    }
+    hipLaunchKernelGGL(k_sample_bwd, dim3(ray_grid(R)), dim3(256), 0, (hipStream_t)stream, rays_d, z_vals, z_row_stride, g_pts, R, S,
+                       d_rays_o, d_rays_d, d_z);
+    TN_HIP_CHECK_LAUNCH("tnerf_sample_bwd");
+    return TNERF_OK;
+}
+
+extern "C" int tnerf_posenc_bwd(const float* x, int64_t n, int32_t L, int32_t include_input, const float* g_out, float* d_x,
+                                tnerf_stream_t stream) {
+    if (n == 0) return TNERF_OK;
+    if (n < 0 || !x || !g_out || !d_x || L < 0 || L > 24 || 6 * L + (include_input ? 3 : 0) < 1) {
+        tn_set_error("tnerf_posenc_bwd: n=%lld L=%d x=%p g_out=%p d_x=%p", (long long)n, L, (const void*)x, (const void*)g_out, (void*)d_x);
+        return TNERF_EINVAL;
+    }
+    hipLaunchKernelGGL(k_posenc_bwd, dim3((unsigned)((3 * n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, n, L, include_input, g_out, d_x);
+    TN_HIP_CHECK_LAUNCH("tnerf_posenc_bwd");
     return TNERF_OK;
 }

@@ -16,6 +16,9 @@ def stratified_samples(near, far, n_samples, rays_o, rays_d, randomized=True):
     if randomized:
         t_rand = torch.rand(rays_o.shape[0], int(n_samples), dtype=torch.float32, device=rays_o.device)
     if isinstance(near, torch.Tensor) or isinstance(far, torch.Tensor):      # "tensors broadcastable to (N_rays, 1)", sampling.py:8
-        return ops.sample_along_rays_per_ray(near, far, int(n_samples), rays_o, rays_d, bool(randomized), t_rand)
-    z_vals, pts, _ = ops.sample_along_rays(float(near), float(far), int(n_samples), rays_o, rays_d, bool(randomized), t_rand)
-    return z_vals, pts
+        z_vals, pts = ops.sample_along_rays_per_ray(near, far, int(n_samples), rays_o, rays_d, bool(randomized), t_rand)
+    else:
+        z_vals, pts, _ = ops.sample_along_rays(float(near), float(far), int(n_samples), rays_o, rays_d, bool(randomized), t_rand)
+    # rays that require grad (a learned pose): pts = o + d z is differentiable in o and d, as in the reference (sampling.py:27);
+    # the depths themselves depend on near / far and the jitter only
+    return z_vals, ops.attach_points_grad(rays_o, rays_d, z_vals, pts)

@@ -106,6 +106,9 @@ SIGNATURES = {
                                               _P, _P, _I64, _P, _P, _P, _I64, _P, _P, _P, _P]),
     "tnerf_train_step_fused_cam_bf16": (C.c_int, [_DESC, _P, C.POINTER(Camera), _P, _I64, _I32, _P, _I32, _P, _U64, _U64, _I32, _D,
                                                   _P, _P, _I64, _P, _P, _P, _I64, _P, _P, _P, _P]),
+    "tnerf_composite_bwd_geom": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "tnerf_sample_bwd": (C.c_int, [_P, _P, _I64, _P, _I64, _I32, _P, _P, _P, _P]),
+    "tnerf_posenc_bwd": (C.c_int, [_P, _I64, _I32, _I32, _P, _P, _P]),
     "tnerf_mlp_generic_acts_floats": (C.c_int64, [_DESC, _I64]),
     "tnerf_mlp_generic_scratch_floats": (C.c_int64, [_DESC, _I64]),
     "tnerf_mlp_fwd_generic": (C.c_int, [_DESC, _P, _P, _P, _I64, _P, _P, _P, _I64, _P]),

@@ -152,11 +152,10 @@ def sample_along_rays_per_ray(near, far, n_samples: int, rays_o: torch.Tensor, r
 def posenc(x: torch.Tensor, num_freqs: int, include_input: bool) -> torch.Tensor:
     dev = _need_cuda(x)
     lead = x.shape[:-1]
-    xf = _f32c(x).reshape(-1, 3)
+    xf = x.reshape(-1, 3)
+    xf = xf if (xf.dtype == torch.float32 and xf.is_contiguous()) else xf.float().contiguous()
     D = 6 * num_freqs + (3 if include_input else 0)
-    out = torch.empty(xf.shape[0], D, dtype=torch.float32, device=dev)
-    _l.call("tnerf_posenc_fwd", xf.data_ptr(), xf.shape[0], int(num_freqs), int(bool(include_input)), out.data_ptr(), _stream(dev))
-    return out.reshape(*lead, D)
+    return _PosEncFn.apply(xf, int(num_freqs), bool(include_input)).reshape(*lead, D)
 
 
 class _Composite(torch.autograd.Function):
@@ -184,16 +183,72 @@ class _Composite(torch.autograd.Function):
         gs = [None if g is None else _f32c(g) for g in (g_comp, g_depth, g_acc, g_w)]
         d_rgb = torch.empty_like(rgb)
         d_sigma = torch.empty(ctx.sigma_shape, dtype=torch.float32, device=dev)
+        need_z, need_d = ctx.needs_input_grad[2], ctx.needs_input_grad[3]
+        if need_z or need_d:          # the geometry side (learned poses, resampling): dL/dz_vals, dL/drays_d
+            d_z = torch.empty(R, S, dtype=torch.float32, device=dev) if need_z else None
+            d_d = torch.empty(R, 3, dtype=torch.float32, device=dev) if need_d else None
+            _l.call("tnerf_composite_bwd_geom", rgb.data_ptr(), sigma.data_ptr(), z_vals.data_ptr(), rays_d.data_ptr(), R, S, ctx.white,
+                    _ptr(gs[0]), _ptr(gs[1]), _ptr(gs[2]), _ptr(gs[3]), d_rgb.data_ptr(), d_sigma.data_ptr(), _ptr(d_z), _ptr(d_d), _stream(dev))
+            return d_rgb, d_sigma, d_z, d_d, None
         _l.call("tnerf_composite_bwd", rgb.data_ptr(), sigma.data_ptr(), z_vals.data_ptr(), rays_d.data_ptr(), R, S, ctx.white,
                 _ptr(gs[0]), _ptr(gs[1]), _ptr(gs[2]), _ptr(gs[3]), d_rgb.data_ptr(), d_sigma.data_ptr(), _stream(dev))
         return d_rgb, d_sigma, None, None, None
 
 
 def volume_render(rgb, sigma, z_vals, rays_d, white_bkgd=True):
-    if z_vals.requires_grad or rays_d.requires_grad:
-        raise NotImplementedError("volume_render (HIP): gradients w.r.t. z_vals / rays_d are not implemented "
-                                  "(the reference never asks for them)")
     return _Composite.apply(rgb, sigma, z_vals, rays_d, white_bkgd)
+
+
+class _PointsFn(torch.autograd.Function):
+    """pts = o + d z (reference src/sampling.py:27) for already drawn depths: the differentiable part of stratified_samples."""
+
+    @staticmethod
+    def forward(ctx, rays_o, rays_d, z_vals, pts):
+        ctx.save_for_backward(rays_d, z_vals)
+        return pts.view_as(pts)
+
+    @staticmethod
+    def backward(ctx, g_pts):
+        rays_d, z_vals = ctx.saved_tensors
+        dev = rays_d.device
+        R, S = z_vals.shape
+        g_pts = _f32c(g_pts)
+        rd = _f32c(rays_d)
+        zs = z_vals if z_vals.stride(-1) == 1 else z_vals.contiguous()
+        stride = 0 if (zs.stride(0) == 0 or R == 1) else zs.stride(0)
+        need_o, need_d, need_z = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        d_o = torch.empty(R, 3, dtype=torch.float32, device=dev) if need_o else None
+        d_d = torch.empty(R, 3, dtype=torch.float32, device=dev) if need_d else None
+        d_z = torch.empty(R, S, dtype=torch.float32, device=dev) if need_z else None
+        _l.call("tnerf_sample_bwd", rd.data_ptr(), zs.data_ptr(), stride, g_pts.data_ptr(), R, S, _ptr(d_o), _ptr(d_d), _ptr(d_z), _stream(dev))
+        return d_o, d_d, d_z, None
+
+
+def attach_points_grad(rays_o, rays_d, z_vals, pts):
+    """pts as computed by the sampling kernel, re-attached to autograd as o + d z when any of its inputs requires grad."""
+    if torch.is_grad_enabled() and (rays_o.requires_grad or rays_d.requires_grad or z_vals.requires_grad):
+        return _PointsFn.apply(rays_o, rays_d, z_vals, pts)
+    return pts
+
+
+class _PosEncFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xf, num_freqs, include_input):
+        dev = xf.device
+        D = 6 * num_freqs + (3 if include_input else 0)
+        out = torch.empty(xf.shape[0], D, dtype=torch.float32, device=dev)
+        _l.call("tnerf_posenc_fwd", xf.data_ptr(), xf.shape[0], int(num_freqs), int(bool(include_input)), out.data_ptr(), _stream(dev))
+        ctx.save_for_backward(xf)
+        ctx.cfg = (int(num_freqs), int(bool(include_input)))
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        (xf,) = ctx.saved_tensors
+        g_out = _f32c(g_out)
+        d_x = torch.empty_like(xf)
+        _l.call("tnerf_posenc_bwd", xf.data_ptr(), xf.shape[0], ctx.cfg[0], ctx.cfg[1], g_out.data_ptr(), d_x.data_ptr(), _stream(xf.device))
+        return d_x, None, None
 
 
 # ------------------------------------------------------------------------------- model state
