@@ -173,11 +173,16 @@ def test_psnr(mods, dev):
 
 
 # -------------------------------------------------------------------------------------- MLP
+@pytest.mark.parametrize("pipe", ["x3", "fp32_mfma"])
 @pytest.mark.parametrize("tag", ["4x128", "8x256"])
-def test_mlp_forward_backward(mods, dev, tag):
+def test_mlp_forward_backward(mods, dev, tag, pipe):
+    """The same gates for both matrix pipes: the default x3 scheme (three fp16 partial products) and plain fp32 MFMA."""
     cfg, params = golden_params(tag)
     g = load_golden(f"mlp_{tag}")
-    model = make_model(mods, cfg, params, dev)
+    model = mods["nerf"].TinyNeRF(cfg["in_dim"], cfg["hidden"], cfg["depth"], cfg["skip_at"], matrix_pipe=pipe).to(dev)
+    with torch.no_grad():
+        for p_, v_ in zip(model.parameters(), params):
+            p_.copy_(v_.to(dev))
     assert list(model.state_dict().keys())[:2] == ["layers.0.weight", "layers.0.bias"]
     assert "sigma.0.weight" in model.state_dict() and "rgb.0.bias" in model.state_dict()
     rgb, sigma = model(g["x"].to(dev))

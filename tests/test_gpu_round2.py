@@ -587,6 +587,37 @@ def test_dataset_trainer_follows_caller_side_parameter_edits(mods, dev, prec):
         t.step()
 
 
+def test_train_main_philox_resume_continues_the_same_run(mods, dev, tmp_path):
+    """train.main with rng="philox" (speed path: draws in the kernels from the device step counter): 6 uninterrupted steps follow the
+    oracle on the emulated draws, and 3 steps + resume to 6 land on the SAME weights bit for bit — the counter, Adam's moments and the
+    image index continue from the checkpoint, and counter-based draws do not depend on where the process was restarted."""
+    train, data = mods["train"], mods["data"]
+    scene = data.make_synthetic_scene(n_images=5, H=20, W=20, focal=138.88887889922103 * 0.2, seed=4)
+    npz = str(tmp_path / "tiny.npz")
+    np.savez(npz, images=scene["images"], poses=scene["poses"], focal=np.float64(scene["focal"]))
+    d = data.load_tiny_nerf_npz(npz)
+    images, poses, focal = torch.from_numpy(d["images"]), torch.from_numpy(d["poses"]), float(d["focal"])
+    n_rand, S, L, hid, dep, skip = 96, 24, 4, 128, 3, 2
+
+    def cfg(iters, tag):
+        return train.Config(iters=iters, n_rand=n_rand, n_samples=S, lr=5e-4, log_every=2, preview_every=100, ckpt_every=3,
+                            ckpt_path=str(tmp_path / tag / "ck" / "latest.pth"), out_dir=str(tmp_path / tag / "out"), resume=True,
+                            preview_pose=None, fused=True, num_freqs=L, hidden=hid, depth=dep, skip_at=skip, data_path=npz, rng="philox")
+
+    torch.manual_seed(0)
+    p0 = [p.detach().clone() for p in mods["nerf"].TinyNeRF(6 * L + 3, hid, dep, skip).parameters()]
+    mA = train.main(cfg(6, "A"))
+    draws = [_emulated_draws(0, s, n_rand, S, 400) for s in range(6)]
+    want, _, _ = _oracle_loop(p0, dict(L=L, skip_at=skip), images, poses, focal, n_rand, S, draws, 0, 5e-4)
+    err = max(float((p.detach().cpu() - q).abs().max()) for p, q in zip(mA.parameters(), want))
+    assert err <= 5e-5, err
+    train.main(cfg(3, "B"))
+    assert torch.load(str(tmp_path / "B" / "ck" / "latest.pth"), map_location="cpu")["step"] == 3
+    mB = train.main(cfg(6, "B"))
+    assert all(torch.equal(a.detach(), b.detach()) for a, b in zip(mA.parameters(), mB.parameters()))
+    assert torch.load(str(tmp_path / "B" / "ck" / "latest.pth"), map_location="cpu")["step"] == 6
+
+
 # ------------------------------------------------------------------ gradients w.r.t. rays and depths (per-function ops)
 @pytest.mark.parametrize("S", [40, 150])
 def test_geometry_gradients_through_the_per_function_ops(mods, dev, S):
