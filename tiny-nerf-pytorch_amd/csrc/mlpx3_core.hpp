@@ -45,6 +45,11 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define TX_NS 7                                // ring slots
 #define TX_RING (TX_NS * TX_SLOT)              // 112 KB
 #define TX_LEAD 5                              // stages in flight behind the published one (LEAD + 2 <= NS)
+#ifndef TX_WAIT_EXTRA
+#define TX_WAIT_EXTRA 0                            // TN_DIAG timing experiments only: a non-zero value makes the stage wait too lax (wrong results)
+#elif !defined(TN_DIAG)
+#error "TX_WAIT_EXTRA is a diagnostic knob: build with -DTN_DIAG"
+#endif
 #define TX_TOP 14                              // scaled activations stay below 2^TX_TOP
 #define TX_BND_N (TN_MAXD + 1)                 // row groups whose magnitude bounds a training kernel keeps (see TX_BND_OFF)
 template <int HID, bool TRAIN_FWD = false> struct TxCfg {
@@ -124,7 +129,7 @@ __device__ __forceinline__ void tx_defer_stage(PipeX& p) {
 // issues its pieces with tx_issue_piece before the next boundary).
 template <int DPW, bool DEFER>
 __device__ __forceinline__ void tx_boundary(PipeX& p) {
-    TN16_WAIT_VM(DPW * (TX_LEAD - 1));
+    TN16_WAIT_VM(DPW * (TX_LEAD - 1) + TX_WAIT_EXTRA);
     __builtin_amdgcn_s_barrier();
     if constexpr (DEFER) tx_defer_stage(p); else tx_issue_stage<DPW>(p);
     p.cur += TX_SLOT; if (p.cur == TX_RING) p.cur = 0;

@@ -399,13 +399,22 @@ class DatasetTrainer:
             self._drop_graph()                 # lr / betas changed: the captured kernel arguments are stale
         if self._graph is None and self._calls >= 1:
             # capture (the first call ran eagerly: every kernel is loaded, every buffer exists)
-            if self.world == 1:
-                self._graph, self._args_keep = self._capture(stream, full)
-            else:
-                self._graph, keep_g = self._capture(stream, _l.PHASE_GRADIENT | _l.PHASE_REDUCE)
-                self._graph_update, keep_u = self._capture(stream, _l.PHASE_UPDATE)
-                self._args_keep = (keep_g, keep_u)
-            self._graph_key = self._hyper_key()
+            try:
+                if self.world == 1:
+                    self._graph, self._args_keep = self._capture(stream, full)
+                else:
+                    self._graph, keep_g = self._capture(stream, _l.PHASE_GRADIENT | _l.PHASE_REDUCE)
+                    self._graph_update, keep_u = self._capture(stream, _l.PHASE_UPDATE)
+                    self._args_keep = (keep_g, keep_u)
+                self._graph_key = self._hyper_key()
+            except (RuntimeError, ValueError) as e:      # a runtime that cannot capture here: the same launches, eagerly, from now on
+                import warnings
+                warnings.warn(f"DatasetTrainer: hipGraph capture failed ({e}); continuing with eager launches")
+                self._drop_graph()
+                self._want_graph = False
+                if own:
+                    torch.cuda.current_stream(st.device).wait_stream(stream)
+                return self.step()
         with torch.cuda.stream(stream):
             if self.world == 1:
                 if self._graph is not None:
