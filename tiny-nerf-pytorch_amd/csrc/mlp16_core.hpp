@@ -24,7 +24,10 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define TN16_NS 8                              // LDS ring slots (stages)
 #define TN16_SLOT (TN16_STAGE * 1024)          // bytes per stage
 #define TN16_RING (TN16_NS * TN16_SLOT)
-#define TN16_PF 4                              // A-fragment prefetch distance (ds_read -> MFMA), in fragments
+#ifndef TN16_PF
+#define TN16_PF 2                              // A-fragment prefetch distance (ds_read -> MFMA), in fragments.  4 measured the same
+                                               // speed (round 3) but cost 8 registers the 256-wide kernels do not have: they spilled
+#endif
 #ifndef TN16_LEAD
 #define TN16_LEAD 6                            // stages in flight behind the published one (LEAD + 2 <= TN16_NS)
 #endif
