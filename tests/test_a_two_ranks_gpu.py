@@ -28,4 +28,6 @@ def test_two_rank_step_graph_equals_eager_bitwise(tmp_path, prec):
     for a, b in zip(r["losses_graph"], r["losses_one_rank"]):
         assert abs(a - b) <= (1e-5 if prec == "fp32" else 2e-3) * abs(b), (a, b)
     assert r["max_dev_vs_one_rank"] <= (3 if prec == "fp32" else 6) * 5e-4 * 1.01
+    # the parity path (torch-drawn batch, FusedTrainer.step_camera) sharded the same way
+    assert r["parity_same_across_ranks"] and r["parity_max_dev_vs_one_rank"] <= (5e-5 if prec == "fp32" else 2e-3), r
 

@@ -54,7 +54,43 @@ def main():
     # ... and they follow the one-rank trainer on the whole batch (different summation order of the shards: not bitwise)
     m1, t1, l1 = run(True, ws=1)
     dev_w = max(float((a - b).abs().max()) for a, b in zip(mg.parameters(), m1.parameters()))
-    res = dict(rank=rank, world=world, precision=prec, losses_graph=lg, losses_eager=le, losses_one_rank=l1, same_losses=lg == le, same_weights=same_w,
+    # the parity path (torch-drawn pixels and jitter, FusedTrainer.step_camera): every rank draws the SAME global batch and takes its
+    # rows; the all-reduced gradient must train both ranks identically and follow a one-rank trainer on the whole batch
+    from tnerf import dist as tdist
+    N, H, W, _ = images.shape
+    pixels = images.view(N, H * W, 3)
+
+    def run_torch_rng(sharded):
+        m = nerf.TinyNeRF(cfg["in_dim"], cfg["hidden"], cfg["depth"], cfg["skip_at"]).to(dev)
+        with torch.no_grad():
+            for p, v in zip(m.parameters(), params):
+                p.copy_(v.to(dev))
+        t = T.FusedTrainer(m, T.FlatAdam(m, lr=5e-4), 2.0, 6.0, S, precision=prec)
+        gen = torch.Generator(device=dev); gen.manual_seed(77)
+        lo, hi = tdist.shard_bounds(Rg, rank, world) if sharded else (0, Rg)
+        for s_ in range(4):
+            inds = torch.randint(0, H * W, (Rg,), device=dev, generator=gen)
+            u = torch.rand(Rg, S, device=dev, generator=gen)
+            if sharded:
+                t.step_camera(poses[s_ % N], H, W, focal, inds[lo:hi], pixels[s_ % N], t_rand=u[lo:hi], global_rays=Rg)
+            else:
+                saved = tdist.all_reduce_sum_
+                tdist.all_reduce_sum_ = lambda x: x            # a one-rank reference inside a two-rank group: no exchange
+                T._dist.all_reduce_sum_ = tdist.all_reduce_sum_
+                try:
+                    t.step_camera(poses[s_ % N], H, W, focal, inds, pixels[s_ % N], t_rand=u, global_rays=Rg)
+                finally:
+                    tdist.all_reduce_sum_ = saved; T._dist.all_reduce_sum_ = saved
+        torch.cuda.synchronize()
+        return m
+    ms, m1r = run_torch_rng(True), run_torch_rng(False)
+    fl = ms.hip_state().flat.clone()
+    oth = [torch.empty_like(fl) for _ in range(world)]
+    dist.all_gather(oth, fl)
+    parity_same_ranks = all(torch.equal(o, fl) for o in oth)
+    parity_dev = max(float((a - b).abs().max()) for a, b in zip(ms.parameters(), m1r.parameters()))
+    res = dict(parity_same_across_ranks=parity_same_ranks, parity_max_dev_vs_one_rank=parity_dev,
+               rank=rank, world=world, precision=prec, losses_graph=lg, losses_eager=le, losses_one_rank=l1, same_losses=lg == le, same_weights=same_w,
                same_packed=same_pack, same_across_ranks=same_ranks, max_dev_vs_one_rank=dev_w, rays_local=tg.R,
                crc=zlib.crc32(flat.cpu().numpy().tobytes()))
     if rank == 0:
@@ -63,7 +99,7 @@ def main():
         print(json.dumps(res), flush=True)
     dist.barrier()
     dist.destroy_process_group()
-    ok = res["same_losses"] and same_w and same_pack and same_ranks
+    ok = res["same_losses"] and same_w and same_pack and same_ranks and parity_same_ranks
     sys.exit(0 if ok else 3)
 
 main()
