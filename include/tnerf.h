@@ -14,7 +14,7 @@
  *   - the CALLER owns all memory (outputs, stashes, workspaces, tables); the library never
  *     allocates or frees device memory.  Process-wide state is limited to values that are written once and never
  *     change: per-device kernel facts (CU count, granted dynamic-LDS size; atomics indexed by device) and the dlopen'ed
- *     RCCL function table (std::call_once).
+ *     RCCL / hipBLAS function tables (std::call_once each; handles and communicators are the caller's).
  *   - every device entry point is asynchronous on the given stream (hipStream_t passed as void*)
  *     and performs no host synchronisation, so it can be captured into a hipGraph.
  *   - all tensors are contiguous fp32 unless stated; index tensors are int64.
