@@ -618,6 +618,39 @@ def test_train_main_philox_resume_continues_the_same_run(mods, dev, tmp_path):
     assert torch.load(str(tmp_path / "B" / "ck" / "latest.pth"), map_location="cpu")["step"] == 6
 
 
+@pytest.mark.parametrize("case", ["zero_layer", "zero_bias", "huge_then_tiny_layer", "tiny_layer", "zero_heads"])
+def test_degenerate_weights_through_the_x3_kernels(mods, dev, case):
+    """The x3 scheme scales every operand by powers of two derived from max|W|, max|b| and per-sample L1 norms: an all-zero layer,
+    zero biases, layers of magnitude 1e6 / 1e-6 / 1e-20 and zero heads must come out like any other weights (scale records at their
+    clamps, no inf / NaN from a zero bound)."""
+    torch.manual_seed(1)
+    m = mods["nerf"].TinyNeRF(39, 128, 4, 2).to(dev)
+    with torch.no_grad():
+        m.sigma[0].bias += 0.5
+        if case == "zero_layer":
+            m.layers[2].weight.zero_()
+        if case == "zero_bias":
+            for l in m.layers:
+                l.bias.zero_()
+        if case == "huge_then_tiny_layer":
+            m.layers[1].weight.mul_(1e6); m.layers[2].weight.mul_(1e-6)
+        if case == "tiny_layer":
+            m.layers[1].weight.mul_(1e-20); m.layers[1].bias.mul_(1e-20)
+        if case == "zero_heads":
+            m.rgb[0].weight.zero_(); m.sigma[0].weight.zero_()
+    params = [p.detach().cpu().clone() for p in m.parameters()]
+    x = torch.randn(500, 39, generator=torch.Generator().manual_seed(0))
+    leaves = [p.clone().requires_grad_(True) for p in params]
+    ro, so = O.mlp_forward(leaves, x, 2)
+    go = torch.autograd.grad(ro.sum() + so.sum(), leaves)
+    r, s = m(x.to(dev))
+    (r.sum() + s.sum()).backward()
+    assert bool(torch.isfinite(r).all()) and all(bool(torch.isfinite(p.grad).all()) for p in m.parameters())
+    assert float((r.detach().cpu() - ro.detach()).abs().max()) <= 2e-6
+    assert float((s.detach().cpu() - so.detach()).abs().max()) <= 1e-5 * max(1.0, float(so.detach().abs().max()))
+    assert max(relmax(p.grad.cpu(), q) for p, q in zip(m.parameters(), go)) <= 5e-5
+
+
 # ------------------------------------------------------------------ gradients w.r.t. rays and depths (per-function ops)
 @pytest.mark.parametrize("S", [40, 150])
 def test_geometry_gradients_through_the_per_function_ops(mods, dev, S):
