@@ -529,19 +529,24 @@ __device__ __forceinline__ void tx_rescale_input(unsigned char* elds, int d) {
 // PositionalEncoding(L, include_input=True) of one point, fp32-accurate (tn_sincos, as the fp32 kernels), in the step numbering
 // of the training stash: encf[a], a = 8u + e.                                                reference src/encoding.py:27-33
 __device__ __forceinline__ void tx_encode(float px, float py, float pz, int Lf, int h, float (&encf)[8 * TN16_KE]) {
-    tn_static_for<8 * TN16_KE>([&](auto ac) TN_INLINE_LAMBDA {
-        constexpr int a = decltype(ac)::value, k = a / 3, c = a % 3;
-        const float pc = c == 0 ? px : (c == 1 ? py : pz);
-        float r = 0.0f;
-        if (a < 3 * Lf) {
-            float sn, cs;
-            tn_sincos(pc * (float)(1u << (k < 31 ? k : 0)), sn, cs);
-            r = h ? cs : sn;
-        } else if (a == 3 * Lf) {
-            r = h ? py : px;
-        } else if (a == 3 * Lf + 1) {
-            r = h ? 0.0f : pz;
+    // six arguments (two frequencies x three coordinates) per tn_sincos_n call: independent chains that fill each other's latency
+    constexpr int NK = (8 * TN16_KE + 2) / 3;                      // frequencies that can appear in the slots
+    tn_static_for<(NK + 1) / 2>([&](auto kc) TN_INLINE_LAMBDA {
+        constexpr int k0 = 2 * decltype(kc)::value;
+        if (k0 < Lf) {                                             // wave-uniform
+            const float f0 = (float)(1u << (k0 < 31 ? k0 : 0)), f1 = (float)(1u << (k0 + 1 < 31 ? k0 + 1 : 0));
+            const float x[6] = {px * f0, py * f0, pz * f0, px * f1, py * f1, pz * f1};
+            float sn[6], cs[6];
+            tn_sincos_n<6>(x, sn, cs);
+            tn_static_for<6>([&](auto ic) TN_INLINE_LAMBDA {
+                constexpr int i = decltype(ic)::value, a = 3 * k0 + i;
+                if constexpr (a < 8 * TN16_KE) encf[a] = h ? cs[i] : sn[i];
+            });
         }
-        encf[a] = r;
+    });
+    // behind the 3 Lf sin / cos slots: the input itself (x | y in the two lane halves, then z | 0), zeros after it
+    tn_static_for<8 * TN16_KE>([&](auto ac) TN_INLINE_LAMBDA {
+        constexpr int a = decltype(ac)::value;
+        if (a >= 3 * Lf) encf[a] = a == 3 * Lf ? (h ? py : px) : (a == 3 * Lf + 1 ? (h ? 0.0f : pz) : 0.0f);
     });
 }
