@@ -39,10 +39,15 @@ __device__ __forceinline__ void tx_stash_input(const FwdX3Args& a, int h, int la
     const MlpLayout& L = a.f.L;
     const int64_t ms = valid ? m : a.f.Mp + (lane & 31);           // padding lanes write to the dump block
     float* __restrict__ q = tn_stash_at(a.f.stash, L.stash_rows, ms) + (int64_t)(L.enc_row0 + h) * 32;      // row enc_row0 + 2 st + h
-    tn_static_for<8 * TN16_KE>([&](auto sc) TN_INLINE_LAMBDA {
-        constexpr int st = decltype(sc)::value;
-        if (st < L.NE) TN_STASH_STORE(&q[2 * st * 32], encf[st]);
-    });
+    // NE is 20 (in_dim <= 40) or 32 input steps: one uniform branch, then straight-line stores with immediate offsets
+    if (L.NE == 20) {
+        tn_static_for<20>([&](auto sc) TN_INLINE_LAMBDA { constexpr int st = decltype(sc)::value; TN_STASH_STORE(&q[2 * st * 32], encf[st]); });
+    } else {
+        tn_static_for<8 * TN16_KE>([&](auto sc) TN_INLINE_LAMBDA {
+            constexpr int st = decltype(sc)::value;
+            if (st < L.NE) TN_STASH_STORE(&q[2 * st * 32], encf[st]);
+        });
+    }
 }
 
 // The network for one 32-sample tile.  m: this lane's sample index in the stash (valid if `valid`).  res[4]: r,g,b after

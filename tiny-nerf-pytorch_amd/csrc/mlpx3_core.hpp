@@ -529,6 +529,9 @@ __device__ __forceinline__ void tx_rescale_input(unsigned char* elds, int d) {
 // PositionalEncoding(L, include_input=True) of one point, fp32-accurate (tn_sincos, as the fp32 kernels), in the step numbering
 // of the training stash: encf[a], a = 8u + e.                                                reference src/encoding.py:27-33
 __device__ __forceinline__ void tx_encode(float px, float py, float pz, int Lf, int h, float (&encf)[8 * TN16_KE]) {
+    // every slot is DEFINED before the conditional writes below (a slot written only under run-time conditions the compiler cannot
+    // prove exhaustive would be an undefined value on the paths it cannot rule out)
+    tn_static_for<8 * TN16_KE>([&](auto ac) TN_INLINE_LAMBDA { encf[decltype(ac)::value] = 0.0f; });
     // six arguments (two frequencies x three coordinates) per tn_sincos_n call: independent chains that fill each other's latency
     constexpr int NK = (8 * TN16_KE + 2) / 3;                      // frequencies that can appear in the slots
     tn_static_for<(NK + 1) / 2>([&](auto kc) TN_INLINE_LAMBDA {
