@@ -165,7 +165,13 @@ int tnerf_composite_bwd(const float* rgb, const float* sigma, const float* z_val
  *   tnerf_composite_bwd_geom: tnerf_composite_bwd + d_z [R,S] (dL/dz_vals) and d_rays_d [R,3] (either may be NULL)   [volume.py:18-44]
  *   tnerf_sample_bwd        : pts = o + d z  ->  dL/drays_o [R,3], dL/drays_d [R,3], dL/dz [R,S] from g_pts [R,S,3]; z_row_stride 0 =
  *                             one shared row of depths (the non-randomized table)                                   [sampling.py:27]
- *   tnerf_posenc_bwd        : dL/dx [n,3] from g_out [n, 6L(+3)]                                                    [encoding.py:27-33] */
+ *   tnerf_posenc_bwd        : dL/dx [n,3] from g_out [n, 6L(+3)]                                                    [encoding.py:27-33]
+ *   tnerf_get_rays_bwd      : dL/dc2w (16 floats; rotation block from g_rays_d, deterministic two-level sum; the translation
+ *                             column's gradient is the sum of dL/drays_o, which the stride-0 expand gives the caller for free);
+ *                             scratch of tnerf_get_rays_bwd_scratch_floats(H, W) floats (HOST query), else TNERF_ESMALL       [rays.py:21-31] */
+int64_t tnerf_get_rays_bwd_scratch_floats(int32_t H, int32_t W);
+int tnerf_get_rays_bwd(int32_t H, int32_t W, float focal, const float* c2w, const float* g_rays_d, float* scratch, int64_t scratch_floats,
+                       float* d_c2w, tnerf_stream_t stream);
 int tnerf_composite_bwd_geom(const float* rgb, const float* sigma, const float* z_vals, const float* rays_d,
                              int64_t n_rays, int32_t n_samples, int32_t white_bkgd,
                              const float* g_comp, const float* g_depth, const float* g_acc, const float* g_weights,

@@ -704,6 +704,52 @@ def test_geometry_gradients_through_the_per_function_ops(mods, dev, S):
         assert t_hip <= 2.0 * t_ref + 2e-5, (name, t_hip, t_ref)
 
 
+def test_pose_gradient_through_the_whole_per_function_pipeline(mods, dev):
+    """A learned camera pose: d(loss)/d(c2w) through get_rays -> stratified_samples -> PositionalEncoding -> TinyNeRF -> volume_render
+    (all ordinary autograd in the reference: rays.py:21-32, sampling.py:27, encoding.py:27-33, nerf.py:29-41, volume.py:18-44) against
+    the oracle's autograd with an fp64 yardstick; deterministic."""
+    cfg, params = golden_params("4x128")
+    L, skip = cfg["L"], cfg["skip_at"]
+    H, W, focal, S = 9, 11, 14.0, 40
+    g = torch.Generator().manual_seed(21)
+    q, _ = torch.linalg.qr(torch.randn(3, 3, generator=g))
+    pose0 = torch.eye(4); pose0[:3, :3] = q; pose0[:3, 3] = torch.tensor([0.3, -0.2, 4.0])
+    tgt = torch.rand(H * W, 3, generator=g)
+    u = torch.rand(H * W, S, generator=g)
+
+    def oracle(dtype):
+        ps = [p.to(dtype) for p in params]
+        pose = pose0.to(dtype).clone().requires_grad_(True)
+        ro, rd = O.pinhole_rays(H, W, focal, pose)
+        comp, depth, _, _ = O.render_rays(ps, skip, L, ro, rd, 2.0, 6.0, S, u.to(dtype))
+        loss = ((comp - tgt.to(dtype)) ** 2).mean() + 0.01 * depth.mean()
+        return torch.autograd.grad(loss, pose)[0], float(loss)
+
+    g32, l32 = oracle(torch.float32)
+    g64, _ = oracle(torch.float64)
+    model = make_model(mods, cfg, params, dev)
+    enc = mods["encoding"].PositionalEncoding(L, True).to(dev)
+
+    def hip():
+        pose = pose0.clone().to(dev).requires_grad_(True)
+        ro, rd = mods["rays"].get_rays(H, W, focal, pose)
+        z, pts, _ = mods["ops"].sample_along_rays(2.0, 6.0, S, ro.detach().contiguous(), rd.detach(), True, t_rand=u.to(dev))
+        pts = mods["ops"].attach_points_grad(ro, rd, z, pts)
+        rgb, sigma = model(enc(pts.reshape(-1, 3)))
+        comp, depth, _, _ = mods["volume"].volume_render(rgb.reshape(H * W, S, 3), sigma.reshape(H * W, S, 1), z, rd)
+        loss = ((comp - tgt.to(dev)) ** 2).mean() + 0.01 * depth.mean()
+        loss.backward()
+        return pose.grad.clone(), float(loss)
+
+    gh, lh = hip()
+    assert abs(lh - l32) <= 1e-5 * abs(l32)
+    assert float(gh[3].abs().max()) == 0.0                                  # the bottom row of the pose takes no part
+    t_hip, t_ref = relmax(gh.cpu().double()[:3], g64[:3]), relmax(g32.double()[:3], g64[:3])
+    assert t_hip <= 2.0 * t_ref + 2e-5, (t_hip, t_ref)
+    gh2, _ = hip()
+    assert torch.equal(gh, gh2)
+
+
 # ------------------------------------------------------------------------------- any hidden width up to 256
 @pytest.mark.parametrize("arch", [(39, 200, 3, 2), (63, 64, 4, 2), (39, 100, 2, 0), (27, 31, 3, 1)])
 def test_hidden_widths_other_than_128_and_256(mods, dev, arch):

@@ -33,6 +33,74 @@ extern "C" int tnerf_get_rays(int32_t H, int32_t W, float focal, const float* c2
     return TNERF_OK;
 }
 
+// get_rays backward w.r.t. the pose (a caller that learns camera poses; the reference's op is ordinary autograd, rays.py:21-31):
+//   w = R cam, d = w / |w|  ->  dL/dw = (g - d (d . g)) / |w|,  dL/dR[c][j] = sum_pixels dL/dw[c] cam[j].
+// Two deterministic levels: every workgroup writes the 9 sums of its pixels (wave sums, then LDS in a fixed order), one wave adds
+// the workgroups' rows in order.  (The translation column's gradient is the plain sum of dL/drays_o: torch's expand backward.)
+#define TN_GRB_MAX_BLOCKS 1024
+__global__ __launch_bounds__(256) void k_get_rays_bwd(int H, int W, float focal, const float* __restrict__ c2w, const float* __restrict__ g_d,
+                                                      float* __restrict__ partial) {
+    __shared__ float red[4][9];
+    float acc[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int64_t n = (int64_t)H * W;
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < n; p += (int64_t)gridDim.x * 256) {
+        const int col = (int)(p % W), row = (int)(p / W);
+        const float cam[3] = {__fdiv_rn(__fsub_rn((float)col, (float)(W * 0.5)), focal), __fdiv_rn(-__fsub_rn((float)row, (float)(H * 0.5)), focal), -1.0f};
+        float w[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) w[c] = fmaf(cam[2], c2w[4 * c + 2], fmaf(cam[1], c2w[4 * c + 1], __fmul_rn(cam[0], c2w[4 * c + 0])));
+        const float nrm = sqrtf(fmaf(w[2], w[2], fmaf(w[1], w[1], __fmul_rn(w[0], w[0]))));
+        if (!(nrm > 1e-12f)) continue;                           // F.normalize clamps: no gradient through a zero direction
+        const float inv = 1.0f / nrm;
+        const float d0 = w[0] * inv, d1 = w[1] * inv, d2 = w[2] * inv;
+        const float g0 = g_d[3 * p], g1 = g_d[3 * p + 1], g2 = g_d[3 * p + 2];
+        const float dg = d0 * g0 + d1 * g1 + d2 * g2;
+        const float gw[3] = {(g0 - d0 * dg) * inv, (g1 - d1 * dg) * inv, (g2 - d2 * dg) * inv};
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) acc[3 * c + j] += gw[c] * cam[j];
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) acc[i] = tn_wave_sum(acc[i]);
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int i = 0; i < 9; ++i) red[threadIdx.x >> 6][i] = acc[i];
+    __syncthreads();
+    if (threadIdx.x < 9) partial[blockIdx.x * 9 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+__global__ void k_get_rays_bwd_final(const float* __restrict__ partial, int n_blocks, float* __restrict__ d_c2w) {
+    const int i = threadIdx.x;                                     // 16 threads: the (4,4) gradient, row-major
+    if (i >= 16) return;
+    const int c = i >> 2, j = i & 3;
+    float s = 0.0f;
+    if (c < 3 && j < 3) for (int b = 0; b < n_blocks; ++b) s += partial[b * 9 + 3 * c + j];
+    d_c2w[i] = s;
+}
+
+// HOST.  Floats of the scratch buffer of tnerf_get_rays_bwd.
+extern "C" int64_t tnerf_get_rays_bwd_scratch_floats(int32_t H, int32_t W) {
+    if (H < 1 || W < 1) { tn_set_error("tnerf_get_rays_bwd_scratch_floats: H=%d W=%d", H, W); return TNERF_EINVAL; }
+    const int64_t nb = ((int64_t)H * W + 255) / 256;
+    return 9 * (nb < TN_GRB_MAX_BLOCKS ? nb : TN_GRB_MAX_BLOCKS);
+}
+extern "C" int tnerf_get_rays_bwd(int32_t H, int32_t W, float focal, const float* c2w, const float* g_rays_d, float* scratch,
+                                  int64_t scratch_floats, float* d_c2w, tnerf_stream_t stream) {
+    if (H < 1 || W < 1 || !c2w || !g_rays_d || !scratch || !d_c2w || !(focal != 0.0f)) {
+        tn_set_error("tnerf_get_rays_bwd: H=%d W=%d focal=%g c2w=%p g=%p scratch=%p out=%p", H, W, focal, (const void*)c2w, (const void*)g_rays_d,
+                     (void*)scratch, (void*)d_c2w);
+        return TNERF_EINVAL;
+    }
+    const int64_t need = tnerf_get_rays_bwd_scratch_floats(H, W);
+    if (scratch_floats < need) { tn_set_error("tnerf_get_rays_bwd: scratch of %lld floats, need %lld", (long long)scratch_floats, (long long)need); return TNERF_ESMALL; }
+    const int nb = (int)(need / 9);
+    hipLaunchKernelGGL(k_get_rays_bwd, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, H, W, focal, c2w, g_rays_d, scratch);
+    TN_HIP_CHECK_LAUNCH("tnerf_get_rays_bwd");
+    hipLaunchKernelGGL(k_get_rays_bwd_final, dim3(1), dim3(64), 0, (hipStream_t)stream, scratch, nb, d_c2w);
+    TN_HIP_CHECK_LAUNCH("tnerf_get_rays_bwd (final)");
+    return TNERF_OK;
+}
+
 // ---------------------------------------------------------------------------- sampling (+encode)
 // reference src/sampling.py:16-27.  One thread per sample writes z and the point.
 __global__ __launch_bounds__(256) void k_sample(const float* __restrict__ rays_o, const float* __restrict__ rays_d,

@@ -109,6 +109,8 @@ SIGNATURES = {
     "tnerf_composite_bwd_geom": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "tnerf_sample_bwd": (C.c_int, [_P, _P, _I64, _P, _I64, _I32, _P, _P, _P, _P]),
     "tnerf_posenc_bwd": (C.c_int, [_P, _I64, _I32, _I32, _P, _P, _P]),
+    "tnerf_get_rays_bwd_scratch_floats": (C.c_int64, [_I32, _I32]),
+    "tnerf_get_rays_bwd": (C.c_int, [_I32, _I32, _F, _P, _P, _P, _I64, _P, _P]),
     "tnerf_mlp_generic_acts_floats": (C.c_int64, [_DESC, _I64]),
     "tnerf_mlp_generic_scratch_floats": (C.c_int64, [_DESC, _I64]),
     "tnerf_mlp_fwd_generic": (C.c_int, [_DESC, _P, _P, _P, _I64, _P, _P, _P, _I64, _P]),

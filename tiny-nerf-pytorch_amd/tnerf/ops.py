@@ -67,11 +67,39 @@ def depth_table(near: float, far: float, n_samples: int, dev: torch.device) -> t
 
 
 # ----------------------------------------------------------------------------------- stage ops
+class _RayDirsFn(torch.autograd.Function):
+    """rays_d of get_rays as a function of the pose (a caller that learns camera poses): tnerf_get_rays / tnerf_get_rays_bwd."""
+
+    @staticmethod
+    def forward(ctx, c2w, H, W, focal):
+        dev = c2w.device
+        rays_d = torch.empty(H * W, 3, dtype=torch.float32, device=dev)
+        _l.call("tnerf_get_rays", int(H), int(W), float(focal), c2w.data_ptr(), None, rays_d.data_ptr(), _stream(dev))
+        ctx.save_for_backward(c2w)
+        ctx.cfg = (int(H), int(W), float(focal))
+        return rays_d
+
+    @staticmethod
+    def backward(ctx, g_d):
+        (c2w,) = ctx.saved_tensors
+        H, W, focal = ctx.cfg
+        dev = c2w.device
+        g_d = _f32c(g_d)
+        n = int(_l.load().tnerf_get_rays_bwd_scratch_floats(H, W))
+        scratch = torch.empty(n, dtype=torch.float32, device=dev)
+        d_c2w = torch.empty(4, 4, dtype=torch.float32, device=dev)
+        _l.call("tnerf_get_rays_bwd", H, W, focal, c2w.data_ptr(), g_d.data_ptr(), scratch.data_ptr(), n, d_c2w.data_ptr(), _stream(dev))
+        return d_c2w, None, None, None
+
+
 def get_rays(H: int, W: int, focal: float, c2w: torch.Tensor, want_origin_copy: bool = False):
     dev = _need_cuda(c2w)
-    c2w = _f32c(c2w)
     if c2w.shape != (4, 4):
         raise ValueError(f"c2w must be (4,4), got {tuple(c2w.shape)}")
+    if c2w.requires_grad and torch.is_grad_enabled():      # learned pose: directions through the kernel pair, origins through torch's expand
+        cc = c2w if (c2w.dtype == torch.float32 and c2w.is_contiguous()) else c2w.float().contiguous()
+        return cc[:3, 3].expand(H * W, 3), _RayDirsFn.apply(cc, int(H), int(W), float(focal))
+    c2w = _f32c(c2w)
     rays_d = torch.empty(H * W, 3, dtype=torch.float32, device=dev)
     rays_o = torch.empty(H * W, 3, dtype=torch.float32, device=dev) if want_origin_copy else None
     _l.call("tnerf_get_rays", int(H), int(W), float(focal), c2w.data_ptr(), _ptr(rays_o), rays_d.data_ptr(), _stream(dev))
