@@ -1,4 +1,4 @@
-"""The same training run (BASELINE cfg 2: 8x256, 4096 rays x 64, torch-generator draws) on the split-bf16 chain kernels, on the
+"""The same training run (BASELINE cfg 2: 8x256, 4096 rays x 64, torch-generator draws) on the x3 chain kernels, on the
 fp32-MFMA kernels and in bf16 mode: held-out PSNR along the way.   STEPS=8000 python tools/pipe_psnr_probe.py
 (one subprocess per pipe: TNERF_FP32_PIPE is read when a model is built)"""
 import os, subprocess, sys, time
@@ -15,7 +15,7 @@ import nerf as nerf_mod, train as train_mod
 from encoding import PositionalEncoding
 from utils import mse2psnr
 prec = sys.argv[1]
-name = prec if prec == "bf16" else ("fp32 on the fp32-MFMA kernels" if os.environ.get("TNERF_FP32_PIPE") else "fp32 on the split-bf16 kernels")
+name = prec if prec == "bf16" else ("fp32 on the fp32-MFMA kernels" if os.environ.get("TNERF_FP32_PIPE") else "fp32 on the x3 kernels (fp16, 3 products)")
 dev = torch.device("cuda:0")
 STEPS = int(os.environ.get("STEPS", "8000"))
 scene = make_synthetic_scene(seed=0)
