@@ -56,3 +56,27 @@ def test_bf16_chain_kernels_spill_budget(src):
         train_fwd_256 = "k_render16ILi256ELb1" in name
         assert r["vgpr_spill"] <= (12 if train_fwd_256 else 0), (name, r)
         assert r["scratch"] <= (52 if train_fwd_256 else 0), (name, r)
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not on PATH")
+@pytest.mark.parametrize("src", ["mlpx3.hip"])
+def test_compiler_emits_no_m0_use_of_its_own(src):
+    """The x3 chain kernels write M0 once per weight-stream stage and issue the stage's LDS-DMA pieces without touching it again
+    (mlpx3_core.hpp tx_m0_set / tx_issue_piece_m0; every other DMA saves and restores M0): valid only while hipcc itself never reads or
+    writes M0 in these kernels.  Every M0 reference in the ISA must sit inside an inline-asm block."""
+    r = subprocess.run(["hipcc", *FLAGS, "-S", "--cuda-device-only", src, "-o", "-"], cwd=CSRC, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    in_asm, n_asm, bad = False, 0, []
+    for line in r.stdout.splitlines():
+        s = line.strip()
+        if s.startswith(";;#ASMSTART"):
+            in_asm = True
+        elif s.startswith(";;#ASMEND"):
+            in_asm = False
+        elif s and not s.startswith((";", ".", "#")) and re.search(r"\bm0\b", s):
+            if in_asm:
+                n_asm += 1
+            else:
+                bad.append(s)
+    assert n_asm > 0, "no LDS-DMA found: the check looks at the wrong thing"
+    assert not bad, bad[:5]

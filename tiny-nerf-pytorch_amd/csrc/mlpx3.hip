@@ -150,6 +150,9 @@ template <int HID, bool TRAIN>
 __global__ __launch_bounds__((TxCfg<HID, TRAIN>::NW * 64), 1) void k_renderx3(FwdX3Args a) {
     constexpr int NW = TxCfg<HID, TRAIN>::NW;
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+#ifdef TN_STAMPS
+    const unsigned long long st_entry = __builtin_amdgcn_s_memrealtime();
+#endif
     const int lane = tn_lane();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int j = lane & 31, h = lane >> 5;
@@ -244,6 +247,7 @@ __global__ __launch_bounds__((TxCfg<HID, TRAIN>::NW * 64), 1) void k_renderx3(Fw
     if (a.f.stamps && lane == 0) {
         unsigned long long* o = a.f.stamps + (blockIdx.x * NW + wave) * 8;
         o[0] = __builtin_amdgcn_s_memtime() - st_c0; o[1] = __builtin_amdgcn_s_memrealtime() - st_r0; o[2] = pf.walk; o[3] = pf.epi;
+        o[4] = st_entry; o[5] = st_r0; o[6] = __builtin_amdgcn_s_memrealtime();
         if (pf.marks) pf.marks[63] = pf.n;
     }
 #endif

@@ -115,10 +115,24 @@ __device__ __forceinline__ void tx_issue_stage(PipeX& p) {
     p.src_off += TX_SLOT; if (p.src_off == p.stream_bytes) p.src_off = 0;
     p.dst_off += TX_SLOT; if (p.dst_off == TX_RING) p.dst_off = 0;
 }
+// M0 for a whole deferred stage.  hipcc emits no M0 use of its own in these kernels (tests/test_kernel_resources.py checks the
+// ISA for that), and every other DMA (tx_issue_piece, tn_glds16) saves and restores it, so M0 written at the stage boundary still
+// holds the slot's LDS base when the stage's pieces are issued behind the MFMAs: ONE instruction per piece instead of five
+// (s_mov x3, s_nop, load) — 320 fewer of the ~3500 instructions a wave issues per 256-wide layer, at one wave per SIMD.
+__device__ __forceinline__ void tx_m0_set(uint32_t lds_dst) { asm volatile("s_mov_b32 m0, %0" :: "s"(lds_dst) : "memory"); }
+template <int I>
+__device__ __forceinline__ void tx_issue_piece_m0(const unsigned char* src, uint32_t voff) {
+    static_assert(I < 4, "one M0 value per stage: pieces 0..3 (immediate offsets 0..3 KB)");
+#ifdef TX_NO_DMA
+    return;
+#endif
+    asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" :: "v"(voff), "s"(src), "n"(I * 1024) : "memory");
+}
 // ... or piece by piece behind the MFMAs of the stage that has just been published (tx_pass): back-to-back DMA instructions
 // cost the wave more issue time than the same pieces spread over as many MFMA groups.
 __device__ __forceinline__ void tx_defer_stage(PipeX& p) {
     p.pend_src = p.src + p.src_off; p.pend_dst = p.lds_dst0 + p.dst_off;
+    tx_m0_set(p.pend_dst);
     p.src_off += TX_SLOT; if (p.src_off == p.stream_bytes) p.src_off = 0;
     p.dst_off += TX_SLOT; if (p.dst_off == TX_RING) p.dst_off = 0;
 }
@@ -281,7 +295,10 @@ __device__ __forceinline__ void tx_pass(PipeX& p, const unsigned char* lds, cons
             constexpr int PPS = (DPW + span - 2) / (span - 1);
             tn_static_for<PPS>([&](auto uc) TN_INLINE_LAMBDA {
                 constexpr int i = since * PPS + decltype(uc)::value;
-                if constexpr (i < DPW && since < span - 1) tx_issue_piece<i>(p.pend_src, p.voff, p.pend_dst);
+                if constexpr (i < DPW && since < span - 1) {
+                    if constexpr (DPW <= 4) tx_issue_piece_m0<i>(p.pend_src, p.voff);
+                    else                    tx_issue_piece<i>(p.pend_src, p.voff, p.pend_dst);
+                }
             });
         }
         TX_PIN();

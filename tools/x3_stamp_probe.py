@@ -43,6 +43,12 @@ for (L, hidden, depth, skip, R, S) in ((6, 256, 8, 4, 4096, 64), (10, 128, 4, 2,
         print(f"L={L} {depth}x{hidden} R={R} S={S} train={train}: waves {len(s)}, clock {np.median(cyc / rt) * 0.1:.3f} GHz, wave lifetime {np.median(rt) / 100:.1f} us")
         print(f"   cycles/wave {np.median(cyc):.0f}: layer walks {np.median(walk):.0f} ({np.median(walk / cyc) * 100:.1f}%), epilogues {np.median(epi):.0f} ({np.median(epi / cyc) * 100:.1f}%), "
               f"rest {np.median(cyc - walk - epi):.0f};  MFMA issue floor 32 x {n_mfma:.0f} = {32 * n_mfma:.0f} ({32 * n_mfma / np.median(cyc) * 100:.1f}% of the wave, {32 * n_mfma / np.median(walk) * 100:.1f}% of the walks)")
+        t_in, t_p, t_out = s[:, 4], s[:, 5], s[:, 6]
+        if t_in.max() > 0:
+            z = t_in.min(); q = lambda a: " ".join(f"{v / 100:.1f}" for v in np.percentile(a, [0, 5, 50, 95, 100]))
+            print(f"   absolute times in us from the first wave's entry (min p5 p50 p95 max): entry {q(t_in - z)} | prologue done {q(t_p - z)} | exit {q(t_out - z)} | lifetime {q(t_out - t_in)}")
+            xcd = (np.arange(len(s)) // 4) % 8
+            print("   per XCD (workgroup % 8) median exit us: " + " ".join(f"{np.median((t_out - z)[xcd == x]) / 100:.1f}" for x in range(8)) + "; median clock GHz: " + " ".join(f"{np.median((cyc / rt)[xcd == x]) * 0.1:.3f}" for x in range(8)))
         nm = int(marks[63])
         if nm > 1:
             print("   first tile of wave 0, cycles between pass marks: " + " ".join(str(int(marks[i + 1] - marks[i])) for i in range(nm - 1)))
