@@ -63,7 +63,6 @@ __device__ __forceinline__ void tx_mlp_tile(PipeX& p, const unsigned char* lds, 
     float* __restrict__ stash = a.f.stash;
     const int64_t Mp = a.f.Mp;
     const int64_t ms = valid ? m : Mp + (lane & 31);               // padding lanes write to the dump block: stores need no branch
-    float* __restrict__ pl = TRAIN ? tn_stash_at(stash, L.stash_rows, ms) + 4 * h * 32 : nullptr;      // per-lane: (row 4h, sample ms)
     uint32_t* __restrict__ mrow = TRAIN ? reinterpret_cast<uint32_t*>(stash + TN_STASH_BODY_FLOATS(L, Mp)) + (2 * ms + h) * (NT / 2) : nullptr;
     constexpr int NH = NT / 2, KH = HID / 16, NP = NH * 8, NW = TxCfg<HID, TRAIN>::NW, G2 = KH / 2 * NH;
     ActX<HID> X;
@@ -72,13 +71,15 @@ __device__ __forceinline__ void tx_mlp_tile(PipeX& p, const unsigned char* lds, 
     TxScale sc{0.0f, 0.0f, {0.0f, 0.0f}};
     int t_prev = in.te;                                            // exponent of the scale of the pieces the running passes consume
     // per-lane stash pointers of the layer whose epilogue is running (training)
-    float* __restrict__ srow = nullptr; uint32_t* __restrict__ mword = nullptr;
+    TxDst srow{}; uint32_t* __restrict__ mword = nullptr;
+    uint32_t dst_off0 = 0;
+    if constexpr (TRAIN) { srow = tx_dst_tile(stash, L.stash_rows, m, valid, h); dst_off0 = srow.off; }
     uint32_t vbe = vb0;                                            // LDS offset of that layer's biases
     // Layer l's epilogues are about to start: its input's L1 norm is complete (the previous layer's half B epilogue ended in the
     // middle of pass A), so the bound on its outputs — and with it the scale of its pieces — is known.
     auto point_at = [&](int l) TN_INLINE_LAMBDA {
         vbe = vb0 + l * HID * 4;
-        if constexpr (TRAIN) { srow = pl + L.h_row0[l] * 32; mword = mrow + (int64_t)l * (Mp + 32) * NT; }
+        if constexpr (TRAIN) { srow.off = dst_off0 + (uint32_t)L.h_row0[l] * 128u; mword = mrow + (int64_t)l * (Mp + 32) * NT; }
         const f32x4 mt = tx_meta(lds, a.n, l);                     // {2^-s, max|W|, max|b|}
         const float l1_own = sc.l1[0] + sc.l1[1];
         float l1_in = l == 0 ? in.l1 : l1_own + tx_partner(l1_own);
@@ -316,7 +317,8 @@ __device__ __forceinline__ void tx_bwd_tile(PipeX& p, const unsigned char* lds, 
     TxEpi es;
     TxScale sc{0.0f, 0.0f, {0.0f, 0.0f}};
     TxMask<NT / 2> mk;                                             // asm load + counted wait (above)
-    float* __restrict__ zrow = nullptr;
+    TxDst zrow = tx_dst_tile(stash, L.stash_rows, m, valid, h);
+    const uint32_t dst_off0 = zrow.off;
     // The product W_l^T dZ_l (l = depth: the heads) is about to enter its epilogues: the L1 norm of dZ_l is complete.
     auto scale_for = [&](int l, float l1_in) TN_INLINE_LAMBDA {
         const f32x4 mt = tx_meta(lds, a.n, l);
@@ -344,7 +346,7 @@ __device__ __forceinline__ void tx_bwd_tile(PipeX& p, const unsigned char* lds, 
     mk.template wait<TxCfg<HID>::DPW>();                           // one boundary (DPW DMAs) was issued behind the fetch
 #pragma unroll
     for (int w = 0; w < NT / 2; ++w) mw[w] = mk.v[w];
-    zrow = pl + L.dz_row0[depth - 1] * 32;
+    zrow.off = dst_off0 + (uint32_t)L.dz_row0[depth - 1] * 128u;
     scale_for(depth, (fabsf(dzh[0]) + fabsf(dzh[1])) + (fabsf(dzh[2]) + fabsf(dzh[3])));
     tx_drain<NP, TX_NSTEP>(epiA);
     // layer l (dH_{l-1} = W_l^T dZ_l): dZ_l's half B epilogue behind the first half of pass A; the sign words of layer l-1 are
@@ -360,7 +362,7 @@ __device__ __forceinline__ void tx_bwd_tile(PipeX& p, const unsigned char* lds, 
                 mk.template wait<TxCfg<HID>::DPW * TX_LEAD>();
 #pragma unroll
                 for (int w = 0; w < NT / 2; ++w) mw[w] = mk.v[w];
-                zrow = pl + L.dz_row0[l - 1] * 32;
+                zrow.off = dst_off0 + (uint32_t)L.dz_row0[l - 1] * 128u;
                 const float l1_own = sc.l1[0] + sc.l1[1];
                 scale_for(l, l1_own + tx_partner(l1_own));
             }

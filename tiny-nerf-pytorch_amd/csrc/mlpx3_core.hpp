@@ -32,7 +32,7 @@
 #include "mlp16_core.hpp"
 
 // Ablation knobs for timing (tools/x3_stamp_probe.py): WRONG numerics, diagnostic builds only (tools/build_variant.sh passes -DTN_DIAG).
-#if (defined(TX_NO_EPI) || defined(TX_NO_FRAG) || defined(TX_NO_DMA)) && !defined(TN_DIAG)
+#if (defined(TX_NO_EPI) || defined(TX_NO_FRAG) || defined(TX_NO_DMA) || defined(TX_NO_STASH) || defined(TX_NO_SIGN)) && !defined(TN_DIAG)
 #error "TX_NO_EPI / TX_NO_FRAG / TX_NO_DMA are diagnostic knobs with wrong numerics: build with -DTN_DIAG (tools/build_variant.sh)"
 #endif
 
@@ -345,6 +345,26 @@ template <int HID, int HALF, int I> struct TxPair {
 // Per-sample scalars of the epilogue that is running: dsc = 2^-(s + t_in) turns the accumulator sum into the layer's output,
 // osc = 2^t_out scales that output into the fp16 range for the split; l1 sums |output| pairwise (the next bound).
 struct TxScale { float dsc, osc; f32x2 l1; };
+// Where a training kernel's epilogues put a tile's fp32 rows.  A wave that is alone on its SIMD pays for every store instruction
+// it issues (tools/microbench/store_issue.hip: behind three MFMAs a global_store_dword with a 64-bit VGPR address holds the wave's
+// issue for ~36 cycles, whatever the width; the buffer form — resource in SGPRs, ONE 32-bit VGPR offset — for ~14), so the 128
+// stores per layer go through a per-tile buffer resource: base = the 32-sample block of the tile's first lane, the lane's offset =
+// (its block - that block, 0 or 1) x block bytes + sample x 4 + 4 h rows, and padding lanes get an offset far behind num_records:
+// the hardware drops their stores (no dump block, no branch, no EXEC games).
+struct TxDst { __amdgpu_buffer_rsrc_t rs; uint32_t off; };
+#define TX_DST_DROP 0x80000000u                     // + any row offset stays >= num_records and does not wrap
+// m: this lane's (clamped, in-range) sample index; lane 0's is the tile's smallest.  rows: stash rows per block.
+__device__ __forceinline__ TxDst tx_dst_tile(float* stash, int64_t rows, int64_t m, bool valid, int h) {
+    const int blk = (int)(m >> 5), blk0 = __builtin_amdgcn_readfirstlane(blk);
+    const uint32_t blk_bytes = (uint32_t)rows * 128u;
+    TxDst d;
+    d.rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<unsigned char*>(stash) + (int64_t)blk0 * rows * 128, 0, (int)(2u * blk_bytes), 0x00020000);
+    d.off = valid ? (uint32_t)(blk - blk0) * blk_bytes + (uint32_t)(m & 31) * 4u + (uint32_t)h * 512u : TX_DST_DROP;
+    return d;
+}
+__device__ __forceinline__ void tx_dst_store(const TxDst& d, uint32_t row_bytes, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), d.rs, (int)(d.off + row_bytes), 0, 2);      // aux 2 = nt, as TN_STASH_STORE
+}
 struct TxEpi { f32x2 v[4], c[4], f[4]; unsigned p1[4]; f32x2 b[4]; uint32_t msk; };      // up to 4 pairs in flight
 
 // An epilogue is a chain of TX_NSTEP fine STEPS per register pair, each step one or two instructions per value that depend only
@@ -368,14 +388,21 @@ struct TxEpi { f32x2 v[4], c[4], f[4]; unsigned p1[4]; f32x2 b[4]; uint32_t msk;
 // steps 4..9 (part S).  FWD: the values are ReLU outputs (sign words are recorded, the L1 norm needs no abs).  PARKED: step 4 first
 // fetches the value part V left in the leading-product accumulator.
 template <int HID, int HALF, int I, int K, bool TRAIN, bool FWD, bool PARKED>
-__device__ __forceinline__ void tx_epi_split(const f32x16 (&acc)[TX_ACCN(HID)], ActX<HID>& X, TxEpi& e, TxScale& sc, float* __restrict__ srow, uint32_t* __restrict__ mword) {
+__device__ __forceinline__ void tx_epi_split(const f32x16 (&acc)[TX_ACCN(HID)], ActX<HID>& X, TxEpi& e, TxScale& sc, const TxDst& srow, uint32_t* __restrict__ mword) {
     using P = TxPair<HID, HALF, I>;
     constexpr int u = I % 4;
     if constexpr (K == 4) {
         if constexpr (PARKED) { e.v[u][0] = acc[P::tl][P::r0]; e.v[u][1] = acc[P::tl][P::r1]; TX_KEEP(e.v[u]); }
-        if constexpr (TRAIN) { TN_STASH_STORE(&srow[P::row0 * 32], e.v[u][0]); TN_STASH_STORE(&srow[P::row1 * 32], e.v[u][1]); }
+#ifndef TX_NO_STASH   // ablation (wrong results): what the stash stores cost
+        if constexpr (TRAIN) { tx_dst_store(srow, P::row0 * 128, e.v[u][0]); tx_dst_store(srow, P::row1 * 128, e.v[u][1]); }
+#endif
     } else if constexpr (K == 5) {
-        if constexpr (TRAIN && FWD) {                           // ReLU sign bits
+#ifndef TX_NO_SIGN    // ablation (wrong results): what the sign words cost
+        if constexpr (TRAIN && FWD)
+#else
+        if constexpr (false)
+#endif
+        {                                                       // ReLU sign bits
             if constexpr (I % 16 == 0) e.msk = 0u;
             e.msk = __builtin_amdgcn_alignbit(e.msk, __float_as_uint(e.v[u][1]) + 0x7FFFFFFFu, 31);
             e.msk = __builtin_amdgcn_alignbit(e.msk, __float_as_uint(e.v[u][0]) + 0x7FFFFFFFu, 31);
