@@ -8,6 +8,17 @@
 #include "mlpx3_core.hpp"
 #include "mlp_args.hpp"
 
+// The backward kernels are compiled WITHOUT packed fp32 VALU instructions.  A v_pk_mul / v_pk_add / v_pk_fma_f32 does not run in the
+// shadow of the wave's MFMA: behind three v_mfma_f32_32x32x16_f16 (96 cycles) two of them per MFMA make the loop 152 cycles, the four
+// plain instructions they stand for 104 (tools/microbench/pk_mfma.hip).  hipcc's post-RA peephole unpacks the ones it believes to be in a
+// shadow and leaves the rest (72 per layer in the dgrad loop); with the feature off the 8x256 dgrad kernel runs 2.7 % faster.  The
+// forward kernels keep it: there the extra instructions cost as much as the stalls (measured: +-0).
+#if defined(__HIP_DEVICE_COMPILE__)            // (hipcc's host pass of this file does not know the feature and would warn)
+#define TX_PLAIN_F32 __attribute__((target("no-packed-fp32-ops")))
+#else
+#define TX_PLAIN_F32
+#endif
+
 // Diagnostic builds (-DTN_STAMPS, tools/x3_stamp_probe.py): cycles a wave spends in the layer walks and in the epilogues, and the
 // shader clock (s_memtime / s_memrealtime).  The values go to a.f.stamps only; the product build has none of this.
 #ifdef TN_STAMPS
@@ -373,7 +384,7 @@ __device__ __forceinline__ void tx_bwd_tile(PipeX& p, const unsigned char* lds, 
 }
 
 template <int HID>
-__global__ __launch_bounds__(TxCfg<HID>::NW * 64, 1) void k_dgradx3(BwdX3Args a) {
+__global__ TX_PLAIN_F32 __launch_bounds__(TxCfg<HID>::NW * 64, 1) void k_dgradx3(BwdX3Args a) {
     constexpr int NW = TxCfg<HID>::NW;
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
     const int lane = tn_lane();
@@ -522,7 +533,7 @@ __global__ __launch_bounds__((TxCfg<HID, TRAIN>::NW * 64), 1) void k_mlpx3_fwd(F
 }
 
 template <int HID>
-__global__ __launch_bounds__(TxCfg<HID>::NW * 64, 1) void k_mlpx3_bwd(BwdX3Args a) {
+__global__ TX_PLAIN_F32 __launch_bounds__(TxCfg<HID>::NW * 64, 1) void k_mlpx3_bwd(BwdX3Args a) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
     constexpr int NW = TxCfg<HID>::NW;
     const int lane = tn_lane();

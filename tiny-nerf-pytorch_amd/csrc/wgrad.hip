@@ -453,8 +453,15 @@ __device__ __forceinline__ void wgrad_x3_body(const float* __restrict__ stash, i
 
 // 512 threads = 8 waves = TWO per SIMD (<= 8 accumulator tiles = 128 registers per wave): while one wave of a SIMD
 // waits for LDS fragments, the staging writes or the barrier, the other one keeps the matrix pipe busy.
+// Compiled without packed fp32 VALU instructions: a v_pk_mul / v_pk_add_f32 does not run in the shadow of the wave's MFMA
+// (tools/microbench/pk_mfma.hip; mlpx3.hip TX_PLAIN_F32), and the conversion steps woven between the MFMAs contained them: -3 %.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define WG_PLAIN_F32 __attribute__((target("no-packed-fp32-ops")))
+#else
+#define WG_PLAIN_F32
+#endif
 template <bool X3>
-__global__ __launch_bounds__(512, 2) void k_wgrad(const float* __restrict__ stash, int64_t stash_rows, int64_t M,
+__global__ WG_PLAIN_F32 __launch_bounds__(512, 2) void k_wgrad(const float* __restrict__ stash, int64_t stash_rows, int64_t M,
                                                   const int32_t* __restrict__ jobs, float* __restrict__ slabs, int64_t* step_inc,
                                                   const float* __restrict__ bounds) {
     __shared__ __attribute__((aligned(16))) float lds[WG_LDS_FLOATS];
