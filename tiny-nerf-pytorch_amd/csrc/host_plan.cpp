@@ -233,9 +233,13 @@ extern "C" int tnerf_param_layout(const tnerf_mlp_desc* d, int64_t* offsets, int
 }
 
 // ------------------------------------------------------------------------------- wgrad plan
+// Cycles of a workgroup of the x3 weight-gradient kernel per 32-sample block = TN_X3_TILE x (tiles per wave) + TN_X3_FIXED, fitted to the
+// per-workgroup stamps of the WHOLE kernel running (tools/wgrad_x3_probe.py on a -DTN_STAMPS build, 4096 x 64 samples, 8x256): 4750 /
+// 2740 / 2394 cycles per block for 8 / 2 / 1 tiles per wave.  (Round 3's first fit, 650 / 2500, was taken class by class and gave the
+// bandwidth-hungry input / skip / head classes too few workgroups: they ran 15 % longer than the 256 x 256 classes.)
 #ifndef TN_X3_TILE
-#define TN_X3_TILE 650.0
-#define TN_X3_FIXED 2500.0
+#define TN_X3_TILE 335.0
+#define TN_X3_FIXED 2070.0
 #endif
 namespace {
 struct JobClass {

@@ -157,7 +157,9 @@ int  tn_check_stash16(const char* who, const tnerf_mlp_desc* d, int64_t n_rays, 
 // every hidden layer: for layer l, sample m, lane-half h: hidden/64 uint32 words
 //   word index ((l*(Mp+32) + m)*2 + h) * (hidden/64) + t/2,  bit (t&1)*16 + r   <->  feature 32t + TN_ACC_ROW(r,h)
 // One extra ("dump") block / sample slot follows the Mp real ones: lanes that pad a ragged tile store there, so
-// that no store in the hot loops needs a per-lane branch.
+// that no store in the hot loops needs a per-lane branch.  (The x3 chain kernels' H / dZ rows do not use it: their stores go
+// through a per-tile buffer resource whose range check drops padding lanes — mlpx3_core.hpp TxDst; sign words, input rows and
+// head rows still do.)
 #define TN_RAY_WS_FLOATS 4                               // floats per ray of the train steps' workspace (tnerf_train_ws_floats)
 #define TN_STASH_BODY_FLOATS(L, Mp) ((int64_t)(L).stash_rows * ((Mp) + 32))
 #define TN_MASK_FLOATS(L, Mp) ((int64_t)(L).depth * ((Mp) + 32) * ((L).hidden / 32))

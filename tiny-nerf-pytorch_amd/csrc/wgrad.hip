@@ -453,15 +453,11 @@ __device__ __forceinline__ void wgrad_x3_body(const float* __restrict__ stash, i
 
 // 512 threads = 8 waves = TWO per SIMD (<= 8 accumulator tiles = 128 registers per wave): while one wave of a SIMD
 // waits for LDS fragments, the staging writes or the barrier, the other one keeps the matrix pipe busy.
-// Compiled without packed fp32 VALU instructions: a v_pk_mul / v_pk_add_f32 does not run in the shadow of the wave's MFMA
-// (tools/microbench/pk_mfma.hip; mlpx3.hip TX_PLAIN_F32), and the conversion steps woven between the MFMAs contained them: -3 %.
-#if defined(__HIP_DEVICE_COMPILE__)
-#define WG_PLAIN_F32 __attribute__((target("no-packed-fp32-ops")))
-#else
-#define WG_PLAIN_F32
-#endif
+// (Packed fp32 VALU stays ON here, unlike in the backward chain kernels (mlpx3.hip TX_PLAIN_F32): with two waves per SIMD a packed
+// instruction that cannot overlap its own wave's MFMA overlaps the other wave's.  A/B in the bench's step, three runs each: 0.886-0.890 ms
+// packed against 0.909-0.915 ms unpacked — although a probe on synthetic operands had said the opposite by 2 %.)
 template <bool X3>
-__global__ WG_PLAIN_F32 __launch_bounds__(512, 2) void k_wgrad(const float* __restrict__ stash, int64_t stash_rows, int64_t M,
+__global__ __launch_bounds__(512, 2) void k_wgrad(const float* __restrict__ stash, int64_t stash_rows, int64_t M,
                                                   const int32_t* __restrict__ jobs, float* __restrict__ slabs, int64_t* step_inc,
                                                   const float* __restrict__ bounds) {
     __shared__ __attribute__((aligned(16))) float lds[WG_LDS_FLOATS];
@@ -485,8 +481,7 @@ __global__ WG_PLAIN_F32 __launch_bounds__(512, 2) void k_wgrad(const float* __re
     if (threadIdx.x == 0) {
         const unsigned long long dt = __builtin_amdgcn_s_memtime() - t_start;
         int32_t* rec = const_cast<int32_t*>(jobs) + (int64_t)blockIdx.x * TN_JOB_INTS;
-        rec[14] = (int32_t)(dt & 0xffffffffu); rec[15] = (int32_t)(dt >> 32);
-        rec[12] = (int32_t)(t_start & 0xffffffffu); rec[13] = (int32_t)(t_start >> 32);
+        rec[14] = (int32_t)(dt & 0xffffffffu); rec[15] = (int32_t)(dt >> 32);      // (slots 12, 13 are JOB_A_BOUND / JOB_B_BOUND: not ours)
     }
 #endif
 }

@@ -41,10 +41,8 @@ for name, flags in (("x3", 0), ("fp32-mfma", lib.FLAG_FP32_MFMA)):
     print(f"{name:10s} {ms:.3f} ms")
     jobs = plan.jobs.cpu().numpy().reshape(-1, 16)
     dt = (jobs[:, 14].astype(np.int64) & 0xffffffff) | (jobs[:, 15].astype(np.int64) << 32)
-    t0 = (jobs[:, 12].astype(np.int64) & 0xffffffff) | (jobs[:, 13].astype(np.int64) << 32)
     if dt.max() > 0:
-        span = (t0 + dt).max() - t0.min()
-        print(f"   kernel span {span} ticks of s_memtime over {ms:.3f} ms -> {span / ms / 1e6:.3f} GHz tick rate; first/last workgroup start {t0.min() - t0.min()} / {t0.max() - t0.min()}")
+        print(f"   longest workgroup {dt.max()} cycles, median {np.median(dt):.0f}")
         for c in sorted(set(jobs[:, 10])):
             m = jobs[:, 10] == c
             print(f"   class {c}: {m.sum():3d} WGs, tiles {jobs[m][0][4]}x{jobs[m][0][5]} blocks/WG {jobs[m][:,8].min()}-{jobs[m][:,8].max()}  cycles median {np.median(dt[m]):.0f} max {dt[m].max()}  per block {np.median(dt[m] / jobs[m][:,8]):.0f}")
