@@ -305,7 +305,11 @@ static int build_classes(const MlpLayout& L, int64_t M, int n_cu, std::vector<Jo
             // cycles per 32-sample block, measured (tools/wgrad_probe.py, LDS-DMA staging): 17.86k / 5.2k / 3.2k for
             // 8 / 2 / 1 tiles per wave, i.e. ~2107 per tile (16 MFMA steps of 64 cycles, two waves per SIMD) + ~1000 fixed
             // The split-bf16 kernel (default pipe): ~TN_X3_TILE per tile + TN_X3_FIXED (tools/wgrad_x3_probe.py, -DTN_STAMPS build)
+            // Jobs of <= 256 combined rows run the kernel's two-item converter (wgrad.hip NI = 2) and cost by the bytes they stream:
+            // 2345 / 1754 / 1582 cycles per block for 256 / 192 / 160 rows (4x128 network, the same stamps) = ~9.2 per row.
+            const int rows = (cls[i].n_at + cls[i].n_bt) * 32;
             const double per_block = (L.flags & TNERF_FLAG_FP32_MFMA) ? (double)cls[i].cost * 2107.0 + 1000.0
+                                   : rows <= 256                     ? 9.2 * (double)rows
                                                                       : (double)cls[i].cost * TN_X3_TILE + TN_X3_FIXED;
             const double t = per_block * (double)((MB + cls[i].chunks - 1) / cls[i].chunks);
             if (t > best_t) { best_t = t; best = (int)i; }

@@ -217,7 +217,10 @@ __device__ __forceinline__ float wx_exp2i(int e) { return __uint_as_float((uint3
 
 // PD = register sets of the fetch pipeline = stages between a fetch and its use: 2 for the 256 x 256 blocks (an iteration is
 // > 1.5k cycles of MFMA), 4 for the small, bandwidth-hungry input / head classes whose iterations are a few hundred cycles.
-template <int TA, int TB, int PD>
+// NI = converter items per thread = ceil(job rows / 128): 4 covers the 512 combined rows of a 256 x 256 job; jobs of <= 256 combined
+// rows (every class of a 128-wide network) run NI = 2 — with 4, half of their fetches and conversions worked on clamped duplicate rows
+// that nobody reads, and their stages are conversion-bound (6 MFMAs against ~90 VALU per wave).
+template <int TA, int TB, int PD, int NI>
 __device__ __forceinline__ void wgrad_x3_body(const float* __restrict__ stash, int64_t stash_rows, int64_t M, const int32_t* __restrict__ job,
                                               float* __restrict__ slabs, float* lds_f, const float* __restrict__ bounds) {
     static_assert(PD % 2 == 0, "the image parity must follow the unrolled stage index");
@@ -245,9 +248,10 @@ __device__ __forceinline__ void wgrad_x3_body(const float* __restrict__ stash, i
     // Rows that do not exist (head: 4 of 32, input: 40 of 64) are clamped to a real row: they only feed slab rows / columns
     // that the reduce table never references.
     const int chunk = tid & 3;
-    int goff[4]; bool isA[4]; int crow[4]; float gsc[4];
+    static_assert(NI % TB == 0 && NI <= 4, "items are dealt to the B-tile groups");
+    int goff[NI]; bool isA[NI]; int crow[NI]; float gsc[NI];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < NI; ++k) {
         crow[k] = (tid >> 2) + 128 * k;
         isA[k] = crow[k] < rows_a;
         const int lr = isA[k] ? crow[k] : crow[k] - rows_a;
@@ -256,10 +260,12 @@ __device__ __forceinline__ void wgrad_x3_body(const float* __restrict__ stash, i
         goff[k] = srow_ * 128 + chunk * 16;
         gsc[k] = wx_exp2i(isA[k] ? ea : eb);
     }
-    float bs[4] = {0.f, 0.f, 0.f, 0.f};
+    float bs[NI];
+#pragma unroll
+    for (int k = 0; k < NI; ++k) bs[k] = 0.f;
     const int nst = 2 * nblk;                                   // stages of 16 samples
     const int64_t blk_bytes = stash_rows * 128;
-    f32x4 raw[PD][4];
+    f32x4 raw[PD][NI];
     // The hot loop must be ONE basic block (a branch ends the scheduling region: the conversion would no longer be placed in the
     // MFMAs' shadow): dead items (combined rows past the job's) are converted like live ones into image rows nobody reads, the
     // bias sums are formed for every item and only A rows are stored at the end, and the stages that need care — the batch's
@@ -336,7 +342,7 @@ __device__ __forceinline__ void wgrad_x3_body(const float* __restrict__ stash, i
         // Group j: the 3 TA MFMAs of B tile j, with the conversion of items j (4/TB) .. of stage s+1 cut into three steps, one
         // behind every TA MFMAs; the order is pinned (left alone, the scheduler emits the MFMAs back to back and the whole
         // conversion after them, in the shadow of the last one only).
-        constexpr int IPG = 4 / TB;                                  // items per group
+        constexpr int IPG = NI / TB;                                 // items per group
         f16x8_t b1, b2;
         if constexpr (ACTIVE) {
             b1 = *reinterpret_cast<const f16x8_t*>(img + ob[0]);
@@ -391,10 +397,10 @@ __device__ __forceinline__ void wgrad_x3_body(const float* __restrict__ stash, i
     tn_static_for<PD>([&](auto pc) TN_INLINE_LAMBDA {
         constexpr int p_ = decltype(pc)::value;
         using PC = std::integral_constant<int, p_>;
-        tn_static_for<4>([&](auto kc) TN_INLINE_LAMBDA { if (p_ < nst) fetch1(p_, PC{}, kc); });
+        tn_static_for<NI>([&](auto kc) TN_INLINE_LAMBDA { if (p_ < nst) fetch1(p_, PC{}, kc); });
     });
     using C0 = std::integral_constant<int, 0>;
-    tn_static_for<4>([&](auto kc) TN_INLINE_LAMBDA {
+    tn_static_for<NI>([&](auto kc) TN_INLINE_LAMBDA {
         if (nst > 0) convert1(0, C0{}, kc, T_{});
         if (PD < nst) fetch1(PD, C0{}, kc);
     });
@@ -443,7 +449,7 @@ __device__ __forceinline__ void wgrad_x3_body(const float* __restrict__ stash, i
     }
     if (has_bias) {                                              // row sums of A: the 4 lanes of a row hold its 4 chunks
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < NI; ++k) {
             float t = bs[k];
             t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64);
             if (chunk == 0 && isA[k]) slab[(int64_t)n_at * 32 * ld + crow[k]] = t;          // (isA implies the row exists in the slab)
@@ -470,11 +476,15 @@ __global__ __launch_bounds__(512, 2) void k_wgrad(const float* __restrict__ stas
     const int32_t* job = jobs + (int64_t)blockIdx.x * TN_JOB_INTS;
     const int n_at = job[JOB_N_AT], n_bt = job[JOB_N_BT], WA = job[JOB_WA], WB = 8 / WA;
     const int ta = (n_at + WA - 1) / WA, tb = (n_bt + WB - 1) / WB;     // the host plan only emits full-or-idle waves
+    const bool small = (n_at + n_bt) * 32 <= 256;                      // combined rows of the job (uniform): two converter items per thread cover them
     switch (ta * 8 + tb) {
-        case 2 * 8 + 4: if (X3) wgrad_x3_body<2, 4, 2>(stash, stash_rows, M, job, slabs, lds, bounds); else wgrad_body<2, 4>(stash, stash_rows, M, job, slabs, lds); break;
-        case 1 * 8 + 2: if (X3) wgrad_x3_body<1, 2, 4>(stash, stash_rows, M, job, slabs, lds, bounds); else wgrad_body<1, 2>(stash, stash_rows, M, job, slabs, lds); break;
-        case 2 * 8 + 1: if (X3) wgrad_x3_body<2, 1, 4>(stash, stash_rows, M, job, slabs, lds, bounds); else wgrad_body<2, 1>(stash, stash_rows, M, job, slabs, lds); break;
-        case 1 * 8 + 1: if (X3) wgrad_x3_body<1, 1, 4>(stash, stash_rows, M, job, slabs, lds, bounds); else wgrad_body<1, 1>(stash, stash_rows, M, job, slabs, lds); break;
+        case 2 * 8 + 4: if (X3) wgrad_x3_body<2, 4, 2, 4>(stash, stash_rows, M, job, slabs, lds, bounds); else wgrad_body<2, 4>(stash, stash_rows, M, job, slabs, lds); break;
+        case 1 * 8 + 2: if (X3) { if (small) wgrad_x3_body<1, 2, 4, 2>(stash, stash_rows, M, job, slabs, lds, bounds); else wgrad_x3_body<1, 2, 4, 4>(stash, stash_rows, M, job, slabs, lds, bounds); }
+                        else wgrad_body<1, 2>(stash, stash_rows, M, job, slabs, lds); break;
+        case 2 * 8 + 1: if (X3) { if (small) wgrad_x3_body<2, 1, 4, 2>(stash, stash_rows, M, job, slabs, lds, bounds); else wgrad_x3_body<2, 1, 4, 4>(stash, stash_rows, M, job, slabs, lds, bounds); }
+                        else wgrad_body<2, 1>(stash, stash_rows, M, job, slabs, lds); break;
+        case 1 * 8 + 1: if (X3) { if (small) wgrad_x3_body<1, 1, 4, 2>(stash, stash_rows, M, job, slabs, lds, bounds); else wgrad_x3_body<1, 1, 4, 4>(stash, stash_rows, M, job, slabs, lds, bounds); }
+                        else wgrad_body<1, 1>(stash, stash_rows, M, job, slabs, lds); break;
         default: break;   // unreachable: shapes are validated on the host (tnerf_plan_fill)
     }
 #ifdef TN_STAMPS
