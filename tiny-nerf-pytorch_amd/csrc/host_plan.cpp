@@ -603,7 +603,9 @@ int build_classes16(const Net16& n, int64_t tiles, int n_cu, std::vector<Job16Cl
         int best = -1; double best_t = 0.0;
         for (size_t i = 0; i < cls.size(); ++i) {
             if (cls[i].chunks >= tiles) continue;
-            const double t = ((double)(cls[i].n_at + cls[i].n_bt) * 2048.0 + 4096.0) * (double)((tiles + cls[i].chunks - 1) / cls[i].chunks);
+            // fitted to per-workgroup stamps of the whole kernel (tools/bf16_time_probe.py on a -DTN_STAMPS build, 8x256, 4096 x 64): 2700 /
+            // 1664 / 1637 cycles per sample tile for the 8x8 / 8x2 / 1x8 classes = the bytes, plus a little for the one-tile-row head class
+            const double t = ((double)(cls[i].n_at + cls[i].n_bt) * 2048.0 + (cls[i].n_at < 2 ? 1400.0 : 0.0)) * (double)((tiles + cls[i].chunks - 1) / cls[i].chunks);
             if (t > best_t) { best_t = t; best = (int)i; }
         }
         if (best < 0) break;

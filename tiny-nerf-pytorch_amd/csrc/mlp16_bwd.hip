@@ -310,6 +310,9 @@ __global__ __launch_bounds__(512, 2) void k_wgrad16(Wgrad16Args a) {
     const int n_at = job[JOB_N_AT], n_bt = job[JOB_N_BT], WA = job[JOB_WA];
     const int ta = (n_at + WA - 1) / WA, tb = (n_bt + 8 / WA - 1) / (8 / WA);
     if (job[JOB_MBLKN] <= 0) return;
+#ifdef TN_STAMPS   // diagnostic build: per-workgroup duration into the unused tail of the job record (tools/bf16_time_probe.py)
+    const unsigned long long t_start = __builtin_amdgcn_s_memtime();
+#endif
     // PER = DMA pieces per wave and sample tile = ceil(2 (n_at + n_bt) / 8)
     const int nf = 2 * (n_at + n_bt);
     if (ta == 2 && tb == 4)      tn16w_body<2, 4, 4>(a, job, lds, lane, wave);      // 8 x 8 tiles: 32 fragments per sample tile
@@ -318,6 +321,13 @@ __global__ __launch_bounds__(512, 2) void k_wgrad16(Wgrad16Args a) {
     else if (ta == 2 && tb == 1) tn16w_body<2, 1, 4>(a, job, lds, lane, wave);
     else { if (nf <= 16)         tn16w_body<1, 1, 2>(a, job, lds, lane, wave);      // 4 x 2 input / 1 x 4 heads of 128-wide nets: 12 / 10
            else                  tn16w_body<1, 1, 3>(a, job, lds, lane, wave); }    // heads 1 x 8: 18
+#ifdef TN_STAMPS
+    if (threadIdx.x == 0) {
+        const unsigned long long dt = __builtin_amdgcn_s_memtime() - t_start;
+        int32_t* rec = const_cast<int32_t*>(a.jobs) + (int64_t)blockIdx.x * TN_JOB_INTS;
+        rec[14] = (int32_t)(dt & 0xffffffffu); rec[15] = (int32_t)(dt >> 32);
+    }
+#endif
 }
 
 int tn16_launch_wgrad(const Net16& n, const unsigned char* stash, const int32_t* jobs, int64_t n_jobs, float* slabs, int64_t* step_inc, hipStream_t stream) {

@@ -42,3 +42,14 @@ for name, fn in calls.items():
     e1.record(); torch.cuda.synchronize()
     out.append(f"{name} {e0.elapsed_time(e1) / 20:.4f}")
 print(os.environ.get("TNERF_LIB", "default"), " | ".join(out), "ms", flush=True)
+
+# per-workgroup stamps of k_wgrad16 (a -DTN_STAMPS build of mlp16_bwd.hip): is the job split balanced?
+import numpy as np
+calls["wgrad"](); torch.cuda.synchronize()
+jobs = bp.jobs.cpu().numpy().reshape(-1, 16)
+dt = (jobs[:, 14].astype(np.int64) & 0xffffffff) | (jobs[:, 15].astype(np.int64) << 32)
+if dt.max() > 0:
+    print(f"   k_wgrad16: longest workgroup {dt.max()} cycles, median {np.median(dt):.0f}")
+    for c in sorted(set(jobs[:, 10])):
+        m = jobs[:, 10] == c
+        print(f"   class {c}: {m.sum():3d} WGs, tiles {jobs[m][0][4]}x{jobs[m][0][5]} sample tiles/WG {jobs[m][:,8].min()}-{jobs[m][:,8].max()}  cycles median {np.median(dt[m]):.0f} max {dt[m].max()}  per tile {np.median(dt[m] / jobs[m][:,8]):.0f}")
