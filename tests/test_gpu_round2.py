@@ -831,10 +831,12 @@ def test_hidden_widths_other_than_128_and_256(mods, dev, arch):
 # ------------------------------------------------- the split-bf16 chain kernels against the fp32-MFMA ones, region by region
 @pytest.mark.parametrize("tag,R,S", [("4x128", 101, 72), ("8x256", 64, 32), ("8x256", 37, 100)])
 def test_x3_chain_kernels_fill_the_stash_like_the_fp32_mfma_kernels(mods, dev, tag, R, S):
-    """tnerf_train_fwd_fused_x3 / tnerf_train_dgrad_fused_x3 (fp32 products formed exactly on the bf16 matrix pipe,
-    half-pass walk, epilogues in the MFMA shadows) write the SAME training stash as the round-1 fp32-MFMA kernels — encoder
-    rows bit-identical, activations / head outputs / every dZ to fp32 rounding, ReLU sign words identical except where an
-    activation is within rounding of zero — for ragged ray counts (R % 4 != 0) and sample counts (S % 32 != 0, two segments)."""
+    """tnerf_train_fwd_fused_x3 / tnerf_train_dgrad_fused_x3 (fp32 products from three fp16 partial products, half-pass walk,
+    epilogues in the MFMA shadows) leave the SAME values in the training stash as the fp32-MFMA kernels — encoder rows
+    bit-identical, activations / head outputs / every dZ to fp32 rounding, ReLU sign bits identical except where an activation
+    is within rounding of zero — for ragged ray counts (R % 4 != 0) and sample counts (S % 32 != 0, two segments).  The x3 pipe
+    keeps its own arrangement of those values (sign words with the bit order reversed: mlpx3_core.hpp TxPair), which the helpers
+    below undo; each dgrad kernel runs on its own pipe's forward stash."""
     ops, lib = mods["ops"], mods["lib"]
     cfg, params = golden_params(tag)
     m = make_model(mods, cfg, params, dev)
@@ -873,13 +875,21 @@ def test_x3_chain_kernels_fill_the_stash_like_the_fp32_mfma_kernels(mods, dev, t
         r0 += H
     assert float((A[:, r0:r0 + 4] - B[:, r0:r0 + 4]).abs().max()) <= 4e-6 * max(1.0, float(A[:, r0:r0 + 4].abs().max()))
     body = rows * (Mp + 32)
-    mA, mB = sA[body:].view(torch.int32).cpu(), sB[body:].view(torch.int32).cpu()
+    def bitrev32(w):                                                # x3 sign words: bit 31 - i <-> the fp32 kernels' bit i
+        w = w.to(torch.int64) & 0xffffffff
+        r = torch.zeros_like(w)
+        for i in range(32):
+            r |= ((w >> i) & 1) << (31 - i)
+        return torch.where(r >= 2 ** 31, r - 2 ** 32, r).to(torch.int32)
+    mA, mB = sA[body:].view(torch.int32).cpu(), bitrev32(sB[body:].view(torch.int32).cpu())
     for l in range(depth):
         a = mA[l * (Mp + 32) * NT: l * (Mp + 32) * NT + M * NT]; b = mB[l * (Mp + 32) * NT: l * (Mp + 32) * NT + M * NT]
         flips = sum(bin(int(v) & 0xffffffff).count("1") for v in (a ^ b)[(a ^ b) != 0])
         assert flips <= 1e-5 * M * H + 2, (l, flips)               # an activation within rounding of 0 may land on either side
-    # dgrad: both kernels on the SAME forward stash
+    # dgrad: both kernels on the SAME forward results — the fp32-MFMA forward's stash, re-arranged for the x3 kernel
     sC = sA.clone()
+    n_mask = depth * (Mp + 32) * NT                                 # the sign words (the bound words behind them stay as they are)
+    sC[body:body + n_mask].view(torch.int32).copy_(bitrev32(sA[body:body + n_mask].view(torch.int32).cpu()).to(dev))
     lib.call("tnerf_train_dgrad_fused", C.byref(st.desc), st.packed.data_ptr(), *common, gc.data_ptr(), sA.data_ptr(), plan.Mp, sp)
     lib.call("tnerf_train_dgrad_fused_x3", C.byref(st.desc), x3.packed.data_ptr(), *common, gc.data_ptr(), sC.data_ptr(), plan.Mp, sp)
     torch.cuda.synchronize()

@@ -79,7 +79,7 @@ __device__ __forceinline__ void tx_mlp_tile(PipeX& p, const unsigned char* lds, 
     ActX<HID> X;
     f32x16 accA[TX_ACCN(HID)], accB[TX_ACCN(HID)];
     TxEpi es;
-    TxScale sc{0.0f, 0.0f, {0.0f, 0.0f}};
+    TxScale sc{0.0f, 0.0f, {0.0f, 0.0f}, tx_konst()};
     int t_prev = in.te;                                            // exponent of the scale of the pieces the running passes consume
     // per-lane stash pointers of the layer whose epilogue is running (training)
     TxDst srow{}; uint32_t* __restrict__ mword = nullptr;
@@ -99,27 +99,26 @@ __device__ __forceinline__ void tx_mlp_tile(PipeX& p, const unsigned char* lds, 
         if (l + 1 == skip_at) bound = fmaxf(bound, in.encmax);     // the skip layer's input pieces share this layer's output scale
         const int t_out = tx_scale_exp(bound);
         if constexpr (TRAIN) tx_bound_note(lds_bnd, TNB_H(l), bound);          // this layer's rows of the stash, for the weight-gradient kernel
-        sc.dsc = mt[0] * tx_exp2i(-t_prev); sc.osc = tx_exp2i(t_out); sc.l1 = f32x2{0.0f, 0.0f};
+        const float dsc = mt[0] * tx_exp2i(-t_prev);
+        sc.dsc = TRAIN ? -dsc : dsc;                               // training: negated pre-activations against the negated bias table (tx_epi_fwd_value)
+        sc.osc = tx_exp2i(t_out); sc.l1 = f32x2{0.0f, 0.0f};
         t_prev = t_out;
     };
     if constexpr (TRAIN) tx_bound_note(lds_bnd, TNB_ENC, in.encmax);
-    // steps 0..3 = part V, 4..9 = part S    (mlpx3_core.hpp)
+    // steps 0..3 = part V, 4..8 = part S    (mlpx3_core.hpp)
     auto epi_full = [&](auto halfc, auto& acc, auto ic, auto kc) TN_INLINE_LAMBDA {
         constexpr int HALF = decltype(halfc)::value, I = decltype(ic)::value, K = decltype(kc)::value;
-        if constexpr (K < TX_VSTEPS) tx_epi_fwd_value<HID, HALF, I, K, false>(acc, es, sc, lds, vbe);
-        else tx_epi_split<HID, HALF, I, K, TRAIN, true, false>(acc, X, es, sc, srow, mword);
+        if constexpr (K < TX_VSTEPS) tx_epi_fwd_value<HID, HALF, I, K, TRAIN>(acc, es, sc, lds, vbe, mword);
+        else tx_epi_split<HID, HALF, I, K, TRAIN, true>(X, es, sc, srow);
     };
     auto epiA = [&](auto ic, auto kc) TN_INLINE_LAMBDA { epi_full(std::integral_constant<int, 0>{}, accA, ic, kc); };
     auto epiB = [&](auto ic, auto kc) TN_INLINE_LAMBDA { epi_full(std::integral_constant<int, 1>{}, accB, ic, kc); };
-    // half A of a hidden layer: part V parked in the first half of pass B, part S from the parked values in the second half
-    auto epiA_value = [&](auto ic, auto kc) TN_INLINE_LAMBDA { tx_epi_fwd_value<HID, 0, decltype(ic)::value, decltype(kc)::value, true>(accA, es, sc, lds, vbe); };
-    auto epiA_split = [&](auto ic, auto kc) TN_INLINE_LAMBDA { tx_epi_split<HID, 0, decltype(ic)::value, decltype(kc)::value, TRAIN, true, true>(accA, X, es, sc, srow, mword); };
-    // 256-wide: one pair per group, the chain pipelined over the gaps (SPS 1); 128-wide: two pairs per group, chains inside the group
-    constexpr int SPF = HID == 256 ? 1 : 4, SPV = HID == 256 ? 1 : 4, SPS_ = HID == 256 ? 1 : 2;
-    // groups of pass A over which half B's epilogue is spread: its pieces are read from the middle of the pass on, tile by tile, so
-    // the window may reach past the middle as long as every pair stays ahead of its first reader (tx_spread_ok)
-    constexpr int GB = HID == 256 ? TX_GB256 : G2;
-    static_assert(HID != 256 || tx_spread_ok<HID, GB>(), "half B's epilogue window overruns the first read of its pieces");
+    // 256-wide: one pair per group at most, the chain pipelined over the gaps (SPS 1) and spread over (almost) the whole pass;
+    // 128-wide: two pairs per group, chains inside the group
+    constexpr int SPF = HID == 256 ? 1 : 4;
+    constexpr int GB = HID == 256 ? TX_GB256 : G2, GA = HID == 256 ? TX_GA256 : G2;
+    static_assert(tx_half_b_ok<HID, GB, SPF>(), "half B's epilogue window overruns the first read of its pieces");
+    static_assert(tx_half_a_ok<HID, TX_WA, GA, SPF>(), "half A's epilogue window writes an activation slot pass B still reads, or overruns the pass");
     auto none = [](auto) TN_INLINE_LAMBDA {};
     TX_PROF_BEGIN(pf);
     TX_PROF_MARK(pf);
@@ -129,22 +128,31 @@ __device__ __forceinline__ void tx_mlp_tile(PipeX& p, const unsigned char* lds, 
     TX_PROF_MARK(pf);
     tx_pass<HID, 0, true, NW>(p, lds, X, E, accB, tx_window<0, TN16_KE * NH, NP, 0, TX_NSTEP, 4>(epiA));
     TX_PROF_MARK(pf);
-    // layer l: half B's epilogue of layer l-1 behind the first half of pass A, half A's of layer l behind the second half of pass B
+    // layer l: half B's epilogue of layer l-1 behind pass A (its pieces are read from the middle of the pass on), half A's of layer l
+    // behind pass B (its pieces replace the input k-steps pass B has just read)
     for (int l = 1; l < depth; ++l) {
         if (l == skip_at) tx_rescale_input(E, t_prev - in.te);     // the skip layer consumes the input at its own input's scale
+#ifdef TX_SERIAL_EPI   // diagnostic (wrong results): the passes bare, the epilogues behind them with nothing to hide in — marks: pass A | epilogue B | pass B | epilogue A
+        tx_pass<HID, 1, true, NW>(p, lds, X, E, accA, none);
+        if (l == skip_at) tx_pass<HID, 0, false, NW>(p, lds, X, E, accA, none);
+        TX_PROF_MARK(pf);
+        tx_drain<NP, TX_NSTEP>(epiB);
+        TX_PROF_MARK(pf);
+        point_at(l);
+        tx_pass<HID, 1, true, NW>(p, lds, X, E, accB, none);
+        if (l == skip_at) tx_pass<HID, 0, false, NW>(p, lds, X, E, accB, none);
+        TX_PROF_MARK(pf);
+        tx_drain<NP, TX_NSTEP>(epiA);
+        TX_PROF_MARK(pf);
+#else
         tx_pass<HID, 1, true, NW>(p, lds, X, E, accA, tx_window<0, GB, NP, 0, TX_NSTEP, SPF>(epiB));
         if (l == skip_at) tx_pass<HID, 0, false, NW>(p, lds, X, E, accA, none);                    // + W_l[:, hidden:] . encoding
         TX_PROF_MARK(pf);
         point_at(l);
-        {
-            // part S starts one group before the middle: its last pair's last step then ends with the pass, and no pair writes an
-            // activation slot before pass B has read it (slot xs of pair i is read until group 4 xs + 3, written in group >= G2 + i)
-            auto w1 = tx_window<0, G2, NP, 0, TX_VSTEPS, SPV>(epiA_value);
-            auto w2 = tx_window<(G2 - (HID == 256 ? 1 : 0)) * TX_SPG, G2, NP, TX_VSTEPS, TX_NSTEP, SPS_>(epiA_split);
-            tx_pass<HID, 1, true, NW>(p, lds, X, E, accB, [&](auto sc_) TN_INLINE_LAMBDA { w1(sc_); w2(sc_); });
-        }
+        tx_pass<HID, 1, true, NW>(p, lds, X, E, accB, tx_window<TX_WA, GA, NP, 0, TX_NSTEP, SPF>(epiA));
         if (l == skip_at) tx_pass<HID, 0, false, NW>(p, lds, X, E, accB, none);
         TX_PROF_MARK(pf);
+#endif
     }
     // heads (tile slot 0 of accA): the last layer's half B epilogue must be through before k-step KH/2
     tx_pass<HID, 3, true, NW>(p, lds, X, E, accA, tx_window<0, KH / 2, NP, 0, TX_NSTEP, 4>(epiB));
@@ -159,7 +167,7 @@ __device__ __forceinline__ void tx_mlp_tile(PipeX& p, const unsigned char* lds, 
 }
 
 template <int HID, bool TRAIN>
-__global__ __launch_bounds__((TxCfg<HID, TRAIN>::NW * 64), 1) void k_renderx3(FwdX3Args a) {
+__global__ TX_PLAIN_F32 __launch_bounds__((TxCfg<HID, TRAIN>::NW * 64), 1) void k_renderx3(FwdX3Args a) {
     constexpr int NW = TxCfg<HID, TRAIN>::NW;
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
 #ifdef TN_STAMPS
@@ -174,7 +182,7 @@ __global__ __launch_bounds__((TxCfg<HID, TRAIN>::NW * 64), 1) void k_renderx3(Fw
     PipeX p;
     unsigned char* lds_bnd0 = lds + TX_BND_OFF(a.n, NW, true);
     unsigned char* lds_bnd = lds_bnd0 + lane * 4;                  // this lane's bound words (forward: TNB_H(l) = l, TNB_ENC)
-    tx_prologue<NW>(p, lds, a.packed3, a.n, a.packed3, a.n.n_stage, lane, wave, TRAIN ? lds_bnd0 : nullptr);
+    tx_prologue<NW, TRAIN>(p, lds, a.packed3, a.n, a.packed3, a.n.n_stage, lane, wave, TRAIN ? lds_bnd0 : nullptr);
     unsigned char* E = lds + TX_RING + TX_CONST_BYTES(a.n) + wave * TX_ELDS_WAVE + lane * 16;      // this lane's input pieces
     TxProf pf;
 #ifdef TN_STAMPS
@@ -326,7 +334,7 @@ __device__ __forceinline__ void tx_bwd_tile(PipeX& p, const unsigned char* lds, 
     f32x16 accA[TX_ACCN(HID)], accB[TX_ACCN(HID)];
     uint32_t mw[NT / 2];
     TxEpi es;
-    TxScale sc{0.0f, 0.0f, {0.0f, 0.0f}};
+    TxScale sc{0.0f, 0.0f, {0.0f, 0.0f}, tx_konst()};
     TxMask<NT / 2> mk;                                             // asm load + counted wait (above)
     TxDst zrow = tx_dst_tile(stash, L.stash_rows, m, valid, h);
     const uint32_t dst_off0 = zrow.off;
@@ -338,19 +346,18 @@ __device__ __forceinline__ void tx_bwd_tile(PipeX& p, const unsigned char* lds, 
         sc.dsc = mt[0] * tx_exp2i(-t_prev); sc.osc = tx_exp2i(t_out); sc.l1 = f32x2{0.0f, 0.0f};
         t_prev = t_out;
     };
-    // steps 0..3 = part V, 4..9 = part S    (mlpx3_core.hpp)
+    // steps 0..3 = part V, 4..8 = part S    (mlpx3_core.hpp)
     auto epi_full = [&](auto halfc, auto& acc, auto ic, auto kc) TN_INLINE_LAMBDA {
         constexpr int HALF = decltype(halfc)::value, I = decltype(ic)::value, K = decltype(kc)::value;
-        if constexpr (K < TX_VSTEPS) tx_epi_bwd_value<HID, HALF, I, K, false>(acc, es, sc, mw);
-        else tx_epi_split<HID, HALF, I, K, true, false, false>(acc, X, es, sc, zrow, nullptr);
+        if constexpr (K < TX_VSTEPS) tx_epi_bwd_value<HID, HALF, I, K>(acc, es, sc, mw);
+        else tx_epi_split<HID, HALF, I, K, true, false>(X, es, sc, zrow);
     };
     auto epiA = [&](auto ic, auto kc) TN_INLINE_LAMBDA { epi_full(std::integral_constant<int, 0>{}, accA, ic, kc); };
     auto epiB = [&](auto ic, auto kc) TN_INLINE_LAMBDA { epi_full(std::integral_constant<int, 1>{}, accB, ic, kc); };
-    auto epiA_value = [&](auto ic, auto kc) TN_INLINE_LAMBDA { tx_epi_bwd_value<HID, 0, decltype(ic)::value, decltype(kc)::value, true>(accA, es, sc, mw); };
-    auto epiA_split = [&](auto ic, auto kc) TN_INLINE_LAMBDA { tx_epi_split<HID, 0, decltype(ic)::value, decltype(kc)::value, true, false, true>(accA, X, es, sc, zrow, nullptr); };
-    constexpr int SPF = HID == 256 ? 1 : 4, SPV = HID == 256 ? 1 : 4, SPS_ = HID == 256 ? 1 : 2;
-    constexpr int GB = HID == 256 ? TX_GB256 : G2;                 // see tx_mlp_tile
-    static_assert(HID != 256 || tx_spread_ok<HID, GB>(), "half B's epilogue window overruns the first read of its pieces");
+    constexpr int SPF = HID == 256 ? 1 : 4;
+    constexpr int GB = HID == 256 ? TX_GB256 : G2, GA = HID == 256 ? TX_GA256 : G2;      // see tx_mlp_tile
+    static_assert(tx_half_b_ok<HID, GB, SPF>(), "half B's epilogue window overruns the first read of its pieces");
+    static_assert(tx_half_a_ok<HID, TX_WA, GA, SPF>(), "half A's epilogue window writes an activation slot pass B still reads, or overruns the pass");
     // dH_{depth-1} = W_head^T dZ_head: both halves; half A's epilogue has nothing to hide behind
     mk.fetch(mrow + (int64_t)(depth - 1) * (Mp + 32) * NT);
     tx_pass_headsT<HID, NW>(p, lds, Z, accA, accB);
@@ -360,14 +367,12 @@ __device__ __forceinline__ void tx_bwd_tile(PipeX& p, const unsigned char* lds, 
     zrow.off = dst_off0 + (uint32_t)L.dz_row0[depth - 1] * 128u;
     scale_for(depth, (fabsf(dzh[0]) + fabsf(dzh[1])) + (fabsf(dzh[2]) + fabsf(dzh[3])));
     tx_drain<NP, TX_NSTEP>(epiA);
-    // layer l (dH_{l-1} = W_l^T dZ_l): dZ_l's half B epilogue behind the first half of pass A; the sign words of layer l-1 are
-    // fetched before pass A and waited for (>= TX_LEAD boundaries later) at the start of pass B, where dZ_{l-1}'s half A epilogue
-    // begins: part V (mask) in the first half of pass B, part S in the second
+    // layer l (dH_{l-1} = W_l^T dZ_l): dZ_l's half B epilogue behind pass A; the sign words of layer l-1 are fetched before pass A
+    // and waited for (>= TX_LEAD boundaries later) at the start of pass B, where dZ_{l-1}'s half A epilogue begins
     for (int l = depth - 1; l >= 1; --l) {
         mk.fetch(mrow + (int64_t)(l - 1) * (Mp + 32) * NT);
         tx_pass<HID, 1, true, NW>(p, lds, X, nullptr, accA, tx_window<0, GB, NP, 0, TX_NSTEP, SPF>(epiB));
-        auto w1 = tx_window<0, G2, NP, 0, TX_VSTEPS, SPV>(epiA_value);
-        auto w2 = tx_window<(G2 - (HID == 256 ? 1 : 0)) * TX_SPG, G2, NP, TX_VSTEPS, TX_NSTEP, SPS_>(epiA_split);
+        auto wa = tx_window<TX_WA, GA, NP, 0, TX_NSTEP, SPF>(epiA);
         tx_pass<HID, 1, true, NW>(p, lds, X, nullptr, accB, [&](auto sc_) TN_INLINE_LAMBDA {
             if constexpr (decltype(sc_)::value == 0) {
                 mk.template wait<TxCfg<HID>::DPW * TX_LEAD>();
@@ -377,7 +382,7 @@ __device__ __forceinline__ void tx_bwd_tile(PipeX& p, const unsigned char* lds, 
                 const float l1_own = sc.l1[0] + sc.l1[1];
                 scale_for(l, l1_own + tx_partner(l1_own));
             }
-            w1(sc_); w2(sc_);
+            wa(sc_);
         });
     }
     tx_drain<NP, 5>(epiB);                                         // dZ_0, half B: to the stash only (steps 0 .. 4)
@@ -486,7 +491,7 @@ __device__ __forceinline__ void tx_load_input(const float* __restrict__ xrow, bo
 }
 
 template <int HID, bool TRAIN>
-__global__ __launch_bounds__((TxCfg<HID, TRAIN>::NW * 64), 1) void k_mlpx3_fwd(FwdX3Args a) {
+__global__ TX_PLAIN_F32 __launch_bounds__((TxCfg<HID, TRAIN>::NW * 64), 1) void k_mlpx3_fwd(FwdX3Args a) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
     constexpr int NW = TxCfg<HID, TRAIN>::NW;
     const int lane = tn_lane();
@@ -495,7 +500,7 @@ __global__ __launch_bounds__((TxCfg<HID, TRAIN>::NW * 64), 1) void k_mlpx3_fwd(F
     PipeX p;
     unsigned char* lds_bnd0 = lds + TX_BND_OFF(a.n, NW, true);
     unsigned char* lds_bnd = lds_bnd0 + lane * 4;                  // this lane's bound words (forward: TNB_H(l) = l, TNB_ENC)
-    tx_prologue<NW>(p, lds, a.packed3, a.n, a.packed3, a.n.n_stage, lane, wave, TRAIN ? lds_bnd0 : nullptr);
+    tx_prologue<NW, TRAIN>(p, lds, a.packed3, a.n, a.packed3, a.n.n_stage, lane, wave, TRAIN ? lds_bnd0 : nullptr);
     unsigned char* E = lds + TX_RING + TX_CONST_BYTES(a.n) + wave * TX_ELDS_WAVE + lane * 16;
     TxProf pf;
     const int64_t M = a.f.M, n_tiles = (M + 31) / 32, n_groups = (n_tiles + NW - 1) / NW;
@@ -519,12 +524,16 @@ __global__ __launch_bounds__((TxCfg<HID, TRAIN>::NW * 64), 1) void k_mlpx3_fwd(F
         tx_store_input(E, Er);
         float res[4];
         tx_mlp_tile<HID, TRAIN>(p, lds, a, h, lane, E, in, mc, valid, res, pf, lds_bnd);
-        if (valid && h == 0) {
-            a.f.rgb_out[3 * m + 0] = res[0]; a.f.rgb_out[3 * m + 1] = res[1]; a.f.rgb_out[3 * m + 2] = res[2];
-            a.f.sigma_out[m] = res[3];
+        // the sample index is formed again behind the tile (from a lane id the compiler cannot match with the one above): kept alive
+        // across the layer walk, the 64-bit index was what spilled to scratch in the 256-wide training kernel
+        int lane2 = lane; asm volatile("" : "+v"(lane2));
+        const int64_t m2 = (g * NW + wave) * 32 + (lane2 & 31);
+        if (m2 < M && (lane2 >> 5) == 0) {
+            a.f.rgb_out[3 * m2 + 0] = res[0]; a.f.rgb_out[3 * m2 + 1] = res[1]; a.f.rgb_out[3 * m2 + 2] = res[2];
+            a.f.sigma_out[m2] = res[3];
             if (TRAIN) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) tn_stash_at(a.f.stash, a.f.L.stash_rows, m)[(a.f.L.out_row0 + i) * 32] = res[i];
+                for (int i = 0; i < 4; ++i) tn_stash_at(a.f.stash, a.f.L.stash_rows, m2)[(a.f.L.out_row0 + i) * 32] = res[i];
             }
         }
     }

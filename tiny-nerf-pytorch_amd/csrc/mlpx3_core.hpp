@@ -32,7 +32,7 @@
 #include "mlp16_core.hpp"
 
 // Ablation knobs for timing (tools/x3_stamp_probe.py): WRONG numerics, diagnostic builds only (tools/build_variant.sh passes -DTN_DIAG).
-#if (defined(TX_NO_EPI) || defined(TX_NO_FRAG) || defined(TX_NO_DMA) || defined(TX_NO_STASH) || defined(TX_NO_SIGN)) && !defined(TN_DIAG)
+#if (defined(TX_NO_EPI) || defined(TX_NO_FRAG) || defined(TX_NO_DMA) || defined(TX_NO_STASH) || defined(TX_NO_SIGN) || defined(TX_SERIAL_EPI) || defined(TX_NO_BARRIER)) && !defined(TN_DIAG)
 #error "TX_NO_EPI / TX_NO_FRAG / TX_NO_DMA are diagnostic knobs with wrong numerics: build with -DTN_DIAG (tools/build_variant.sh)"
 #endif
 
@@ -144,14 +144,17 @@ __device__ __forceinline__ void tx_defer_stage(PipeX& p) {
 template <int DPW, bool DEFER>
 __device__ __forceinline__ void tx_boundary(PipeX& p) {
     TN16_WAIT_VM(DPW * (TX_LEAD - 1) + TX_WAIT_EXTRA);
+#ifndef TX_NO_BARRIER    // diagnostic (races): what the stage barriers cost
     __builtin_amdgcn_s_barrier();
+#endif
     if constexpr (DEFER) tx_defer_stage(p); else tx_issue_stage<DPW>(p);
     p.cur += TX_SLOT; if (p.cur == TX_RING) p.cur = 0;
 }
 
 // Workgroup prologue: biases + scale records -> LDS, LEAD stages in flight, the first one landed; the first tx_boundary
 // publishes stage 0.  `src` / `n_stage`: the stream this kernel walks (forward: packed, n.n_stage; dgrad: the backward stream).
-template <int NW>
+// NEGB (training forward): the hidden layers' biases are stored as nb = 0 - b (b = +-0 -> +0), see tx_epi_fwd_value.
+template <int NW, bool NEGB = false>
 __device__ __forceinline__ void tx_prologue(PipeX& p, unsigned char* lds, const unsigned char* packed, const NetX3& n,
                                             const unsigned char* src, int n_stage, int lane, int wave, unsigned char* lds_bnd = nullptr) {
     constexpr int DPW = TX_STAGE / NW;
@@ -159,7 +162,8 @@ __device__ __forceinline__ void tx_prologue(PipeX& p, unsigned char* lds, const 
         float* bl = reinterpret_cast<float*>(lds + TX_RING);
         const float* bg = reinterpret_cast<const float*>(packed + n.bias_off);
         const int nf = n.n_bias + (n.depth + 1) * TX_META;            // the scale records follow the biases
-        for (int i = threadIdx.x; i < nf; i += NW * 64) bl[i] = bg[i];
+        const int nneg = NEGB ? n.depth * n.hidden : 0;
+        for (int i = threadIdx.x; i < nf; i += NW * 64) bl[i] = i < nneg ? 0.0f - bg[i] : bg[i];
     }
     if (lds_bnd) {                                                   // the bound words start at zero
         for (int i = threadIdx.x; i < TX_BND_N * 64; i += NW * 64) reinterpret_cast<unsigned*>(lds_bnd)[i] = 0u;
@@ -330,21 +334,36 @@ __device__ __forceinline__ void tx_pass_headsT(PipeX& p, const unsigned char* ld
     });
 }
 
-// ---- epilogues as micro-steps.  A half has NP = NH*8 register PAIRS (values 2pr, 2pr+1 of a tile); pair i of the order
-// below is tile 2(i/16) + 1 - (i%16)/8 of the half, pair 7 - i%8: the sign words of the training stash are built by shifting
-// (alignbit), i.e. bit 31 first = the odd tile of the word, register 15 downwards.
+// ---- epilogues as micro-steps.  A half has NP = NH*8 register PAIRS (values 2pr, 2pr+1 of a tile), walked in ASCENDING order of
+// the activation k-step they land in: pair I = tile slot I / 8, register pair I % 8 -> k-step xs = 2 t + pr / 4.  That order is what
+// lets an epilogue ride on (almost) a whole pass: half A's pieces overwrite X[xs] right behind pass B's last read of it, half B's
+// pieces are ready right before the next pass A's first read — no parking of values, no second window (round 3 walked the pairs
+// in the order its sign-word shifts dictated and had to park half A's values in AGPRs: two extra moves per value).
+// Sign words of the x3 stash (written here, read by the x3 dgrad epilogue only): the bit of register r of tile t is bit
+// 31 - ((t & 1) * 16 + r) of word t / 2 — the first value shifted in ends up at the top.
 template <int HID, int HALF, int I> struct TxPair {
     static constexpr int NH = HID / 64;
-    static constexpr int tl = 2 * (I / 16) + (1 - (I % 16) / 8);      // accumulator slot in the half
+    static constexpr int tl = I / 8;                                  // accumulator slot in the half
     static constexpr int t = HALF * NH + tl;                          // n-tile
-    static constexpr int pr = 7 - I % 8;
+    static constexpr int pr = I % 8;
     static constexpr int r0 = 2 * pr, r1 = 2 * pr + 1;
     static constexpr int xs = 2 * t + pr / 4, xq = pr % 4;            // activation k-step and dword the pair lands in
     static constexpr int row0 = 32 * t + (r0 & 3) + 8 * (r0 >> 2), row1 = 32 * t + (r1 & 3) + 8 * (r1 >> 2);   // feature rows (+ 4h) of the stash
+    static constexpr int bit0 = 31 - ((t & 1) * 16 + r0), bit1 = 31 - ((t & 1) * 16 + r1);                     // sign-word bits
 };
-// Per-sample scalars of the epilogue that is running: dsc = 2^-(s + t_in) turns the accumulator sum into the layer's output,
-// osc = 2^t_out scales that output into the fp16 range for the split; l1 sums |output| pairwise (the next bound).
-struct TxScale { float dsc, osc; f32x2 l1; };
+// Per-sample scalars of the epilogue that is running: dsc = 2^-(s + t_in) turns the accumulator sum into the layer's output
+// (NEGATIVE in the training forward, see tx_epi_fwd_value), osc = 2^t_out scales that output into the fp16 range for the split;
+// l1 sums |output| pairwise (the next bound); kk = one dword the compiler cannot see through (tx_konst): as fp32 the largest
+// finite multiple of ... (0x7f7fbc00 = 3.39e38, the ReLU's upper clamp), its low half the fp16 value -1.0 (the split's multiplier).
+struct TxScale { float dsc, osc; f32x2 l1; float kk; };
+// x - (float)half in ONE instruction: v_fma_mix_f32 (f16 * f16 + f32 -> f32) runs in an MFMA's shadow like a plain v_fma_f32
+// (tools/microbench/epi_mix.hip), where round 3's v_cvt_f32_f16 + packed subtract cost three to four times as much.  hipcc selects
+// it for fma(fpext(a), fpext(b), c) — but only if b is not a visible constant (it folds * -1 into a subtraction first) and only
+// in functions compiled without packed fp32 (TX_PLAIN_F32: otherwise the SLP vectoriser forms v_pk_fma_f32 first).
+__device__ __forceinline__ float tx_konst() { float k = __uint_as_float(0x7f7fbc00u); asm volatile("" : "+s"(k)); return k; }      // (an SGPR: wave-uniform, and the kernels have no VGPR to spare)
+__device__ __forceinline__ float tx_sub_half(float x, _Float16 hv, float kk) {
+    return __builtin_fmaf((float)hv, (float)__builtin_bit_cast(f16x2, kk)[0], x);
+}
 // Where a training kernel's epilogues put a tile's fp32 rows.  A wave that is alone on its SIMD pays for every store instruction
 // it issues (tools/microbench/store_issue.hip: behind three MFMAs a global_store_dword with a 64-bit VGPR address holds the wave's
 // issue for ~36 cycles, whatever the width; the buffer form — resource in SGPRs, ONE 32-bit VGPR offset — for ~14), so the 128
@@ -365,71 +384,74 @@ __device__ __forceinline__ TxDst tx_dst_tile(float* stash, int64_t rows, int64_t
 __device__ __forceinline__ void tx_dst_store(const TxDst& d, uint32_t row_bytes, float v) {
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), d.rs, (int)(d.off + row_bytes), 0, 2);      // aux 2 = nt, as TN_STASH_STORE
 }
-struct TxEpi { f32x2 v[4], c[4], f[4]; unsigned p1[4]; f32x2 b[4]; uint32_t msk; };      // up to 4 pairs in flight
+struct TxEpi { f32x2 v[4], c[4]; unsigned p1[4]; f32x2 b[4]; uint32_t msk; };      // up to 4 pairs in flight
 
 // An epilogue is a chain of TX_NSTEP fine STEPS per register pair, each step one or two instructions per value that depend only
 // on the step before.  With one wave per SIMD a dependent instruction cannot issue until its predecessor has left the pipeline
 // (~8 cycles), and the wave issues in order — so an epilogue whose chain runs within one MFMA gap stretches the gap to 50
 // cycles (measured: stamps per pass, PMC issue-stall counters).  The steps are therefore SOFTWARE-PIPELINED over the MFMA
-// gaps: pair i runs step k behind MFMA number W0 + 3 i + k, so that a gap carries steps of three different pairs — mutually
+// gaps: pair i runs step k behind MFMA number W0 + 3 start(i) + k, so that a gap carries steps of three different pairs — mutually
 // independent instructions — and a pair's next step is a whole gap away.
-// The chain is also cut in two PARTS so that it can straddle the point where its activation registers become free:
-//   part V (steps 0..3): accumulators -> the layer's fp32 output (descale, bias + ReLU / sign-bit mask).  Half A's part V runs in
-//           the first half of pass B and parks the values in the leading-product accumulators themselves;
-//   part S (steps 4..9): value -> [stash, sign bits] L1 norm, scale, two fp16 pieces into the activation registers.  For half A in
-//           the second half of pass B (the slots it overwrites are dead there), from the parked values; for half B both parts run
-//           back to back in the first half of the next layer's pass A.
-#define TX_NSTEP 10
+//   steps 0..3 (part V): accumulators -> the layer's fp32 output (leading + correction, descale, bias + ReLU / sign-bit mask)
+//   steps 4..8 (part S): [stash] L1 norm, scale, first pieces, residuals (v_fma_mix_f32), second pieces into the activation registers
+// What an instruction costs a lone wave behind its MFMAs (tools/microbench/epi_mix.hip, pk_mfma.hip): about three plain VALU
+// instructions per MFMA are free, every further one ~3.4 cycles; v_accvgpr_read ~2x, v_cvt_pk_f16_f32 ~2x, v_fma_mixlo/hi_f16 ~2.5x,
+// packed fp32 ~3x (does not overlap the MFMA at all).  The chain below is the cheapest found: 19 instructions per pair (inference).
+#define TX_NSTEP 9
 #ifndef TX_GB256
-#define TX_GB256 44                              // 256-wide: groups over which half B's epilogue is spread in the next pass A (32 = its first half)
+#define TX_GB256 56                              // 256-wide: groups of the next pass A over which half B's epilogue is spread
 #endif
+#ifndef TX_GA256
+#define TX_GA256 58                              // 256-wide: groups of pass B over which half A's epilogue is spread (from group TX_WA / 3 on)
+#endif
+#define TX_WA 6                                  // first slot of half A's window in pass B: X[0] has been read by then
 #define TX_VSTEPS 4
 
-// steps 4..9 (part S).  FWD: the values are ReLU outputs (sign words are recorded, the L1 norm needs no abs).  PARKED: step 4 first
-// fetches the value part V left in the leading-product accumulator.
-template <int HID, int HALF, int I, int K, bool TRAIN, bool FWD, bool PARKED>
-__device__ __forceinline__ void tx_epi_split(const f32x16 (&acc)[TX_ACCN(HID)], ActX<HID>& X, TxEpi& e, TxScale& sc, const TxDst& srow, uint32_t* __restrict__ mword) {
+// steps 4..8 (part S).  FWD: the values are ReLU outputs (the L1 norm needs no abs).
+template <int HID, int HALF, int I, int K, bool TRAIN, bool FWD>
+__device__ __forceinline__ void tx_epi_split(ActX<HID>& X, TxEpi& e, TxScale& sc, const TxDst& srow) {
     using P = TxPair<HID, HALF, I>;
     constexpr int u = I % 4;
     if constexpr (K == 4) {
-        if constexpr (PARKED) { e.v[u][0] = acc[P::tl][P::r0]; e.v[u][1] = acc[P::tl][P::r1]; TX_KEEP(e.v[u]); }
 #ifndef TX_NO_STASH   // ablation (wrong results): what the stash stores cost
         if constexpr (TRAIN) { tx_dst_store(srow, P::row0 * 128, e.v[u][0]); tx_dst_store(srow, P::row1 * 128, e.v[u][1]); }
 #endif
-    } else if constexpr (K == 5) {
-#ifndef TX_NO_SIGN    // ablation (wrong results): what the sign words cost
-        if constexpr (TRAIN && FWD)
-#else
-        if constexpr (false)
-#endif
-        {                                                       // ReLU sign bits
-            if constexpr (I % 16 == 0) e.msk = 0u;
-            e.msk = __builtin_amdgcn_alignbit(e.msk, __float_as_uint(e.v[u][1]) + 0x7FFFFFFFu, 31);
-            e.msk = __builtin_amdgcn_alignbit(e.msk, __float_as_uint(e.v[u][0]) + 0x7FFFFFFFu, 31);
-            if constexpr (I % 16 == 15) mword[P::t / 2] = e.msk;
-        }
-        if constexpr (FWD) sc.l1 += e.v[u];
+        if constexpr (FWD) { sc.l1[0] += e.v[u][0]; sc.l1[1] += e.v[u][1]; }
         else { sc.l1[0] += fabsf(e.v[u][0]); sc.l1[1] += fabsf(e.v[u][1]); }
-        e.v[u] *= sc.osc;
-        TX_KEEP(e.v[u]); TX_KEEP(sc.l1);
+        TX_KEEP(sc.l1);
+    } else if constexpr (K == 5) {
+        e.v[u][0] *= sc.osc; e.v[u][1] *= sc.osc; TX_KEEP(e.v[u]);                 // (the unscaled value is dead: stored and summed in step 4)
     } else if constexpr (K == 6) {
         e.p1[u] = tx_cvt2(e.v[u][0], e.v[u][1]); TX_KEEP(e.p1[u]);
     } else if constexpr (K == 7) {
-        e.f[u][0] = tx_lo2f(e.p1[u]); e.f[u][1] = tx_hi2f(e.p1[u]); TX_KEEP(e.f[u]);
+        const f16x2 hp = __builtin_bit_cast(f16x2, e.p1[u]);
+        e.v[u][0] = tx_sub_half(e.v[u][0], hp[0], sc.kk); e.v[u][1] = tx_sub_half(e.v[u][1], hp[1], sc.kk); TX_KEEP(e.v[u]);
     } else if constexpr (K == 8) {
-        e.v[u] -= e.f[u]; TX_KEEP(e.v[u]);
-    } else if constexpr (K == 9) {
         unsigned q2 = tx_cvt2(e.v[u][0], e.v[u][1]);
+#ifdef TX_X_AGPR     // experiment (measured: no gain, 9.3 k / 8.05 k cycles per pass against 9.0 k / 8.1 k): the activation pieces written to AGPRs,
+        // which the MFMA reads as its B operand directly — instead of the allocator's own parking of pieces in AGPRs with reloads
+        unsigned o1, o2;
+        asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(o1) : "v"(e.p1[u]));
+        asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(o2) : "v"(q2));
+        X.p1[P::xs][P::xq] = o1;
+        X.p2[P::xs][P::xq] = o2;
+#else
         TX_KEEP(q2);
         X.p1[P::xs][P::xq] = e.p1[u];
         X.p2[P::xs][P::xq] = q2;
+#endif
     }
 }
 
 // Forward part V (steps 0..3): leading + correction, descale + bias (fp32, LDS byte offset vb + 16 h: this layer's biases for rows
-// 4h..), ReLU.  PARK: step 3 puts the value back into the leading-product accumulator (half A).
-template <int HID, int HALF, int I, int K, bool PARK>
-__device__ __forceinline__ void tx_epi_fwd_value(f32x16 (&acc)[TX_ACCN(HID)], TxEpi& e, const TxScale& sc, const unsigned char* lds, uint32_t vb) {
+// 4h..), ReLU.  TRAIN: the ReLU sign bits ride on a NEGATED pre-activation: the LDS table holds nb = 0 - b (so that b = +-0 gives
+// +0) and dsc is negative, nz = fma(acc, dsc, nb) = -z; then bit 31 of nz IS "z > 0" (z = +-0 gives nz = +0: not set, as
+// torch's relu'(0) = 0), one v_alignbit per value shifts it into the sign word, and ReLU is med3(-nz, 0, 3.39e38) — source modifier,
+// ONE instruction: fmaxf behind TX_KEEP needs a canonicalising v_max first, and med3 against a visible inf is folded into exactly
+// that fmaxf; the clamp is the opaque constant of TxScale (an activation of 3.4e38 has overflowed every product downstream anyway).  (Round 3: v_add_u32 0x7fffffff + v_alignbit on the ReLU output.)
+template <int HID, int HALF, int I, int K, bool TRAIN>
+__device__ __forceinline__ void tx_epi_fwd_value(const f32x16 (&acc)[TX_ACCN(HID)], TxEpi& e, const TxScale& sc, const unsigned char* lds, uint32_t vb,
+                                                 uint32_t* __restrict__ mword) {
     using P = TxPair<HID, HALF, I>;
     constexpr int u = I % 4;
     if constexpr (K == 0) {
@@ -438,20 +460,30 @@ __device__ __forceinline__ void tx_epi_fwd_value(f32x16 (&acc)[TX_ACCN(HID)], Tx
         e.c[u][0] = acc[P::tl + P::NH][P::r0]; e.c[u][1] = acc[P::tl + P::NH][P::r1];
         TX_KEEP(e.v[u]); TX_KEEP(e.c[u]);
     } else if constexpr (K == 1) {
-        e.v[u] += e.c[u]; TX_KEEP(e.v[u]);
+        e.v[u][0] += e.c[u][0]; e.v[u][1] += e.c[u][1]; TX_KEEP(e.v[u]);
     } else if constexpr (K == 2) {
-        e.v[u][0] = __builtin_fmaf(e.v[u][0], sc.dsc, e.b[u][0]); e.v[u][1] = __builtin_fmaf(e.v[u][1], sc.dsc, e.b[u][1]); TX_KEEP(e.v[u]);
+        e.c[u][0] = __builtin_fmaf(e.v[u][0], sc.dsc, e.b[u][0]); e.c[u][1] = __builtin_fmaf(e.v[u][1], sc.dsc, e.b[u][1]); TX_KEEP(e.c[u]);
     } else if constexpr (K == 3) {
-        // ReLU as a signed-integer max: negative floats (and -0) are negative integers.  (fmaxf on a value that has just passed
-        // through an asm needs a canonicalising v_max in front of it.)
-        e.v[u][0] = __int_as_float(max(__float_as_int(e.v[u][0]), 0)); e.v[u][1] = __int_as_float(max(__float_as_int(e.v[u][1]), 0)); TX_KEEP(e.v[u]);
-        if constexpr (PARK) { acc[P::tl][P::r0] = e.v[u][0]; acc[P::tl][P::r1] = e.v[u][1]; }
+        if constexpr (TRAIN) {
+#ifndef TX_NO_SIGN    // ablation (wrong results): what the sign words cost
+            if constexpr (I % 16 == 0) e.msk = 0u;
+            e.msk = __builtin_amdgcn_alignbit(e.msk, __float_as_uint(e.c[u][0]), 31);
+            e.msk = __builtin_amdgcn_alignbit(e.msk, __float_as_uint(e.c[u][1]), 31);
+            if constexpr (I % 16 == 15) mword[P::t / 2] = e.msk;
+#endif
+            e.v[u][0] = __builtin_amdgcn_fmed3f(-e.c[u][0], 0.0f, sc.kk);
+            e.v[u][1] = __builtin_amdgcn_fmed3f(-e.c[u][1], 0.0f, sc.kk);
+        } else {
+            // ReLU as a signed-integer max: negative floats (and -0) are negative integers.
+            e.v[u][0] = __int_as_float(max(__float_as_int(e.c[u][0]), 0)); e.v[u][1] = __int_as_float(max(__float_as_int(e.c[u][1]), 0));
+        }
+        TX_KEEP(e.v[u]);
     }
 }
 // Backward part V: leading + correction, descale, ReLU backward with the forward's sign bits (mw: the words of the layer this
 // activation gradient belongs to).
-template <int HID, int HALF, int I, int K, bool PARK>
-__device__ __forceinline__ void tx_epi_bwd_value(f32x16 (&acc)[TX_ACCN(HID)], TxEpi& e, const TxScale& sc, const uint32_t (&mw)[HID / 64]) {
+template <int HID, int HALF, int I, int K>
+__device__ __forceinline__ void tx_epi_bwd_value(const f32x16 (&acc)[TX_ACCN(HID)], TxEpi& e, const TxScale& sc, const uint32_t (&mw)[HID / 64]) {
     using P = TxPair<HID, HALF, I>;
     constexpr int u = I % 4;
     if constexpr (K == 0) {
@@ -459,27 +491,25 @@ __device__ __forceinline__ void tx_epi_bwd_value(f32x16 (&acc)[TX_ACCN(HID)], Tx
         e.c[u][0] = acc[P::tl + P::NH][P::r0]; e.c[u][1] = acc[P::tl + P::NH][P::r1];
         TX_KEEP(e.v[u]); TX_KEEP(e.c[u]);
     } else if constexpr (K == 1) {
-        e.v[u] += e.c[u]; TX_KEEP(e.v[u]);
-        e.b[u][0] = __int_as_float(__builtin_amdgcn_sbfe((int)mw[P::t / 2], (P::t & 1) * 16 + P::r0, 1));       // the mask: 0 / all ones
-        e.b[u][1] = __int_as_float(__builtin_amdgcn_sbfe((int)mw[P::t / 2], (P::t & 1) * 16 + P::r1, 1));
+        e.v[u][0] += e.c[u][0]; e.v[u][1] += e.c[u][1]; TX_KEEP(e.v[u]);
+        e.b[u][0] = __int_as_float(__builtin_amdgcn_sbfe((int)mw[P::t / 2], P::bit0, 1));       // the mask: 0 / all ones
+        e.b[u][1] = __int_as_float(__builtin_amdgcn_sbfe((int)mw[P::t / 2], P::bit1, 1));
         TX_KEEP(e.b[u]);
     } else if constexpr (K == 2) {
-        e.v[u] *= sc.dsc; TX_KEEP(e.v[u]);
+        e.v[u][0] *= sc.dsc; e.v[u][1] *= sc.dsc; TX_KEEP(e.v[u]);
     } else if constexpr (K == 3) {
         e.v[u][0] = __int_as_float(__float_as_int(e.v[u][0]) & __float_as_int(e.b[u][0]));
         e.v[u][1] = __int_as_float(__float_as_int(e.v[u][1]) & __float_as_int(e.b[u][1]));
         TX_KEEP(e.v[u]);
-        if constexpr (PARK) { acc[P::tl][P::r0] = e.v[u][0]; acc[P::tl][P::r1] = e.v[u][1]; }
     }
 }
 
 // Epilogue steps [K0, K1) of NP pairs over the slots of a pass from W0 on, SPS consecutive steps per slot.  G = groups in which
 // pairs start: G <= NP: PPG = ceil(NP / G) pairs start per group; G > NP ("spread"): pair i starts in group floor(i G / NP), some
 // groups start none.  Pair i runs steps K0 + q SPS .. behind MFMA slot W0 + 3 start(i) + q.
-// SPS = 1 is the software pipeline of the comment above (four pairs in flight); SPS = 4 runs a pair's chain inside its
+// SPS = 1 is the software pipeline of the comment above (three pairs in flight); SPS = 4 runs a pair's chain inside its
 // own group (several pairs per group interleave instead).  f(integral_constant<I>, integral_constant<K>).
-// The caller checks that the last pair's last step (slot W0 + 3 (G - 1) + ceil((K1 - K0) / SPS) - 1) lies inside the pass and
-// before the first read of what it writes (tx_spread_ok for the spread windows).
+// The caller checks the window against the pass that carries it: tx_half_a_ok / tx_half_b_ok below.
 template <int W0, int G, int NP, int K0, int K1, int SPS, typename F>
 __device__ __forceinline__ auto tx_window(F&& f) {
     return [&f](auto sc) TN_INLINE_LAMBDA {
@@ -513,14 +543,27 @@ __device__ __forceinline__ auto tx_window(F&& f) {
         }
     };
 }
-// Half B's epilogue rides on the next layer's pass A, whose k-steps KH/2 .. KH-1 read the pieces it writes: pair i (TxPair: tile,
-// register pair -> activation k-step xs) must be through one group before group NH xs starts.  True if a spread window of G groups
-// (SPS = 1, all TX_NSTEP steps) meets that for every pair.
-template <int HID, int G> constexpr bool tx_spread_ok() {
+// slot (relative to W0) behind which pair i of a window runs its LAST step
+template <int G, int NP, int SPS> constexpr int tx_last_slot(int i) {
+    const int start = G > NP ? (i * G) / NP : i / ((NP + G - 1) / G);
+    return TX_SPG * start + (TX_NSTEP - 1) / SPS;
+}
+// Half A's epilogue rides on pass B of its own layer and writes X[xs], xs = pair / 4, which pass B reads until the last tile of
+// k-step xs (slot 3 (NH xs + NH - 1) + 2): the pair's last step must come later — and inside the pass (NG groups).
+template <int HID, int W0, int G, int SPS> constexpr bool tx_half_a_ok() {
+    constexpr int NH = HID / 64, NP = NH * 8, NG = HID / 16 * NH;
+    for (int i = 0; i < NP; ++i) {
+        const int last = W0 + tx_last_slot<G, NP, SPS>(i), xs = i / 4;
+        if (last <= TX_SPG * (NH * xs + NH - 1) + 2 || last >= TX_SPG * NG) return false;
+    }
+    return true;
+}
+// Half B's epilogue rides on the NEXT pass A, which reads X[xs], xs = 2 NH + pair / 4, from slot 3 NH xs on: the pair must be
+// through one group earlier.
+template <int HID, int G, int SPS> constexpr bool tx_half_b_ok() {
     constexpr int NH = HID / 64, NP = NH * 8;
     for (int i = 0; i < NP; ++i) {
-        const int tl = 2 * (i / 16) + (1 - (i % 16) / 8), t = NH + tl, pr = 7 - i % 8, xs = 2 * t + pr / 4;
-        const int last = TX_SPG * ((i * G) / NP) + TX_NSTEP - 1;
+        const int last = tx_last_slot<G, NP, SPS>(i), xs = 2 * NH + i / 4;
         if (last + TX_SPG >= TX_SPG * NH * xs) return false;
     }
     return true;
