@@ -312,7 +312,8 @@ def run(args):
 
     out = {"metric": "rays/s (train step)", "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling,
-           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "vs_baseline": None,
+           "dtype": "f32 values; products = 3 x fp16 MFMA of two-piece operands" if FP32_PATH_PEAK == PEAK_X3_TFLOPS else "f32", "data": "synthetic",
            "dtype_note": ("fp32 values in, out and in every accumulator; the matrix products are APPROXIMATED to fp32 grade on the fp16 "
                           "matrix pipe: every fp32 operand is scaled by a power of two and carried as two fp16 pieces, a*b = a1*b1 (one "
                           "accumulator) + a1*b2 + a2*b1 (a second one), three v_mfma_f32_32x32x16_f16 per 16 k; measured against fp64: "
@@ -454,13 +455,25 @@ def run(args):
             out["step_mfma_frac"] = step_flops / (ms_per_step * 1e-3) / 1e12 / peak
             out["step_minus_big3_us"] = (ms_per_step - sum(kern[k] for k in step_kernels)) * 1e3
 
+    held = make_synthetic_scene(n_images=8, seed=1)               # eight cameras on the same scene that are not in the training set
+    h_images = torch.from_numpy(held["images"]).to(dev); h_poses = torch.from_numpy(held["poses"]).to(dev)
+
     def psnr_block(mdl, extra=None):
-        """Keep training (untimed), then minibatch PSNR and a held-out full-image PSNR (rank 0)."""
-        losses = []
+        """Keep training (untimed), then minibatch PSNR, the full-image PSNR of one training view, and — the statistic the bf16
+        tolerance of BASELINE configs[3] is checked on, as tests/test_gpu_parity.py::test_bf16_trainer_tracks_fp32_training does —
+        the HELD-OUT PSNR: mean over 8 unseen views, averaged over the last 5 checkpoints (one checkpoint's value moves by ~0.1 dB
+        from step to step)."""
+        losses, ckpts = [], []
+        every = max(1, args.psnr_steps // 20)
         for i in range(args.psnr_steps):
             loss, _ = one_step()
             if i >= args.psnr_steps - 20:
                 losses.append(loss.clone())
+            left = args.psnr_steps - 1 - i
+            if rank == 0 and left % every == 0 and left // every < 5:
+                ps = [float(mse2psnr(torch.mean((train_mod.render_one(mdl, encoder, H, W, focal, h_poses[k], dev, n_samples=SAMPLES, near=NEAR, far=FAR) - h_images[k]) ** 2)))
+                      for k in range(h_poses.shape[0])]
+                ckpts.append(sum(ps) / len(ps))
         mb = torch.stack(losses).mean()
         if use_dist:
             dist.all_reduce(mb)                                     # each rank's loss is its shard's share of the global mean
@@ -468,7 +481,9 @@ def run(args):
             return None
         img = train_mod.render_one(mdl, encoder, H, W, focal, poses[N - 1], dev, n_samples=SAMPLES, near=NEAR, far=FAR)
         full = float(mse2psnr(torch.mean((img - images[N - 1]) ** 2)))
-        return {"train_minibatch_db": float(mse2psnr(mb)), "full_image_view105_db": full, "after_steps": state["step"]}, img
+        return {"train_minibatch_db": float(mse2psnr(mb)), "full_image_view105_db": full, "after_steps": state["step"],
+                "heldout_8_views_last_5_checkpoints_db": sum(ckpts) / len(ckpts), "heldout_checkpoints_db": [round(c, 3) for c in ckpts],
+                "heldout_checkpoint_every_steps": every}, img
 
     # ---- PSNR context
     if args.psnr_steps > 0:
@@ -487,6 +502,10 @@ def run(args):
                                  "ms_per_step": d32 / args.steps * 1e3, "value": R_global * args.steps / d32, "unit": "rays/s",
                                  "mfma_frac": 2 * (f_ + dg_ + wg_) * R_local * SAMPLES / (d32 / args.steps) / 1e12 / PEAK_F32_MFMA_TFLOPS,
                                  "mfma_peak": PEAK_F32_MFMA_TFLOPS, "x3_speedup": d32 / dt}
+        # the like-for-like figure on the pipe north_star names (fp32 MFMA), beside `value`
+        out["fp32_mfma_value"] = out["fp32_mfma_step"]["value"]
+        out["fp32_mfma_ms_per_step"] = out["fp32_mfma_step"]["ms_per_step"]
+        out["frac_of_fp32_mfma_peak"] = out["fp32_mfma_step"]["mfma_frac"]
         run_["tr"] = tr
         del m32, o32, t32
 
@@ -584,7 +603,11 @@ def run(args):
                 p16.update(full_image_rendered_in_bf16_db=float(mse2psnr(torch.mean((img16 - images[N - 1]) ** 2))),
                            max_abs_rgb_bf16_vs_fp32_render=float((img16 - img).abs().max()))
                 if "psnr" in out:
-                    p16["delta_full_image_db_vs_fp32"] = p16["full_image_view105_db"] - out["psnr"]["full_image_view105_db"]
+                    # the comparison BASELINE configs[3] asks for (|dPSNR| <= 0.1 dB, held-out): means over 8 unseen views x 5 checkpoints
+                    p16["delta_heldout_db_vs_fp32"] = p16["heldout_8_views_last_5_checkpoints_db"] - out["psnr"]["heldout_8_views_last_5_checkpoints_db"]
+                    p16["delta_tolerance_db"] = 0.1
+                    # (one checkpoint of ONE training view, for continuity with earlier rounds' lines: chaotic to +-0.2 dB)
+                    p16["delta_full_image_view105_db_vs_fp32"] = p16["full_image_view105_db"] - out["psnr"]["full_image_view105_db"]
                 b16["psnr"] = p16
         out["bf16"] = b16
         run_["tr"] = tr

@@ -463,6 +463,15 @@ int tnerf_x3_plan_sizes(const tnerf_mlp_desc* d, tnerf_bf16_sizes* out);        
 int tnerf_x3_pack_table(const tnerf_mlp_desc* d, int32_t* table);                           /* HOST: table[pack_entries] */
 int tnerf_mlp_pack_x3(const tnerf_mlp_desc* d, const float* params, const int32_t* table, void* packed3,
                       tnerf_stream_t stream);
+/* The x3 pipe's DOMAIN.  Its scales are one power of two per layer (weights) and per sample (activations); an element keeps its 22
+ * bits down to 2^-15 of its block's maximum and loses them below.  counts [4 * (depth + 1)] (device, uint32) receives per layer
+ * (index depth = the heads): nonzero weights, weights below 2^-13 max|W_l|, nonzero biases, biases below 2^-14 max|b_l| — against the
+ * maxima in packed3's scale records (tnerf_mlp_pack_x3 or the last tnerf_train_step_dataset left them).  A caller that wants
+ * fp32-grade results for ANY weights reads the counts back and runs layers where the second count is a sizeable share of the first
+ * (the Python binding: more than 1/64) with TNERF_FLAG_FP32_MFMA; well-conditioned networks (every initialisation and every trained
+ * TinyNeRF seen here) have shares below 1e-3.  No counterpart in the reference. */
+int tnerf_x3_domain_counts(const tnerf_mlp_desc* d, const float* params, const int32_t* table, const void* packed3,
+                           uint32_t* counts, tnerf_stream_t stream);
 int tnerf_render_fused_x3(const tnerf_mlp_desc* d, const void* packed3,
                           const float* rays_o, const float* rays_d, int64_t n_rays, int32_t n_samples,
                           const float* ztab, int32_t randomized, const float* t_rand,

@@ -359,10 +359,11 @@ def test_train_gradients_match_oracle(mods, dev, tag):
     print(f"[{tag}] grad err vs fp64: L2 hip {l2_hip:.2e} cpu-fp32 {l2_cpu:.2e} | worst element hip {worst_hip:.2e} cpu-fp32 {worst_cpu:.2e}")
     assert l2_hip <= 2.0 * l2_cpu + 1e-6, (l2_hip, l2_cpu)
     assert worst_hip <= 2.0 * worst_cpu + 1e-5, (worst_hip, worst_cpu)
-    worst = max(relmax(p.grad.cpu(), go) for p, go in zip(plist, grads_o))
-    assert worst <= 1e-2, worst                      # fp32 HIP vs fp32 oracle directly (each ~2e-3 from fp64)
-    gn = torch.stack([p.grad.norm().cpu() for p in plist])
-    torch.testing.assert_close(gn, g["gnorm0"], rtol=5e-3, atol=1e-9)      # fp32-vs-fp32; both sit ~2e-3 from fp64 (printed above)
+    # (no direct fp32-vs-fp32 bound: both evaluations sit ~2e-3 from fp64 in the worst element, the yardstick gates above are the
+    #  statement; the fixture's recorded norms pin the ORACLE in tests/test_oracle_golden.py)
+    for p, gg, go in zip(plist, g64, grads_o):                  # ... and per tensor, as for the MLP fixture
+        t_hip, t_cpu = float((p.grad.cpu().double() - gg).norm() / gg.norm()), float((go.double() - gg).norm() / gg.norm())
+        assert t_hip <= 2.0 * t_cpu + 2e-6, (t_hip, t_cpu)
     # unfused autograd path (per-function HIP ops) gives the same gradients
     m2 = make_model(mods, cfg, params, dev)
     enc = mods["encoding"].PositionalEncoding(cfg["L"], True).to(dev)
@@ -416,7 +417,7 @@ def test_adam_kernel_matches_oracle(mods, dev):
         opt.step()
         ost.step(ref, grads)
     for p, r in zip(model.parameters(), ref):
-        assert float((p.detach().cpu() - r).abs().max()) <= 2e-7
+        assert float((p.detach().cpu() - r).abs().max()) <= 1e-7
 
 
 # ------------------------------------------------------ BASELINE-size properties (no oracle at this size)

@@ -519,8 +519,9 @@ def test_dataset_step_equals_the_per_call_path_bitwise(mods, dev, prec):
     for s, (x, y) in enumerate(zip(ba, bb)):
         assert torch.equal(x, y), (s, x.tolist(), y.tolist())
         used = [l for l in range(cfg["depth"])] + [16] + [17 + l for l in range(cfg["depth"])] + [33]
-        rest = torch.ones(64, dtype=torch.bool); rest[used] = False
+        rest = torch.ones(64, dtype=torch.bool); rest[used] = False; rest[63] = False
         assert bool((x.cpu()[rest] == 0).all()) and bool((x.cpu()[used] > 0).all()), (s, x.tolist())
+        assert int(x.cpu().view(torch.int32)[63]) == 0x78330004, hex(int(x.cpu().view(torch.int32)[63]))      # the stash's pipe tag: an x3 forward's
     # (c) the per-call path with the same draws
     mc = make_model(mods, cfg, params, dev)
     oc = T.FlatAdam(mc, lr=5e-4)
@@ -649,6 +650,140 @@ def test_degenerate_weights_through_the_x3_kernels(mods, dev, case):
     assert float((r.detach().cpu() - ro.detach()).abs().max()) <= 2e-6
     assert float((s.detach().cpu() - so.detach()).abs().max()) <= 1e-5 * max(1.0, float(so.detach().abs().max()))
     assert max(relmax(p.grad.cpu(), q) for p, q in zip(m.parameters(), go)) <= 5e-5
+
+
+# ------------------------------------------------------------------ outliers INSIDE a layer (the x3 scheme's scales are per layer / per sample)
+OUTLIER_CASES = ["weight_x2^14", "weight_x2^20", "row_x2^-14", "row_x2^-20", "input_feature_x2^-20", "bias_x2^20", "bias_x2^12_one_layer_tiny_acts",
+                 "column_x2^-20", "weight_x2^20_and_row_x2^-20"]
+
+
+def _outlier_params(case, params):
+    """8x256 fixture weights (layers.l.weight at 2l, bias at 2l+1) with one in-layer outlier."""
+    ps = [p.clone() for p in params]
+    if case.startswith("weight_x2^14"):
+        ps[4][17, 101] *= 2.0 ** 14
+    if case.startswith("weight_x2^20"):
+        ps[4][17, 101] *= 2.0 ** 20
+    if "row_x2^-14" in case:
+        ps[6][33] *= 2.0 ** -14; ps[7][33] *= 2.0 ** -14
+    if "row_x2^-20" in case:
+        ps[6][33] *= 2.0 ** -20; ps[7][33] *= 2.0 ** -20
+    if case == "column_x2^-20":
+        ps[6][:, 77] *= 2.0 ** -20
+    if case == "bias_x2^20":
+        ps[5][9] = abs(ps[5][9]) * 2.0 ** 20                      # one huge positive bias: the layer's bound sits 2^20 above every other activation
+    if case == "bias_x2^12_one_layer_tiny_acts":
+        ps[4] *= 2.0 ** -8; ps[5] *= 2.0 ** -8; ps[5][9] = abs(ps[5][9]) * 2.0 ** 20
+    return ps
+
+
+# where the forced x3 pipe is measurably outside the 2x gate (3-17x the reference's error in single gradient tensors) ...
+X3_OUTSIDE = {"weight_x2^14", "weight_x2^20", "bias_x2^20", "weight_x2^20_and_row_x2^-20"}
+# ... and what the domain check (ops.ModelState.check_x3_domain) flags: those, and one case the pipe would still have handled
+X3_FLAGGED = X3_OUTSIDE | {"bias_x2^12_one_layer_tiny_acts"}
+
+
+@pytest.mark.parametrize("pipe", [None, "x3", "fp32_mfma"])
+@pytest.mark.parametrize("case", OUTLIER_CASES)
+def test_in_layer_outliers_against_the_fp64_yardstick(mods, dev, case, pipe):
+    """the x3 pipe's scales are one power of two per LAYER for the weights and per SAMPLE for the activations,
+    so an operand far below its block's maximum carries fewer than 22 bits (the fp16 pieces' own exponents cover 2^-15; below that the
+    second piece goes subnormal).  One weight 2^14 / 2^20 above max|W_l|, one output row or input column 2^-14 / 2^-20 below it, one
+    input feature 2^-20 below the others, one bias that lifts a layer's bound 2^20 above its other activations: outputs and every
+    gradient tensor are judged like the well-conditioned fixture — against an fp64 evaluation, with the reference's own CPU fp32
+    error as the yardstick (x2).
+      pipe=None ("auto", the default): every case meets the gate — the model notices the cases outside the x3 domain when it packs
+                 the weights and runs them on the fp32-MFMA kernels (RuntimeWarning; X3_FLAGGED);
+      pipe="x3" (forced): the same gate, except X3_OUTSIDE where the measured degradation (up to 17x in a single tensor: gate 32x) is the statement;
+      pipe="fp32_mfma": the gate."""
+    import warnings
+    cfg, params0 = golden_params("8x256")
+    g = load_golden("mlp_8x256")
+    params = _outlier_params(case, params0)
+    x = g["x"][:1024].clone()
+    if case == "input_feature_x2^-20":
+        x[:, 7] *= 2.0 ** -20
+    model = mods["nerf"].TinyNeRF(cfg["in_dim"], cfg["hidden"], cfg["depth"], cfg["skip_at"], matrix_pipe=pipe).to(dev)
+    with torch.no_grad():
+        for p_, v_ in zip(model.parameters(), params):
+            p_.copy_(v_.to(dev))
+    grgb, gsig = g["g_rgb"][:1024], g["g_sigma"][:1024]
+
+    def ref(dtype):
+        leaves = [p.to(dtype).requires_grad_(True) for p in params]
+        r, s_ = O.mlp_forward(leaves, x.to(dtype), cfg["skip_at"])
+        gr = torch.autograd.grad((r * grgb.to(dtype)).sum() + (s_ * gsig.to(dtype)).sum(), leaves)
+        return r.detach(), s_.detach(), gr
+    r32, s32, g32 = ref(torch.float32)
+    r64, s64, g64 = ref(torch.float64)
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        rgb, sigma = model(x.to(dev))
+    st = model.hip_state()
+    if pipe is None:                                                # the default model switches exactly where the domain check says so
+        assert st.uses_x3 == (case not in X3_FLAGGED), (case, st.x3_domain() if st.uses_x3 else st.pipe_switched)
+        assert any(issubclass(w.category, RuntimeWarning) and "fp32-MFMA" in str(w.message) for w in caught) == (case in X3_FLAGGED)
+        assert (st.pipe_switched is not None) == (case in X3_FLAGGED)
+    else:
+        assert st.uses_x3 == (pipe == "x3") and st.pipe_switched is None
+    gate = 32.0 if (pipe == "x3" and case in X3_OUTSIDE) else 2.0
+    ((rgb * grgb.to(dev)).sum() + (sigma * gsig.to(dev)).sum()).backward()
+    assert bool(torch.isfinite(rgb).all()) and bool(torch.isfinite(sigma).all())
+    e_rgb, e_rgb_ref = float((rgb.detach().cpu().double() - r64).abs().max()), float((r32.double() - r64).abs().max())
+    e_sig, e_sig_ref = float((sigma.detach().cpu().double() - s64).abs().max()), float((s32.double() - s64).abs().max())
+    scale_sig = max(1.0, float(s64.abs().max()))
+    assert e_rgb <= gate * e_rgb_ref + 5e-7, (case, pipe, e_rgb, e_rgb_ref)
+    assert e_sig <= gate * e_sig_ref + 2e-6 * scale_sig, (case, pipe, e_sig, e_sig_ref)
+    flat = lambda ts: torch.cat([t.reshape(-1).double() for t in ts])
+    gh_all, gr_all, gd_all = flat([p.grad.cpu() for p in model.parameters()]), flat(g32), flat(g64)
+    l2_hip, l2_ref = float((gh_all - gd_all).norm() / gd_all.norm()), float((gr_all - gd_all).norm() / gd_all.norm())
+    worst = (0.0, -1, 0.0)
+    for i, p in enumerate(model.parameters()):
+        gh, gr, gd = p.grad.cpu().double(), g32[i].double(), g64[i]
+        assert bool(torch.isfinite(gh).all()), (case, pipe, i)
+        if float(gd.norm()) == 0.0:
+            assert float(gh.norm()) == 0.0
+            continue
+        t_hip, t_ref = float((gh - gd).norm() / gd.norm()), float((gr - gd).norm() / gd.norm())
+        if t_hip / (t_ref + 1e-7) > worst[0]:
+            worst = (t_hip / (t_ref + 1e-7), i, t_hip)
+        assert t_hip <= gate * t_ref + 2e-7, (case, pipe, i, t_hip, t_ref)
+    print(f"[{case} / {pipe}] rgb err {e_rgb:.1e} (ref {e_rgb_ref:.1e}) sigma err {e_sig:.1e} (ref {e_sig_ref:.1e}) grads L2 {l2_hip:.1e} (ref {l2_ref:.1e}); "
+          f"worst tensor {worst[1]}: {worst[2]:.1e} = {worst[0]:.2f} x the reference's")
+    assert l2_hip <= gate * l2_ref + 1e-7, (case, pipe, l2_hip, l2_ref)
+
+
+def test_dataset_trainer_leaves_the_x3_pipe_when_the_weights_leave_its_domain(mods, dev):
+    """The device-resident loop checks the x3 domain every X3_CHECK_EVERY steps: a weight that has grown 2^16 above the rest of its layer
+    (written between two steps here) moves an "auto" model onto the fp32-MFMA kernels — warning, graphs dropped, training goes on and
+    the loss stays finite; a model built with matrix_pipe="x3" stays where it was told to."""
+    import warnings
+    from data import make_synthetic_scene
+    T = mods["trainer"]
+    scene = make_synthetic_scene(n_images=4, H=24, W=24, seed=3)
+    images = torch.from_numpy(scene["images"]).to(dev); poses = torch.from_numpy(scene["poses"]).to(dev); focal = float(scene["focal"])
+    for pipe in (None, "x3"):
+        torch.manual_seed(0)
+        m = mods["nerf"].TinyNeRF(39, 128, 3, 2, matrix_pipe=pipe).to(dev)
+        with torch.no_grad():
+            m.sigma[0].bias += 0.5
+        tr = T.DatasetTrainer(m, T.FlatAdam(m, lr=5e-4), images, poses, focal, 128, 32, 2.0, 6.0, seed=1)
+        tr.X3_CHECK_EVERY = 4
+        st = m.hip_state()
+        for _ in range(6):
+            tr.step()
+        assert st.uses_x3 and st.pipe_switched is None
+        with torch.no_grad():
+            m.layers[1].weight[5, 7] = 2.0 ** 16 * float(m.layers[1].weight.abs().max())
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            losses = [float(tr.step()[0]) for _ in range(8)]
+        assert all(math.isfinite(v) for v in losses)
+        if pipe is None:
+            assert not st.uses_x3 and st.pipe_switched is not None and tr._x3_packed is None
+            assert any(issubclass(w.category, RuntimeWarning) and "fp32-MFMA" in str(w.message) for w in caught)
+        else:
+            assert st.uses_x3 and st.pipe_switched is None
 
 
 # ------------------------------------------------------------------ gradients w.r.t. rays and depths (per-function ops)
@@ -828,6 +963,71 @@ def test_hidden_widths_other_than_128_and_256(mods, dev, arch):
         assert int(noisy.sum()) < 0.5 * err.numel()
 
 
+# ------------------------------------------------- the stash's pipe tag: tnerf_wgrad after either pipe's forward; a mixed sequence fails loudly
+@pytest.mark.parametrize("tag", ["4x128", "8x256"])
+def test_wgrad_entry_point_follows_the_stash_and_mixed_pipes_give_nan(mods, dev, tag):
+    """tnerf_wgrad chose its kernel from desc.flags alone, so the documented per-call sequence fp32-MFMA forward ->
+    fp32-MFMA dgrad -> tnerf_wgrad (default flags = x3) scaled its operands by bound words nobody had written.  The training forward
+    now labels the stash (its last bound word), tnerf_wgrad runs the body the label names, and a backward kernel that meets the
+    other pipe's stash refuses it: the gradients come out NaN instead of plausible garbage."""
+    ops, lib = mods["ops"], mods["lib"]
+    cfg, params = golden_params(tag)
+    m = make_model(mods, cfg, params, dev)
+    st = m._ensure_packed(); x3 = st.repack_x3(("t", 1))
+    R, S = 96, 64
+    g = torch.Generator().manual_seed(5)
+    d = torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=-1).to(dev)
+    o = (-4.0 * d + 0.1).contiguous(); u = torch.rand(R, S, generator=g).to(dev)
+    gc = (torch.randn(R, 3, generator=g) / (3 * R)).to(dev)
+    plan = st.plan(R * S); ztab = ops.depth_table(2.0, 6.0, S, dev)
+    comp = torch.empty(R, 3, device=dev)
+    sp = torch.cuda.current_stream(dev).cuda_stream
+    common = (o.data_ptr(), d.data_ptr(), R, S, ztab.data_ptr(), 1, u.data_ptr(), 0, 0, 1)
+    n = int(st.flat.numel())
+
+    def wgrad_reduce(stash):
+        grads = torch.zeros(n, device=dev)
+        lib.call("tnerf_wgrad", C.byref(st.desc), stash.data_ptr(), plan.Mp, R * S, plan.jobs.data_ptr(), plan.n_jobs, plan.slabs.data_ptr(), sp)
+        lib.call("tnerf_wgrad_reduce", plan.slabs.data_ptr(), plan.reduce.data_ptr(), n, grads.data_ptr(), sp)
+        torch.cuda.synchronize()
+        return grads
+
+    def whole_backward(stash, packed_x3):
+        grads = torch.zeros(n, device=dev)
+        lib.call("tnerf_train_bwd_fused", C.byref(st.desc), st.packed.data_ptr(), *common, gc.data_ptr(), stash.data_ptr(), plan.Mp, plan.jobs.data_ptr(), plan.n_jobs,
+                 plan.slabs.data_ptr(), plan.reduce.data_ptr(), grads.data_ptr(), packed_x3, sp)
+        torch.cuda.synchronize()
+        return grads
+    s1, s2 = torch.zeros_like(plan.stash), torch.zeros_like(plan.stash)
+    # fp32-MFMA forward + dgrad, then the per-call weight-gradient entry point with the descriptor's default (x3) flags
+    lib.call("tnerf_train_fwd_fused", C.byref(st.desc), st.packed.data_ptr(), *common, comp.data_ptr(), s1.data_ptr(), plan.Mp, sp)
+    s2.copy_(s1)
+    lib.call("tnerf_train_dgrad_fused", C.byref(st.desc), st.packed.data_ptr(), *common, gc.data_ptr(), s1.data_ptr(), plan.Mp, sp)
+    g_call = wgrad_reduce(s1)
+    g_ref = whole_backward(s2, None)                               # the same pipe end to end
+    assert torch.isfinite(g_call).all() and float(g_call.abs().max()) > 0
+    assert torch.equal(g_call, g_ref)
+    # x3 forward + dgrad + the same entry point = the x3 backward end to end
+    lib.call("tnerf_train_fwd_fused_x3", C.byref(st.desc), x3.packed.data_ptr(), *common, comp.data_ptr(), s1.data_ptr(), plan.Mp, sp)
+    s2.copy_(s1)
+    lib.call("tnerf_train_dgrad_fused_x3", C.byref(st.desc), x3.packed.data_ptr(), *common, gc.data_ptr(), s1.data_ptr(), plan.Mp, sp)
+    g_call3 = wgrad_reduce(s1)
+    g_ref3 = whole_backward(s2, x3.packed.data_ptr())
+    assert torch.isfinite(g_call3).all() and torch.equal(g_call3, g_ref3)
+    assert float((g_call3 - g_call).norm() / g_call.norm()) <= 2e-4          # and the two pipes agree (each ~1e-4 from fp64 on this vector)
+    # mixed: x3 forward, fp32-MFMA dgrad -> refused, NaN gradients from either weight-gradient path
+    lib.call("tnerf_train_fwd_fused_x3", C.byref(st.desc), x3.packed.data_ptr(), *common, comp.data_ptr(), s1.data_ptr(), plan.Mp, sp)
+    s2.copy_(s1)
+    lib.call("tnerf_train_dgrad_fused", C.byref(st.desc), st.packed.data_ptr(), *common, gc.data_ptr(), s1.data_ptr(), plan.Mp, sp)
+    assert torch.isnan(wgrad_reduce(s1)).all()
+    assert torch.isnan(whole_backward(s2, None)).all()             # fp32-MFMA backward on an x3 forward's stash
+    # ... and the other way round
+    lib.call("tnerf_train_fwd_fused", C.byref(st.desc), st.packed.data_ptr(), *common, comp.data_ptr(), s1.data_ptr(), plan.Mp, sp)
+    assert torch.isnan(whole_backward(s1, x3.packed.data_ptr())).all()
+    # a stash no training forward has written
+    assert torch.isnan(wgrad_reduce(torch.zeros_like(plan.stash))).all()
+
+
 # ------------------------------------------------- the split-bf16 chain kernels against the fp32-MFMA ones, region by region
 @pytest.mark.parametrize("tag,R,S", [("4x128", 101, 72), ("8x256", 64, 32), ("8x256", 37, 100)])
 def test_x3_chain_kernels_fill_the_stash_like_the_fp32_mfma_kernels(mods, dev, tag, R, S):
@@ -890,6 +1090,7 @@ def test_x3_chain_kernels_fill_the_stash_like_the_fp32_mfma_kernels(mods, dev, t
     sC = sA.clone()
     n_mask = depth * (Mp + 32) * NT                                 # the sign words (the bound words behind them stay as they are)
     sC[body:body + n_mask].view(torch.int32).copy_(bitrev32(sA[body:body + n_mask].view(torch.int32).cpu()).to(dev))
+    sC.view(torch.int32)[-1] = 0x78330004                          # ... and labelled as an x3 forward's (the stash's pipe tag, TN_TAG_X3)
     lib.call("tnerf_train_dgrad_fused", C.byref(st.desc), st.packed.data_ptr(), *common, gc.data_ptr(), sA.data_ptr(), plan.Mp, sp)
     lib.call("tnerf_train_dgrad_fused_x3", C.byref(st.desc), x3.packed.data_ptr(), *common, gc.data_ptr(), sC.data_ptr(), plan.Mp, sp)
     torch.cuda.synchronize()

@@ -230,6 +230,17 @@ __device__ __forceinline__ const float* tn_stash_at(const float* stash, int64_t 
     return stash + ((m >> 5) * rows) * 32 + (m & 31);
 }
 
+// The stash's pipe tag (tnerf_internal.h TNB_TAG): true if it is `want`; otherwise the tag is marked BAD (whoever consumes the stash
+// next sees the mismatch too) and the caller returns before doing anything.
+__device__ __forceinline__ bool tn_stash_tag_is(float* stash, const MlpLayout& L, int64_t Mp, unsigned want) {
+    unsigned* w = reinterpret_cast<unsigned*>(stash + TN_BOUND_OFF(L, Mp)) + TNB_TAG;
+    const unsigned tag = __builtin_nontemporal_load(w);
+    if (tag == want) return true;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *w = TN_TAG_BAD;
+    return false;
+}
+__global__ void k_stash_tag(unsigned* __restrict__ w, unsigned tag);      // mlp_fwd.hip
+
 // ---------------------------------------------------------------------------------------- LDS-DMA
 // global_load_lds_dwordx4: 64 lanes x 16 B from (wave-uniform base + per-lane 32-bit offset) straight into LDS at
 // lds_dst + lane * 16 (wave-uniform destination, lane-linear image), no VGPR round trip.  Issued from inline asm: hipcc

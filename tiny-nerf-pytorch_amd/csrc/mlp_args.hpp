@@ -40,9 +40,9 @@ inline RaySource tn_table_source(const float* rays_o, const float* rays_d) { ret
 int tn_launch_mlp_bwd(const BwdArgs& a, hipStream_t stream);
 int tn_launch_train_bwd(const BwdArgs& a, hipStream_t stream);
 // wgrad.hip
-// x3: the products on the bf16 matrix pipe by exact 3-way splitting (wgrad.hip), else fp32 MFMA
-int tn_launch_wgrad(const float* stash, int64_t stash_rows, int64_t M, const int32_t* jobs, int64_t n_jobs, float* slabs, int64_t* step_inc, hipStream_t stream, bool x3,
-                    const float* bounds = nullptr);
+// mode 0: fp32-MFMA body, 1: x3 body (three fp16 partial products), 2: whichever the stash's pipe tag names; bounds = the stash's bound words
+int tn_launch_wgrad(const float* stash, int64_t stash_rows, int64_t M, const int32_t* jobs, int64_t n_jobs, float* slabs, int64_t* step_inc, hipStream_t stream, int mode,
+                    const float* bounds);
 int tn_launch_reduce(const float* slabs, const int32_t* reduce_table, int64_t n_params, float* grads, hipStream_t stream);
 // Dataset mode: the device step counter and the Philox counters consumed per step (zero = per-call mode)
 struct TnStepRef { int64_t* step; uint64_t per_step; };

@@ -80,6 +80,7 @@ template <int HID>
 __global__ __launch_bounds__(256, HID == 128 ? 2 : 1) void k_mlp_bwd(BwdArgs a) {
     const int lane = tn_lane();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (!tn_stash_tag_is(a.stash, a.L, a.Mp, TN_TAG_F32)) return;      // not this pipe's forward
     const int64_t m0 = ((int64_t)blockIdx.x * 4 + wave) * 32;
     if (m0 >= a.M) return;
     const int64_t m = m0 + (lane & 31);
@@ -104,6 +105,7 @@ template <int HID>
 __global__ __launch_bounds__(256, HID == 128 ? 2 : 1) void k_train_bwd(BwdArgs a) {
     const int lane = tn_lane();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (!tn_stash_tag_is(a.stash, a.L, a.Mp, TN_TAG_F32)) return;      // not this pipe's forward
     const int64_t ray = (int64_t)blockIdx.x * 4 + wave;
     if (ray >= a.R) return;
     RaySource rs = a.rs; SampleArgs sa = a.sa;

@@ -226,8 +226,14 @@ __global__ __launch_bounds__(256, HID == 128 ? (NE == 32 ? TN_NE32_WAVES : 2) : 
 }
 
 // ----------------------------------------------------------------------------------- dispatch
+__global__ void k_stash_tag(unsigned* __restrict__ w, unsigned tag) { if (threadIdx.x == 0) *w = tag; }
+
 template <bool FUSED, bool TRAIN>
 static int launch_fwd(const FwdArgs& a, int64_t units, hipStream_t stream, const char* who) {
+    if (TRAIN) {       // this pipe's stash (tnerf_internal.h TNB_TAG): the x3 backward kernels refuse it, tnerf_wgrad picks the fp32 body
+        hipLaunchKernelGGL(k_stash_tag, dim3(1), dim3(64), 0, stream, reinterpret_cast<unsigned*>(a.stash + TN_BOUND_OFF(a.L, a.Mp)) + TNB_TAG, TN_TAG_F32);
+        TN_HIP_CHECK_LAUNCH(who);
+    }
     const dim3 grid((unsigned)((units + 3) / 4)), block(256);
     const int hid = a.L.hidden, ne = a.L.NE;
 #define TN_CASE(H_, N_)                                                                                     \

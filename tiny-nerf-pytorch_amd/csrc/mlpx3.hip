@@ -262,7 +262,10 @@ __global__ TX_PLAIN_F32 __launch_bounds__((TxCfg<HID, TRAIN>::NW * 64), 1) void 
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // no DMA may still be writing this workgroup's LDS at exit
-    if constexpr (TRAIN) tx_bound_flush<NW>(lds_bnd0, a.f.stash + TN_BOUND_OFF(a.f.L, a.f.Mp), 0, lane, wave);
+    if constexpr (TRAIN) {
+        tx_bound_flush<NW>(lds_bnd0, a.f.stash + TN_BOUND_OFF(a.f.L, a.f.Mp), 0, lane, wave);
+        if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<unsigned*>(a.f.stash + TN_BOUND_OFF(a.f.L, a.f.Mp))[TNB_TAG] = TN_TAG_X3;      // this pipe's stash
+    }
 #ifdef TN_STAMPS
     if (a.f.stamps && lane == 0) {
         unsigned long long* o = a.f.stamps + (blockIdx.x * NW + wave) * 8;
@@ -392,6 +395,7 @@ template <int HID>
 __global__ TX_PLAIN_F32 __launch_bounds__(TxCfg<HID>::NW * 64, 1) void k_dgradx3(BwdX3Args a) {
     constexpr int NW = TxCfg<HID>::NW;
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    if (!tn_stash_tag_is(a.b.stash, a.b.L, a.b.Mp, TN_TAG_X3)) return;      // not an x3 forward's stash: its sign words mean something else
     const int lane = tn_lane();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     RaySource rs = a.b.rs; SampleArgs sa = a.b.sa;
@@ -538,13 +542,17 @@ __global__ TX_PLAIN_F32 __launch_bounds__((TxCfg<HID, TRAIN>::NW * 64), 1) void 
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if constexpr (TRAIN) tx_bound_flush<NW>(lds_bnd0, a.f.stash + TN_BOUND_OFF(a.f.L, a.f.Mp), 0, lane, wave);
+    if constexpr (TRAIN) {
+        tx_bound_flush<NW>(lds_bnd0, a.f.stash + TN_BOUND_OFF(a.f.L, a.f.Mp), 0, lane, wave);
+        if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<unsigned*>(a.f.stash + TN_BOUND_OFF(a.f.L, a.f.Mp))[TNB_TAG] = TN_TAG_X3;      // this pipe's stash
+    }
 }
 
 template <int HID>
 __global__ TX_PLAIN_F32 __launch_bounds__(TxCfg<HID>::NW * 64, 1) void k_mlpx3_bwd(BwdX3Args a) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
     constexpr int NW = TxCfg<HID>::NW;
+    if (!tn_stash_tag_is(a.b.stash, a.b.L, a.b.Mp, TN_TAG_X3)) return;      // not an x3 forward's stash
     const int lane = tn_lane();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     PipeX p;
@@ -793,6 +801,61 @@ int tnx3_launch_stats(const NetX3& n, const float* params, const int32_t* table,
     }
     hipLaunchKernelGGL(k_x3stats_final, dim3(1), dim3(64), 0, stream, n.depth + 1, meta, post);
     TN_HIP_CHECK_LAUNCH("x3 weight statistics");
+    return TNERF_OK;
+}
+
+// ---- the x3 pipe's DOMAIN.  Its scales are one power of two per LAYER (weights) and per SAMPLE (activations); the fp16 pieces' own
+// exponents carry an element down to 2^-15 of its block's maximum with all 22 bits, below that the second piece goes subnormal and
+// bits are lost.  A layer in which a sizeable share of the weights sits that far below max|W_l| (one outlier 2^14+ above the rest),
+// or whose largest bias lifts the activation bound 2^14 above the other biases, is outside the domain: measured (tests/
+// test_gpu_round2.py::test_in_layer_outliers_*) as 3-13x the reference's own fp32 error in single gradient tensors.
+// counts[4 l + {0,1,2,3}] = nonzero weights, weights below 2^-13 max|W_l|, nonzero biases, biases below 2^-14 max|b_l| of layer l
+// (index depth = the heads); the maxima are the scale records' (tnerf_mlp_pack_x3 / the finishing kernel keep them).
+__global__ __launch_bounds__(256) void k_x3domain(const float* __restrict__ params, const int32_t* __restrict__ table, NetX3 n,
+                                                  const float* __restrict__ meta, unsigned* __restrict__ counts) {
+    const int l = blockIdx.x / TX_SCAN_NB, part = blockIdx.x % TX_SCAN_NB;
+    const int64_t fe = (int64_t)n.rec_frags * 512;
+    const int64_t e0 = n.fw_rec0[l] * fe, e1 = n.fw_rec0[l + 1] * fe, n_w = (int64_t)(n.n_rec + n.n_bw_rec) * fe;
+    const float wlim = meta[l * TX_META + 1] * 0x1p-13f, blim = meta[l * TX_META + 2] * 0x1p-14f;
+    unsigned nz = 0, small = 0, bnz = 0, bsmall = 0;
+    for (int64_t e = e0 + part * 256 + threadIdx.x; e < e1; e += TX_SCAN_NB * 256) {
+        if (((e >> 9) % TX_NP) != 0) continue;
+        const int32_t s = table[e];
+        if (s < 0) continue;
+        const float a = fabsf(params[s]);
+        nz += a > 0.0f; small += (a > 0.0f && a < wlim);
+    }
+    if (part == 0) {
+        const int nb = l < n.depth ? n.hidden : 4, b0 = l < n.depth ? l * n.hidden : n.depth * n.hidden;
+        for (int j = threadIdx.x; j < nb; j += 256) {
+            const int32_t s = table[n_w + b0 + j];
+            if (s < 0) continue;
+            const float a = fabsf(params[s]);
+            bnz += a > 0.0f; bsmall += (a > 0.0f && a < blim);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        nz += __shfl_xor((int)nz, o, 64); small += __shfl_xor((int)small, o, 64); bnz += __shfl_xor((int)bnz, o, 64); bsmall += __shfl_xor((int)bsmall, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(counts + 4 * l, nz); atomicAdd(counts + 4 * l + 1, small);
+        if (part == 0) { atomicAdd(counts + 4 * l + 2, bnz); atomicAdd(counts + 4 * l + 3, bsmall); }
+    }
+}
+
+extern "C" int tnerf_x3_domain_counts(const tnerf_mlp_desc* d, const float* params, const int32_t* table, const void* packed3,
+                                      uint32_t* counts, tnerf_stream_t stream) {
+    NetX3 n; int rc = tn_build_netx3(d, &n); if (rc) return rc;
+    if (!params || !table || !packed3 || !counts) {
+        tn_set_error("tnerf_x3_domain_counts: params=%p table=%p packed3=%p counts=%p", (const void*)params, (const void*)table, packed3, (void*)counts);
+        return TNERF_EINVAL;
+    }
+    hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, (hipStream_t)stream, counts, 4 * (n.depth + 1));
+    TN_HIP_CHECK_LAUNCH("tnerf_x3_domain_counts (clear)");
+    const float* meta = reinterpret_cast<const float*>(static_cast<const unsigned char*>(packed3) + n.meta_off);
+    hipLaunchKernelGGL(k_x3domain, dim3((unsigned)((n.depth + 1) * TX_SCAN_NB)), dim3(256), 0, (hipStream_t)stream, params, table, n, meta, counts);
+    TN_HIP_CHECK_LAUNCH("tnerf_x3_domain_counts");
     return TNERF_OK;
 }
 

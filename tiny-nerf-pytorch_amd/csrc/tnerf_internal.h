@@ -24,6 +24,15 @@ enum {
 #define TNB_ENC TN_MAXD                   // the network input
 #define TNB_DZ(l) (TN_MAXD + 1 + (l))     // layer l's activation gradients
 #define TNB_DZH (2 * TN_MAXD + 1)         // the head gradient
+// The last bound word says WHICH matrix pipe's training forward filled the stash: the two pipes arrange the sign words (and, for the
+// x3 pipe, the bound words themselves) differently, so a backward kernel of the other pipe must not consume it.  Written by the
+// training forward (x3: by the kernel; fp32 MFMA: by its launcher), checked by every dgrad and weight-gradient kernel: on a mismatch
+// the kernel marks the tag BAD and the weight-gradient kernel fills its slabs with NaN — a loud failure instead of silently wrong
+// gradients.  tnerf_wgrad (the per-call entry point) picks its kernel body by the tag.
+#define TNB_TAG (TN_BOUND_FLOATS - 1)
+#define TN_TAG_X3  0x78330004u
+#define TN_TAG_F32 0x66333204u
+#define TN_TAG_BAD 0x0bad0badu
 
 // Everything the kernels need to know about one model; passed by value as a kernel argument.
 struct MlpLayout {

@@ -33,7 +33,7 @@ extern "C" int tnerf_mlp_bwd(const tnerf_mlp_desc* d, const float* packed, int64
     hipStream_t s = (hipStream_t)stream;
     if ((rc = tn_launch_mlp_bwd(a, s))) return rc;
     // (the x3 weight-gradient kernel scales its operands by bounds only the x3 chain kernels leave in the stash)
-    if ((rc = tn_launch_wgrad(stash, a.L.stash_rows, M, job_table, n_jobs, slabs, nullptr, s, false))) return rc;
+    if ((rc = tn_launch_wgrad(stash, a.L.stash_rows, M, job_table, n_jobs, slabs, nullptr, s, 0, stash + TN_BOUND_OFF(a.L, Mp)))) return rc;
     return tn_launch_reduce(slabs, reduce_table, a.L.n_params, grads, s);
 }
 
@@ -48,7 +48,7 @@ extern "C" int tnerf_mlp_bwd_x3(const tnerf_mlp_desc* d, const void* packed_x3, 
     a.packed = nullptr; a.stash = stash; a.Mp = Mp; a.M = M; a.d_rgb = d_rgb; a.d_sigma = d_sigma;
     hipStream_t s = (hipStream_t)stream;
     if ((rc = tnx3_mlp_dgrad(who, a, d, packed_x3, s))) return rc;
-    if ((rc = tn_launch_wgrad(stash, a.L.stash_rows, M, job_table, n_jobs, slabs, nullptr, s, !(a.L.flags & TNERF_FLAG_FP32_MFMA), stash + TN_BOUND_OFF(a.L, Mp)))) return rc;
+    if ((rc = tn_launch_wgrad(stash, a.L.stash_rows, M, job_table, n_jobs, slabs, nullptr, s, 1, stash + TN_BOUND_OFF(a.L, Mp)))) return rc;
     return tn_launch_reduce(slabs, reduce_table, a.L.n_params, grads, s);
 }
 
@@ -70,7 +70,7 @@ static int train_bwd_impl(const char* who, const tnerf_mlp_desc* d, const float*
     if (x3) rc = tnx3_train_dgrad(who, a, d, packed3, s);
     else    rc = tn_launch_train_bwd(a, s);
     if (rc) return rc;
-    if ((rc = tn_launch_wgrad(stash, a.L.stash_rows, R * S, job_table, n_jobs, slabs, sr.step, s, x3, stash + TN_BOUND_OFF(a.L, Mp)))) return rc;
+    if ((rc = tn_launch_wgrad(stash, a.L.stash_rows, R * S, job_table, n_jobs, slabs, sr.step, s, x3 ? 1 : 0, stash + TN_BOUND_OFF(a.L, Mp)))) return rc;
     if (!reduce_table) return TNERF_OK;
     return tn_launch_reduce(slabs, reduce_table, a.L.n_params, grads, s);
 }
@@ -117,7 +117,8 @@ extern "C" int tnerf_wgrad(const tnerf_mlp_desc* d, const float* stash, int64_t 
                            float* slabs, tnerf_stream_t stream) {
     MlpLayout L; int rc = tn_build_layout(d, &L); if (rc) return rc;
     if (!stash || Mp < M || M < 1 || !job_table || n_jobs < 1 || !slabs) { tn_set_error("tnerf_wgrad: bad arguments"); return TNERF_EINVAL; }
-    return tn_launch_wgrad(stash, L.stash_rows, M, job_table, n_jobs, slabs, nullptr, (hipStream_t)stream, !(L.flags & TNERF_FLAG_FP32_MFMA), stash + TN_BOUND_OFF(L, Mp));
+    // which forward filled the stash is not this call's to know: the kernel reads the stash's pipe tag (tnerf_internal.h TNB_TAG)
+    return tn_launch_wgrad(stash, L.stash_rows, M, job_table, n_jobs, slabs, nullptr, (hipStream_t)stream, 2, stash + TN_BOUND_OFF(L, Mp));
 }
 
 extern "C" int tnerf_wgrad_reduce(const float* slabs, const int32_t* reduce_table, int64_t n_params, float* grads, tnerf_stream_t stream) {

@@ -462,7 +462,10 @@ __device__ __forceinline__ void wgrad_x3_body(const float* __restrict__ stash, i
 // (Packed fp32 VALU stays ON here, unlike in the backward chain kernels (mlpx3.hip TX_PLAIN_F32): with two waves per SIMD a packed
 // instruction that cannot overlap its own wave's MFMA overlaps the other wave's.  A/B in the bench's step, three runs each: 0.886-0.890 ms
 // packed against 0.909-0.915 ms unpacked — although a probe on synthetic operands had said the opposite by 2 %.)
-template <bool X3>
+// MODE 0: the fp32-MFMA body, 1: the x3 body — the stash's pipe tag (tnerf_internal.h TNB_TAG) must agree; 2: the body the tag names
+// (tnerf_wgrad: the per-call entry point cannot know which forward filled the stash).  A stash whose tag does not fit — another
+// pipe's forward, a dgrad kernel that refused it, memory no training forward ever wrote — gives NaN slabs, not garbage.
+template <int MODE>
 __global__ __launch_bounds__(512, 2) void k_wgrad(const float* __restrict__ stash, int64_t stash_rows, int64_t M,
                                                   const int32_t* __restrict__ jobs, float* __restrict__ slabs, int64_t* step_inc,
                                                   const float* __restrict__ bounds) {
@@ -475,16 +478,24 @@ __global__ __launch_bounds__(512, 2) void k_wgrad(const float* __restrict__ stas
 #endif
     const int32_t* job = jobs + (int64_t)blockIdx.x * TN_JOB_INTS;
     const int n_at = job[JOB_N_AT], n_bt = job[JOB_N_BT], WA = job[JOB_WA], WB = 8 / WA;
+    const unsigned tag = reinterpret_cast<const unsigned*>(bounds)[TNB_TAG];
+    const bool X3 = MODE == 2 ? tag == TN_TAG_X3 : MODE == 1;                 // uniform
+    if (tag != (X3 ? TN_TAG_X3 : TN_TAG_F32)) {
+        float* slab = slabs + job[JOB_SLAB_OFF];
+        const int n = n_at * 32 * n_bt * 32 + (job[JOB_HAS_BIAS] ? n_at * 32 : 0);
+        for (int i = threadIdx.x; i < n; i += 512) slab[i] = __builtin_nanf("");
+        return;
+    }
     const int ta = (n_at + WA - 1) / WA, tb = (n_bt + WB - 1) / WB;     // the host plan only emits full-or-idle waves
     const bool small = (n_at + n_bt) * 32 <= 256;                      // combined rows of the job (uniform): two converter items per thread cover them
     switch (ta * 8 + tb) {
-        case 2 * 8 + 4: if (X3) wgrad_x3_body<2, 4, 2, 4>(stash, stash_rows, M, job, slabs, lds, bounds); else wgrad_body<2, 4>(stash, stash_rows, M, job, slabs, lds); break;
-        case 1 * 8 + 2: if (X3) { if (small) wgrad_x3_body<1, 2, 4, 2>(stash, stash_rows, M, job, slabs, lds, bounds); else wgrad_x3_body<1, 2, 4, 4>(stash, stash_rows, M, job, slabs, lds, bounds); }
-                        else wgrad_body<1, 2>(stash, stash_rows, M, job, slabs, lds); break;
-        case 2 * 8 + 1: if (X3) { if (small) wgrad_x3_body<2, 1, 4, 2>(stash, stash_rows, M, job, slabs, lds, bounds); else wgrad_x3_body<2, 1, 4, 4>(stash, stash_rows, M, job, slabs, lds, bounds); }
-                        else wgrad_body<2, 1>(stash, stash_rows, M, job, slabs, lds); break;
-        case 1 * 8 + 1: if (X3) { if (small) wgrad_x3_body<1, 1, 4, 2>(stash, stash_rows, M, job, slabs, lds, bounds); else wgrad_x3_body<1, 1, 4, 4>(stash, stash_rows, M, job, slabs, lds, bounds); }
-                        else wgrad_body<1, 1>(stash, stash_rows, M, job, slabs, lds); break;
+        case 2 * 8 + 4: if (MODE != 0 && X3) wgrad_x3_body<2, 4, 2, 4>(stash, stash_rows, M, job, slabs, lds, bounds); else if (MODE != 1) wgrad_body<2, 4>(stash, stash_rows, M, job, slabs, lds); break;
+        case 1 * 8 + 2: if (MODE != 0 && X3) { if (small) wgrad_x3_body<1, 2, 4, 2>(stash, stash_rows, M, job, slabs, lds, bounds); else wgrad_x3_body<1, 2, 4, 4>(stash, stash_rows, M, job, slabs, lds, bounds); }
+                        else if (MODE != 1) wgrad_body<1, 2>(stash, stash_rows, M, job, slabs, lds); break;
+        case 2 * 8 + 1: if (MODE != 0 && X3) { if (small) wgrad_x3_body<2, 1, 4, 2>(stash, stash_rows, M, job, slabs, lds, bounds); else wgrad_x3_body<2, 1, 4, 4>(stash, stash_rows, M, job, slabs, lds, bounds); }
+                        else if (MODE != 1) wgrad_body<2, 1>(stash, stash_rows, M, job, slabs, lds); break;
+        case 1 * 8 + 1: if (MODE != 0 && X3) { if (small) wgrad_x3_body<1, 1, 4, 2>(stash, stash_rows, M, job, slabs, lds, bounds); else wgrad_x3_body<1, 1, 4, 4>(stash, stash_rows, M, job, slabs, lds, bounds); }
+                        else if (MODE != 1) wgrad_body<1, 1>(stash, stash_rows, M, job, slabs, lds); break;
         default: break;   // unreachable: shapes are validated on the host (tnerf_plan_fill)
     }
 #ifdef TN_STAMPS
@@ -496,12 +507,13 @@ __global__ __launch_bounds__(512, 2) void k_wgrad(const float* __restrict__ stas
 #endif
 }
 
-// bounds: the stash's magnitude-bound words (TN_BOUND_OFF); required by the x3 kernel
-int tn_launch_wgrad(const float* stash, int64_t stash_rows, int64_t M, const int32_t* jobs, int64_t n_jobs, float* slabs, int64_t* step_inc, hipStream_t stream, bool x3,
+// bounds: the stash's magnitude-bound words (TN_BOUND_OFF), whose last word is the pipe tag.  mode: 0 fp32-MFMA body, 1 x3 body, 2 by the tag.
+int tn_launch_wgrad(const float* stash, int64_t stash_rows, int64_t M, const int32_t* jobs, int64_t n_jobs, float* slabs, int64_t* step_inc, hipStream_t stream, int mode,
                     const float* bounds) {
-    if (x3 && !bounds) { tn_set_error("wgrad: the x3 kernel needs the stash's bound words"); return TNERF_EINVAL; }
-    if (x3) hipLaunchKernelGGL(k_wgrad<true>, dim3((unsigned)n_jobs), dim3(512), 0, stream, stash, stash_rows, M, jobs, slabs, step_inc, bounds);
-    else    hipLaunchKernelGGL(k_wgrad<false>, dim3((unsigned)n_jobs), dim3(512), 0, stream, stash, stash_rows, M, jobs, slabs, step_inc, bounds);
+    if (!bounds) { tn_set_error("wgrad: the stash's bound words are required"); return TNERF_EINVAL; }
+    if (mode == 1)      hipLaunchKernelGGL(k_wgrad<1>, dim3((unsigned)n_jobs), dim3(512), 0, stream, stash, stash_rows, M, jobs, slabs, step_inc, bounds);
+    else if (mode == 0) hipLaunchKernelGGL(k_wgrad<0>, dim3((unsigned)n_jobs), dim3(512), 0, stream, stash, stash_rows, M, jobs, slabs, step_inc, bounds);
+    else                hipLaunchKernelGGL(k_wgrad<2>, dim3((unsigned)n_jobs), dim3(512), 0, stream, stash, stash_rows, M, jobs, slabs, step_inc, bounds);
     TN_HIP_CHECK_LAUNCH("wgrad");
     return TNERF_OK;
 }

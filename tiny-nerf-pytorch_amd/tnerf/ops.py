@@ -332,8 +332,16 @@ class ModelState:
 
     def __init__(self, in_dim: int, hidden: int, depth: int, skip_at: int, device: torch.device, flags: Optional[int] = None):
         self.device = device
+        # "auto" (matrix_pipe=None): the x3 pipe while the weights are inside its domain (x3_domain below), the fp32-MFMA kernels from the
+        # moment they are not; an explicit matrix_pipe="x3" / "fp32_mfma" is never changed.
+        self.pipe_policy = "auto" if flags is None else "fixed"
+        self.pipe_switched: Optional[str] = None           # why an "auto" model left the x3 pipe (None: it has not)
+        self._x3_packs = 0
         if flags is None:      # TNERF_FP32_PIPE=mfma32 selects the plain fp32-MFMA kernels for models built from now on (A/B runs)
-            flags = _l.FLAG_FP32_MFMA if os.environ.get("TNERF_FP32_PIPE", "").lower() in ("mfma32", "fp32", "mfma") else 0
+            env = os.environ.get("TNERF_FP32_PIPE", "").lower()
+            flags = _l.FLAG_FP32_MFMA if env in ("mfma32", "fp32", "mfma") else 0
+            if env in ("mfma32", "fp32", "mfma", "x3"):
+                self.pipe_policy = "fixed"
         self.desc = _l.MlpDesc(int(in_dim), int(hidden), int(depth), int(skip_at), int(flags))
         n = _l.load().tnerf_param_count(C.byref(self.desc))
         if n < 0:
@@ -410,7 +418,8 @@ class ModelState:
         return b
 
     def repack_x3(self, key=None) -> "_X3State":
-        """x3 chain (fp32-grade products on the fp16 matrix pipe): (re)build the two-piece record stream, its scale records and the fp32 biases."""
+        """x3 chain (fp32-grade products on the fp16 matrix pipe): (re)build the two-piece record stream, its scale records and the fp32 biases.
+        An "auto" model checks the x3 pipe's domain on its first pack and on every 64th after it (one 72-byte read-back)."""
         if self.x3 is None:
             self.x3 = _X3State(self)
         b = self.x3
@@ -418,7 +427,48 @@ class ModelState:
             _l.call("tnerf_mlp_pack_x3", C.byref(self.desc), self.flat.data_ptr(), b.table.data_ptr(), b.packed.data_ptr(),
                     _stream(self.device))
             b.key = key
+            if self.pipe_policy == "auto" and self._x3_packs % 64 == 0:
+                self.check_x3_domain()
+            self._x3_packs += 1
         return b
+
+    @property
+    def uses_x3(self) -> bool:
+        """True if the fused fp32 paths of this model run on the x3 kernels right now."""
+        return self.x3_capable and not (self.desc.flags & _l.FLAG_FP32_MFMA)
+
+    def x3_domain(self):
+        """Per layer (index depth = the heads): (share of the nonzero weights below 2^-13 max|W_l|, share of the nonzero biases below
+        2^-14 max|b_l|) for the parameters as they are now, against the maxima in the x3 stream's scale records (include/tnerf.h,
+        tnerf_x3_domain_counts).  Synchronises."""
+        b = self.x3 if self.x3 is not None else self.repack_x3()
+        counts = torch.zeros(4 * (self.desc.depth + 1), dtype=torch.int32, device=self.device)
+        _l.call("tnerf_x3_domain_counts", C.byref(self.desc), self.flat.data_ptr(), b.table.data_ptr(), b.packed.data_ptr(), counts.data_ptr(),
+                _stream(self.device))
+        c = counts.cpu().numpy().astype(np.int64).reshape(-1, 4)
+        return [(float(r[1]) / max(1, int(r[0])), float(r[3]) / max(1, int(r[2]))) for r in c]
+
+    X3_MAX_SMALL_SHARE = 1.0 / 64.0        # of a layer's weights (or biases) that may sit below the x3 pipe's full-precision range
+
+    def check_x3_domain(self) -> bool:
+        """True if the weights are inside the x3 pipe's domain.  Otherwise an "auto" model switches to the fp32-MFMA kernels (for good:
+        desc.flags gains TNERF_FLAG_FP32_MFMA, every later call of the fused paths takes them) and says so once."""
+        if not self.uses_x3:
+            return True
+        shares = self.x3_domain()
+        bad = [(l, w, bb) for l, (w, bb) in enumerate(shares) if w > self.X3_MAX_SMALL_SHARE or bb > 0.5]
+        if not bad:
+            return True
+        if self.pipe_policy == "auto":
+            l, w, bb = bad[0]
+            self.pipe_switched = (f"layer {l}: {100 * w:.1f} % of the weights are more than 2^13 below max|W| and {100 * bb:.1f} % of the biases more than "
+                                  f"2^14 below max|b|")
+            self.desc.flags |= _l.FLAG_FP32_MFMA
+            import warnings
+            warnings.warn("TinyNeRF (HIP): the weights left the domain in which the x3 matrix pipe (three fp16 partial products) is fp32-grade — "
+                          + self.pipe_switched + "; this model now runs on the plain fp32-MFMA kernels (about 2.4x slower).  "
+                          "matrix_pipe='x3' keeps the x3 pipe regardless.", RuntimeWarning, stacklevel=3)
+        return False
 
     def grad_views(self, params):
         return [self.grad[o:o + p.numel()].view(p.shape) for p, o in zip(params, self.offsets)]
@@ -504,6 +554,8 @@ class _MlpFn(torch.autograd.Function):
         x3 = None
         if st.x3_capable and not (st.desc.flags & _l.FLAG_FP32_MFMA):
             x3 = st.repack_x3(("pack", st.packed_key) if st.packed_key is not None else None)
+            if not st.uses_x3:                     # an "auto" model has just left the x3 pipe's domain (ModelState.check_x3_domain)
+                x3 = None
         _l.call("tnerf_mlp_fwd_x3" if x3 is not None else "tnerf_mlp_fwd", C.byref(st.desc),
                 (x3 if x3 is not None else st).packed.data_ptr(), x.data_ptr(), M, rgb.data_ptr(), sigma.data_ptr(),
                 lease.buf.data_ptr() if train else None, plan.Mp if train else 0, _stream(dev))
@@ -610,6 +662,8 @@ class _FusedRaysFn(torch.autograd.Function):
         x3 = None
         if st.x3_capable and not (st.desc.flags & _l.FLAG_FP32_MFMA):
             x3 = st.repack_x3(("pack", st.packed_key) if st.packed_key is not None else None)
+            if not st.uses_x3:                     # an "auto" model has just left the x3 pipe's domain (ModelState.check_x3_domain)
+                x3 = None
         if train:
             plan = st.plan(R * S)
             lease = plan.lease()
@@ -703,6 +757,7 @@ def render_camera_fused(st: ModelState, c2w, H, W, focal, pix_first, n_rays, nea
         if x3_key is None and st.packed_key is not None:
             x3_key = ("pack", st.packed_key)
         b = st.repack_x3(x3_key)              # fp32-grade results, products on the fp16 matrix pipe (x3)
+    if st.uses_x3:                            # (an "auto" model may have left the x3 pipe's domain in that pack)
         _l.call("tnerf_render_fused_cam_x3", C.byref(st.desc), b.packed.data_ptr(), C.byref(cam), int(n_rays), S, ztab.data_ptr(), rnd,
                 _ptr(tr), seed, off, int(bool(white_bkgd)), comp.data_ptr(), depth.data_ptr(), acc.data_ptr(), _stream(dev))
         return comp, depth, acc

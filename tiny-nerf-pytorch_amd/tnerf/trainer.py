@@ -153,7 +153,8 @@ class FusedTrainer:
         st = self.st
         if (st.desc.flags & _l.FLAG_FP32_MFMA) or not st.x3_capable:
             return None
-        return st.repack_x3(tuple(p._version for p in self.model._param_list())).packed.data_ptr()
+        b = st.repack_x3(tuple(p._version for p in self.model._param_list()))
+        return b.packed.data_ptr() if st.uses_x3 else None          # (an "auto" model may have left the x3 pipe's domain in that pack)
 
     @torch.no_grad()
     def step_camera(self, pose, H: int, W: int, focal: float, inds, pixels, t_rand: Optional[torch.Tensor] = None, philox=None,
@@ -275,8 +276,9 @@ class DatasetTrainer:
             tab = st.pack_table.cpu().numpy()
             if st.x3_capable and not (st.desc.flags & _l.FLAG_FP32_MFMA):    # forward on the x3 chain kernel; the finishing kernel keeps its stream current
                 x3 = st.repack_x3(tuple(p._version for p in model._param_list()))
-                self._x3_packed, self._x3_table = x3.packed, x3.table
-                self._x3_scatter = torch.from_numpy(_scatter_table(x3.table.cpu().numpy(), st.n_params)).to(dev)
+                if st.uses_x3:                                                # (an "auto" model whose weights are outside the x3 domain has just switched)
+                    self._x3_packed, self._x3_table = x3.packed, x3.table
+                    self._x3_scatter = torch.from_numpy(_scatter_table(x3.table.cpu().numpy(), st.n_params)).to(dev)
         else:
             b = st.repack_bf16(tuple(p._version for p in model._param_list()))
             self._packed = b.packed
@@ -369,6 +371,14 @@ class DatasetTrainer:
             if st.x3 is not None:
                 st.x3.key = None
 
+    X3_CHECK_EVERY = 256
+
+    def _leave_x3(self):
+        """The model's flags now ask for the fp32-MFMA kernels: drop the x3 stream (the fp32 fragment copy has been kept current by every
+        update) and the captured graphs (their kernels are the x3 ones)."""
+        self._x3_packed = self._x3_scatter = None
+        self._drop_graph()
+
     @torch.no_grad()
     def step(self):
         """One training step.  Returns (loss [device scalar: this rank's share of the batch MSE], comp_rgb [R,3]).
@@ -382,6 +392,12 @@ class DatasetTrainer:
             raise RuntimeError(f"DatasetTrainer: Adam's step count ({self.opt._t}) no longer equals the loop's ({self._calls + self._start_step}): "
                                "the optimizer was stepped outside this trainer; one device counter serves both")
         self._sync_params()
+        # an "auto" model: every X3_CHECK_EVERY steps the x3 pipe's domain is checked against the weights as they are now (one small
+        # kernel + a 72-byte read-back); outside it the step continues on the fp32-MFMA kernels (ops.ModelState.check_x3_domain)
+        if self._x3_packed is not None and st.pipe_policy == "auto" and self._calls > 0 and self._calls % self.X3_CHECK_EVERY == 0:
+            st.check_x3_domain()
+        if self._x3_packed is not None and not st.uses_x3:      # (the check above, or a re-pack of caller-edited parameters, switched the model)
+            self._leave_x3()
         full = _l.PHASE_GRADIENT | _l.PHASE_REDUCE | _l.PHASE_UPDATE
         if not self._want_graph:
             if self.world > 1:                      # gradient -> all-reduce -> update, six eager launches
