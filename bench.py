@@ -509,6 +509,40 @@ def run(args):
         run_["tr"] = tr
         del m32, o32, t32
 
+    # ---- N > 1: the OTHER scaling mode and what the exchange costs, in the same line (a SCALE run needs no extra flags).
+    # `value` above is the contract number (weak unless --scaling strong).  Here: the same step with the global batch fixed at 4096 rays
+    # (strong) resp. 4096 per rank (weak), and both again WITHOUT the all-reduce — the difference is the exposed (non-overlapped) part of
+    # the exchange; allreduce.us_per_step above is the collective on its own.
+    if world > 1 and not args.no_extra and not args.parity_rng:
+        def other_mode():
+            res = {}
+            for mode in ("weak", "strong"):
+                Rg = world * RAYS if mode == "weak" else RAYS
+                lo_, hi_ = tdist.shard_bounds(Rg, rank, world)
+                if hi_ - lo_ < 1:
+                    res[mode] = {"error": f"{Rg} rays do not split over {world} ranks"}
+                    continue
+                mdl, op, t_ = make_trainer("fp32", rays_global=Rg)
+                run_.update(tr=t_, R_global=Rg, lo=lo_, hi=hi_)
+                state["step"] = 0
+                d_ex = timed(args.warmup, args.steps)
+                t_.skip_exchange_for_timing = True
+                d_no = timed(args.warmup, args.steps)
+                t_.skip_exchange_for_timing = False
+                res[mode] = {"value": Rg * args.steps / d_ex, "unit": "rays/s", "ms_per_step": d_ex / args.steps * 1e3, "rays_per_step_global": Rg,
+                             "rays_per_gpu": hi_ - lo_, "ms_per_step_without_allreduce": d_no / args.steps * 1e3,
+                             "exposed_allreduce_us": (d_ex - d_no) / args.steps * 1e6}
+                del mdl, op, t_
+            run_.update(tr=tr, R_global=R_global, lo=lo, hi=hi)
+            res["how"] = ("each mode: W warm-up + K timed steps between barrier + synchronize fences, max over ranks, with the all-reduce and (ranks' weights "
+                          "then diverge: timing only, on throw-away models) without it; one un-bucketed all-reduce of the flat gradient per step between two "
+                          "captured graphs — bucketing it behind the weight-gradient kernel does not pay in this design (DESIGN.md, multi-GPU)")
+            return res
+        try:
+            out["scaling_modes"] = other_mode()
+        except Exception as e:
+            out["scaling_modes"] = {"error": f"{type(e).__name__}: {e}"}
+
     # ---- strong-scaling loads on one GPU: the step at 2048 / 1024 / 512 rays (what each of N = 2 / 4 / 8 ranks runs when 4096 rays are
     # sharded) + the cost of an RCCL all-reduce of the flat gradient in a one-rank group -> the efficiency these predict
     if not args.no_extra and world == 1 and rank == 0:

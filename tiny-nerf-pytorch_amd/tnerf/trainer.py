@@ -372,6 +372,7 @@ class DatasetTrainer:
                 st.x3.key = None
 
     X3_CHECK_EVERY = 256
+    skip_exchange_for_timing = False       # bench.py only: N ranks step WITHOUT the all-reduce (the ranks' weights diverge) to price the exchange
 
     def _leave_x3(self):
         """The model's flags now ask for the fp32-MFMA kernels: drop the x3 stream (the fp32 fragment copy has been kept current by every
@@ -444,7 +445,8 @@ class DatasetTrainer:
                 else:
                     a = self._args(_l.PHASE_GRADIENT | _l.PHASE_REDUCE)
                     _l.call("tnerf_train_step_dataset", C.byref(a), stream.cuda_stream)
-                _dist.all_reduce_sum_(st.grad)          # ordered on `stream` (torch's collective waits for / is waited on by the current stream)
+                if not self.skip_exchange_for_timing:
+                    _dist.all_reduce_sum_(st.grad)      # ordered on `stream` (torch's collective waits for / is waited on by the current stream)
                 if self._graph is not None:
                     _l.call("tnerf_graph_launch", self._graph_update, stream.cuda_stream)
                 else:
