@@ -652,6 +652,51 @@ def test_degenerate_weights_through_the_x3_kernels(mods, dev, case):
     assert max(relmax(p.grad.cpu(), q) for p, q in zip(m.parameters(), go)) <= 5e-5
 
 
+# ------------------------------------------------------------------ gradients w.r.t. tensor near / far bounds
+@pytest.mark.parametrize("randomized", [True, False])
+def test_gradients_wrt_tensor_near_far(mods, dev, randomized):
+    """Reference src/sampling.py:17,25: near / far given as tensors are ordinary autograd leaves.  d(loss)/d(near), d(loss)/d(far) through
+    stratified_samples -> encoder -> MLP -> volume_render (colour, depth and opacity terms; per-ray bounds of shape (R,1) and a shared
+    scalar bound) against the oracle's autograd, with the fp64 evaluation as the yardstick."""
+    cfg, params = golden_params("4x128")
+    L, skip, S, R = cfg["L"], cfg["skip_at"], 48, 60
+    g = torch.Generator().manual_seed(3)
+    d0 = torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=-1)
+    o0 = -4.0 * d0 + 0.1 * torch.randn(R, 3, generator=g)
+    near0 = 2.0 + 0.3 * torch.rand(R, 1, generator=g); far0 = torch.tensor(6.0)
+    u = torch.rand(R, S, generator=g)
+    wc, wd, wa = torch.randn(R, 3, generator=g), torch.randn(R, 1, generator=g) * 0.1, torch.randn(R, 1, generator=g)
+
+    def oracle(dtype):
+        ps = [p.to(dtype) for p in params]
+        nr, fr = near0.to(dtype).clone().requires_grad_(True), far0.to(dtype).clone().requires_grad_(True)
+        z, pts = O.stratified(nr, fr, S, o0.to(dtype), d0.to(dtype), u.to(dtype) if randomized else None)
+        rgb, sig = O.mlp_forward(ps, O.posenc(pts.reshape(-1, 3), L, True), skip)
+        comp, depth, acc, _ = O.composite(rgb.reshape(R, S, 3), sig.reshape(R, S, 1), z, d0.to(dtype))
+        loss = (comp * wc.to(dtype)).sum() + (depth * wd.to(dtype)).sum() + (acc * wa.to(dtype)).sum()
+        return torch.autograd.grad(loss, [nr, fr])
+    gn32, gf32 = oracle(torch.float32)
+    gn64, gf64 = oracle(torch.float64)
+    model = make_model(mods, cfg, params, dev)
+    enc = mods["encoding"].PositionalEncoding(L, True).to(dev)
+    nr, fr = near0.clone().to(dev).requires_grad_(True), far0.clone().to(dev).requires_grad_(True)
+    torch.manual_seed(0)
+    if randomized:                                                  # the drop-in draws its own jitter: hand it ours through the op
+        z, pts = mods["ops"].sample_along_rays_per_ray(nr.detach(), fr.detach(), S, o0.to(dev), d0.to(dev), True, t_rand=u.to(dev))
+        z = mods["ops"].attach_depth_grad(nr, fr, z, u.to(dev))
+        pts = mods["ops"].attach_points_grad(o0.to(dev), d0.to(dev), z, pts)
+    else:
+        z, pts = mods["sampling"].stratified_samples(nr, fr, S, o0.to(dev), d0.to(dev), randomized=False)
+    assert z.requires_grad and pts.requires_grad
+    rgb, sigma = model(enc(pts.reshape(-1, 3)))
+    comp, depth, acc, _ = mods["volume"].volume_render(rgb.reshape(R, S, 3), sigma.reshape(R, S, 1), z, d0.to(dev))
+    ((comp * wc.to(dev)).sum() + (depth * wd.to(dev)).sum() + (acc * wa.to(dev)).sum()).backward()
+    assert nr.grad.shape == near0.shape and fr.grad.shape == far0.shape
+    for name, a, b, c in (("near", nr.grad, gn32, gn64), ("far", fr.grad, gf32, gf64)):
+        t_hip, t_ref = relmax(a.cpu().double(), c), relmax(b.double(), c)
+        assert t_hip <= 2.0 * t_ref + 2e-5, (name, t_hip, t_ref)
+
+
 # ------------------------------------------------------------------ outliers INSIDE a layer (the x3 scheme's scales are per layer / per sample)
 OUTLIER_CASES = ["weight_x2^14", "weight_x2^20", "row_x2^-14", "row_x2^-20", "input_feature_x2^-20", "bias_x2^20", "bias_x2^12_one_layer_tiny_acts",
                  "column_x2^-20", "weight_x2^20_and_row_x2^-20"]

@@ -19,6 +19,8 @@ def stratified_samples(near, far, n_samples, rays_o, rays_d, randomized=True):
         z_vals, pts = ops.sample_along_rays_per_ray(near, far, int(n_samples), rays_o, rays_d, bool(randomized), t_rand)
     else:
         z_vals, pts, _ = ops.sample_along_rays(float(near), float(far), int(n_samples), rays_o, rays_d, bool(randomized), t_rand)
-    # rays that require grad (a learned pose): pts = o + d z is differentiable in o and d, as in the reference (sampling.py:27);
-    # the depths themselves depend on near / far and the jitter only
+    # tensor bounds that require grad: the depths are linear in them (reference sampling.py:17,25 is plain autograd)
+    z_vals = ops.attach_depth_grad(near, far, z_vals, t_rand)
+    # rays that require grad (a learned pose): pts = o + d z is differentiable in o and d — and, through z, in the bounds — as in
+    # the reference (sampling.py:27)
     return z_vals, ops.attach_points_grad(rays_o, rays_d, z_vals, pts)

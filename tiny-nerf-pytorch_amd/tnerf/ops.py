@@ -259,6 +259,51 @@ def attach_points_grad(rays_o, rays_d, z_vals, pts):
     return pts
 
 
+class _DepthsFn(torch.autograd.Function):
+    """z_vals as a function of tensor near / far bounds (reference src/sampling.py:16-25 is ordinary autograd, so bounds that
+    require grad receive one).  The depths themselves are the sampling kernel's (bit-exact bins); they are LINEAR in the bounds,
+    z_s = near a_s + far b_s with a = lerp of (1 - t), b = lerp of t through the same bin midpoints and jitter, so the backward is
+    d near = sum_s g_s a_s, d far = sum_s g_s b_s — a handful of elementwise torch ops on (R, S) tensors, summed to the bounds' shapes."""
+
+    @staticmethod
+    def forward(ctx, near_t, far_t, z_vals, t_rand):
+        ctx.shapes = (near_t.shape, far_t.shape)
+        ctx.save_for_backward(t_rand if t_rand is not None else torch.empty(0, device=z_vals.device))
+        ctx.randomized = t_rand is not None
+        return z_vals.view_as(z_vals)
+
+    @staticmethod
+    def backward(ctx, g_z):
+        (u,) = ctx.saved_tensors
+        R, S = g_z.shape
+        t = torch.linspace(0.0, 1.0, steps=S, device=g_z.device, dtype=torch.float32)
+
+        def coeff(c):                                  # the reference's own arithmetic applied to the coefficient row c (S,)
+            c = c.expand(R, S)
+            if not ctx.randomized:
+                return c
+            mid = 0.5 * (c[:, :-1] + c[:, 1:])
+            hi = torch.cat([mid, c[:, -1:]], dim=-1); lo = torch.cat([c[:, :1], mid], dim=-1)
+            return lo + (hi - lo) * u
+        g = g_z.float()
+        d_near = (g * coeff(1.0 - t)).sum(-1, keepdim=True) if ctx.needs_input_grad[0] else None
+        d_far = (g * coeff(t)).sum(-1, keepdim=True) if ctx.needs_input_grad[1] else None
+        ns, fs = ctx.shapes
+        return (d_near.sum_to_size(ns) if d_near is not None else None, d_far.sum_to_size(fs) if d_far is not None else None, None, None)
+
+
+def attach_depth_grad(near, far, z_vals, t_rand):
+    """z_vals as drawn by the sampling kernel, re-attached to autograd when near / far are tensors that require grad."""
+    nt = near if isinstance(near, torch.Tensor) else None
+    ft = far if isinstance(far, torch.Tensor) else None
+    if torch.is_grad_enabled() and ((nt is not None and nt.requires_grad) or (ft is not None and ft.requires_grad)):
+        dev = z_vals.device
+        nt = nt if nt is not None else torch.tensor(float(near), device=dev)
+        ft = ft if ft is not None else torch.tensor(float(far), device=dev)
+        return _DepthsFn.apply(nt, ft, z_vals, t_rand)
+    return z_vals
+
+
 class _PosEncFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xf, num_freqs, include_input):
