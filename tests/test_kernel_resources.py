@@ -31,7 +31,9 @@ def resources(src):
 
 
 @pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not on PATH")
-@pytest.mark.parametrize("src,prefixes", [("mlpx3.hip", ("k_renderx3", "k_dgradx3", "k_mlpx3_fwd", "k_mlpx3_bwd")), ("wgrad.hip", ("k_wgrad", "k_finish"))])
+@pytest.mark.parametrize("src,prefixes", [("mlpx3.hip", ("k_renderx3", "k_dgradx3", "k_mlpx3_fwd", "k_mlpx3_bwd", "k_tilex3_fwd", "k_tilex3_bwd", "k_compx3")),
+                                          ("wgrad.hip", ("k_wgrad", "k_finish")),
+                                          ("mlp_fwd.hip", ("k_render_fused", "k_mlp_fwd")), ("mlp_bwd.hip", ("k_train_bwd", "k_mlp_bwd"))])
 def test_hot_path_kernels_use_no_scratch(src, prefixes):
     res = resources(src)
     hit = {n: r for n, r in res.items() if any(p in n for p in prefixes)}
@@ -39,8 +41,8 @@ def test_hot_path_kernels_use_no_scratch(src, prefixes):
     for name, r in hit.items():
         assert r["scratch"] == 0, (name, r)                    # nothing lives in memory that was meant to live in registers
         # "VGPRs Spill" also counts values the allocator parks in a FREE accumulator register (v_accvgpr_write / read, no memory):
-        # the 256-wide dgrad kernels keep one loop-invariant address there.  Anything beyond that would be real pressure.
-        assert r["vgpr_spill"] <= 1, (name, r)
+        # the 256-wide dgrad kernels keep one loop-invariant address there (the fp32-MFMA ones two).  Anything beyond that would be real pressure.
+        assert r["vgpr_spill"] <= 2, (name, r)
 
 
 @pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not on PATH")

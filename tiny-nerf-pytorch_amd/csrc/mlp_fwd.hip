@@ -150,11 +150,11 @@ __global__ __launch_bounds__(256, HID == 128 ? 2 : 1) void k_mlp_fwd(FwdArgs a) 
 }
 
 // ------------------------------------------------------------------------------ fused rays
-#ifndef TN_NE32_WAVES
-#define TN_NE32_WAVES 2      // waves per SIMD of the 128-wide kernels with 32 input steps (L = 10): 2 = 256 registers (25 spilled), 1 = 512
-#endif
+#ifndef TN_NE32_TRAIN_WAVES
+#define TN_NE32_TRAIN_WAVES 1      // waves per SIMD of the 128-wide TRAINING forward with 32 input steps (L = 10): at 2 (256 registers) it
+#endif                             // kept 25 values in scratch memory; 1 = the 512-register budget, nothing spilled (tests/test_kernel_resources.py)
 template <int HID, int NE, bool TRAIN>
-__global__ __launch_bounds__(256, HID == 128 ? (NE == 32 ? TN_NE32_WAVES : 2) : 1) void k_render_fused(FwdArgs a) {
+__global__ __launch_bounds__(256, HID == 128 ? (NE == 32 && TRAIN ? TN_NE32_TRAIN_WAVES : 2) : 1) void k_render_fused(FwdArgs a) {
     const int lane = tn_lane();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t ray = (int64_t)blockIdx.x * 4 + wave;

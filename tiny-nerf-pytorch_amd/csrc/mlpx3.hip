@@ -578,6 +578,226 @@ __global__ TX_PLAIN_F32 __launch_bounds__(TxCfg<HID>::NW * 64, 1) void k_mlpx3_b
     tx_bound_flush<NW>(lds_bnd0, a.b.stash + TN_BOUND_OFF(a.b.L, a.b.Mp), TNB_DZ(0), lane, wave);
 }
 
+// ------------------------------------------------------------------------------------------------ sub-ray work units
+// A ray is a wave in the kernels above, so a batch of fewer rays than the chip has waves (4 x 256 = 1024) leaves CUs idle while
+// every wave still walks its ray's tiles one after the other: 512 rays x 64 samples occupy half the chip for two tile times.  With
+// 32-sample TILES as the unit, 512 rays are 1024 tiles — every wave one tile.  What couples the tiles of a ray is the compositing
+// (reference src/volume.py:30-36) and its backward; both are a few hundred flops per sample, so they move into a kernel of
+// their own that runs between the tile kernels, one wave per ray, on the head outputs the forward tiles left in the stash:
+//   k_tilex3_fwd  tile -> network -> stash (inputs, activations, sign bits, head outputs)
+//   k_compx3      ray  -> compositing forward (exactly the arithmetic of k_renderx3: same segment scans, bit-identical colours),
+//                         loss gradient, compositing backward (exactly k_dgradx3's) -> the head gradients into the stash
+//   k_tilex3_bwd  tile -> head gradients from the stash -> the dgrad chain (tx_bwd_tile)
+// The launchers take this route when rays < waves (tnx3_tile_units); results are bit-identical to the ray kernels'.
+template <int HID>
+__global__ TX_PLAIN_F32 __launch_bounds__((TxCfg<HID, true>::NW * 64), 1) void k_tilex3_fwd(FwdX3Args a) {
+    constexpr int NW = TxCfg<HID, true>::NW;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    const int lane = tn_lane();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int j = lane & 31, h = lane >> 5;
+    RaySource rs = a.f.rs; SampleArgs sa = a.f.sa;
+    tn_resolve_step(rs, sa);
+    const int S = sa.S, Lf = a.n.Lf, nt = (S + 31) / 32;
+    PipeX p;
+    unsigned char* lds_bnd0 = lds + TX_BND_OFF(a.n, NW, true);
+    unsigned char* lds_bnd = lds_bnd0 + lane * 4;
+    tx_prologue<NW, true>(p, lds, a.packed3, a.n, a.packed3, a.n.n_stage, lane, wave, lds_bnd0);
+    unsigned char* E = lds + TX_RING + TX_CONST_BYTES(a.n) + wave * TX_ELDS_WAVE + lane * 16;
+    TxProf pf;
+    const int64_t R = a.f.R, units = R * nt, n_groups = (units + NW - 1) / NW;
+    for (int64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {         // every wave of the workgroup runs every pass (stage barriers)
+        const int64_t u = g * NW + wave;
+        const bool uvalid = u < units;
+        const int64_t uc = uvalid ? u : units - 1;
+        const int64_t ray = uc / nt;
+        const int sb = (int)(uc - ray * nt) * 32;
+        float ro_[3], rd_[3];
+        tn_fetch_ray(rs, ray, ro_, rd_);
+        const int s = sb + j;
+        const bool valid = uvalid && s < S;
+        const int sc = s < S ? s : S - 1;
+        const float z = tn_depth(sa, ray, sc);
+        const float px = tn_point(ro_[0], rd_[0], z), py = tn_point(ro_[1], rd_[1], z), pz = tn_point(ro_[2], rd_[2], z);
+        EncX Er;
+        float encf[8 * TN16_KE];
+        tx_encode(px, py, pz, Lf, h, encf);
+        TxIn in;
+        in.encmax = fmaxf(fmaxf(fabsf(px), fabsf(py)), fmaxf(fabsf(pz), 1.0f));
+        in.l1 = __builtin_fmaf(3.0f, in.encmax, (float)(6 * Lf));
+        in.te = tx_scale_exp(in.encmax);
+        const int64_t m = ray * S + sc;
+        tx_stash_input(a, h, lane, encf, m, valid);
+        tx_split_input(Er, tx_exp2i(in.te), [&](auto ac) TN_INLINE_LAMBDA { return encf[decltype(ac)::value]; });
+        tx_store_input(E, Er);
+        float res[4];
+        tx_mlp_tile<HID, true>(p, lds, a, h, lane, E, in, m, valid, res, pf, lds_bnd);
+        int lane2 = lane; asm volatile("" : "+v"(lane2));             // (as k_mlpx3_fwd: the index is formed again behind the tile)
+        const int s2 = sb + (lane2 & 31);
+        if (uvalid && s2 < S && (lane2 >> 5) == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) tn_stash_at(a.f.stash, a.f.L.stash_rows, ray * S + s2)[(a.f.L.out_row0 + i) * 32] = res[i];
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    tx_bound_flush<NW>(lds_bnd0, a.f.stash + TN_BOUND_OFF(a.f.L, a.f.Mp), 0, lane, wave);
+    if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<unsigned*>(a.f.stash + TN_BOUND_OFF(a.f.L, a.f.Mp))[TNB_TAG] = TN_TAG_X3;
+}
+
+// One wave per ray.  FWD: compositing forward from the stash's head outputs -> comp (+ depth, acc), the loss gradient if a target is
+// given.  BWD: the compositing backward for g = dL/dcomp (the loss gradient just formed, or g_comp) -> head gradients into the stash.
+struct CompX3Args {
+    MlpLayout L; float* stash; int64_t Mp;
+    RaySource rs; SampleArgs sa; int64_t R; int32_t white;
+    float* comp; float* depth; float* acc; LossArgs loss;          // FWD
+    const float* g_comp; int32_t g_stride;                         // BWD without FWD
+};
+template <bool FWD, bool BWD>
+__global__ __launch_bounds__(256) void k_compx3(CompX3Args a) {
+    const int lane = tn_lane();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t ray = (int64_t)blockIdx.x * 4 + wave;
+    if (ray >= a.R) return;
+    RaySource rs = a.rs; SampleArgs sa = a.sa;
+    tn_resolve_step(rs, sa);
+    const int S = sa.S, nseg = (S + 63) / 64;
+    float ro_[3], rd_[3];
+    tn_fetch_ray(rs, ray, ro_, rd_);
+    const float dn = tn_norm3(rd_[0], rd_[1], rd_[2]);
+    const int orow = a.L.out_row0 * 32; const int64_t SR = a.L.stash_rows;
+    const int64_t mray = ray * S;
+    auto outv = [&](int i, int sc) TN_INLINE_LAMBDA { return tn_stash_at(a.stash, SR, mray + sc)[orow + 32 * i]; };
+    float gr = 0.f, gg = 0.f, gb = 0.f;
+    if constexpr (FWD) {       // k_renderx3's compositing, segment by segment                       reference src/volume.py:18-42
+        float T_in = 1.0f, cr = 0.f, cg = 0.f, cb = 0.f, cd = 0.f, ca = 0.f;
+        for (int s0 = 0; s0 < S; s0 += 64) {
+            const int s = s0 + lane;
+            const bool ok = s < S;
+            const int sc = ok ? s : S - 1;
+            const float v0 = outv(0, sc), v1 = outv(1, sc), v2 = outv(2, sc), v3 = outv(3, sc);
+            const float z = tn_depth(sa, ray, sc);
+            const float zn = (s + 1 < S) ? tn_depth(sa, ray, s + 1) : z;
+            const CompTerms t = tn_comp_terms(ok ? v3 : 0.0f, z, zn, s == S - 1, dn);
+            const float om = ok ? t.om : 1.0f;
+            const float incl = tn_wave_scan_mul(om, lane);
+            float excl = __shfl_up(incl, 1, 64);
+            if (lane == 0) excl = 1.0f;
+            const float T = T_in * excl;
+            const float w = ok ? t.alpha * T : 0.0f;
+            cr += w * v0; cg += w * v1; cb += w * v2; cd += w * z; ca += w;
+            T_in *= __shfl(incl, 63, 64);
+        }
+        cr = tn_wave_sum(cr); cg = tn_wave_sum(cg); cb = tn_wave_sum(cb); cd = tn_wave_sum(cd); ca = tn_wave_sum(ca);
+        const float bg = a.white ? (1.0f - ca) : 0.0f;
+        if (lane == 0) {
+            a.comp[3 * ray] = cr + bg; a.comp[3 * ray + 1] = cg + bg; a.comp[3 * ray + 2] = cb + bg;
+            if (a.depth) a.depth[ray] = cd;
+            if (a.acc) a.acc[ray] = ca;
+            if (a.loss.ray_ws) tn_ray_loss(a.loss, rs, ray, cr + bg, cg + bg, cb + bg);      // train.py:122
+        }
+        if constexpr (BWD) {   // every lane needs the gradient lane 0 has just stored: the same three operations, redone in registers
+            int64_t row = ray;
+            if (rs.c2w) { const int64_t pp = tn_ray_pixel(rs, ray); row = rs.step ? (int64_t)rs.image * rs.H * rs.W + pp : pp; }
+            else if (a.loss.target_index) row = a.loss.target_index[ray];
+            gr = (2.0f * ((cr + bg) - a.loss.target[3 * row])) * a.loss.inv_denom;
+            gg = (2.0f * ((cg + bg) - a.loss.target[3 * row + 1])) * a.loss.inv_denom;
+            gb = (2.0f * ((cb + bg) - a.loss.target[3 * row + 2])) * a.loss.inv_denom;
+        }
+    } else {
+        const int64_t gi = (int64_t)a.g_stride * ray;
+        gr = a.g_comp[gi]; gg = a.g_comp[gi + 1]; gb = a.g_comp[gi + 2];
+    }
+    if constexpr (BWD) {       // k_dgradx3's compositing backward; the head gradients go to the stash instead of into the tile walk
+        const float gbg = a.white ? (gr + gg + gb) : 0.0f;
+        float segprod = 1.0f;
+        if (nseg > 1) {
+            for (int sg_ = 0; sg_ < nseg; ++sg_) {
+                const int s = sg_ * 64 + lane; const bool ok = s < S; const int sc = ok ? s : S - 1;
+                const float z = tn_depth(sa, ray, sc);
+                const float zn = (s + 1 < S) ? tn_depth(sa, ray, s + 1) : z;
+                const CompTerms t = tn_comp_terms(ok ? outv(3, sc) : 0.f, z, zn, s == S - 1, dn);
+                const float pr = tn_wave_prod(ok ? t.om : 1.0f);
+                if (lane == sg_) segprod = pr;
+            }
+        }
+        const float seg_incl = tn_wave_scan_mul(segprod, lane);
+        float seg_T = __shfl_up(seg_incl, 1, 64);
+        if (lane == 0) seg_T = 1.0f;
+        float tail = 0.0f;
+        const int zrow = a.L.dzh_row0 * 32;
+        for (int sg_ = nseg - 1; sg_ >= 0; --sg_) {
+            const int s = sg_ * 64 + lane; const bool ok = s < S; const int sc = ok ? s : S - 1;
+            const float c0 = outv(0, sc), c1 = outv(1, sc), c2 = outv(2, sc);
+            const float sg = ok ? outv(3, sc) : 0.f;
+            const float z = tn_depth(sa, ray, sc);
+            const float zn = (s + 1 < S) ? tn_depth(sa, ray, s + 1) : z;
+            const CompTerms t = tn_comp_terms(sg, z, zn, s == S - 1, dn);
+            const float om = ok ? t.om : 1.0f;
+            const float incl = tn_wave_scan_mul(om, lane);
+            float excl = __shfl_up(incl, 1, 64);
+            if (lane == 0) excl = 1.0f;
+            const float T = __shfl(seg_T, sg_, 64) * excl;
+            const float w = ok ? t.alpha * T : 0.f;
+            const float dw = gr * c0 + gg * c1 + gb * c2 - gbg;
+            const float v = ok ? w * dw : 0.f;
+            const float suf = tn_wave_suffix_sum(v, lane);
+            const float after = (suf - v) + tail;
+            const float da = T * dw - after / om;
+            float d4[4];
+            d4[0] = ok ? (w * gr) * (c0 * (1.0f - c0)) : 0.f;
+            d4[1] = ok ? (w * gg) * (c1 * (1.0f - c1)) : 0.f;
+            d4[2] = ok ? (w * gb) * (c2 * (1.0f - c2)) : 0.f;
+            d4[3] = (ok && sg > 0.0f) ? (da * t.e) * t.delta : 0.f;
+            tail += __shfl(suf, 0, 64);
+            if (ok) {
+                float* q = tn_stash_at(a.stash, SR, mray + s) + zrow;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) q[32 * i] = d4[i];
+            }
+        }
+    }
+}
+
+template <int HID>
+__global__ TX_PLAIN_F32 __launch_bounds__(TxCfg<HID>::NW * 64, 1) void k_tilex3_bwd(BwdX3Args a) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    constexpr int NW = TxCfg<HID>::NW;
+    if (!tn_stash_tag_is(a.b.stash, a.b.L, a.b.Mp, TN_TAG_X3)) return;
+    const int lane = tn_lane();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    PipeX p;
+    unsigned char* lds_bnd0 = lds + TX_BND_OFF(a.n, NW, false);
+    unsigned char* lds_bnd = lds_bnd0 + lane * 4;
+    tx_prologue<NW>(p, lds, a.packed3, a.n, a.packed3 + (int64_t)a.n.n_rec * a.n.rec_frags * 1024, a.n.n_bw_stage, lane, wave, lds_bnd0);
+    const int S = a.b.sa.S, nt = (S + 31) / 32;
+    const int64_t R = a.b.R, units = R * nt, n_groups = (units + NW - 1) / NW;
+    const int zrow = a.b.L.dzh_row0 * 32;
+    for (int64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
+        const int64_t u = g * NW + wave;
+        const bool uvalid = u < units;
+        const int64_t uc = uvalid ? u : units - 1;
+        const int64_t ray = uc / nt;
+        const int s = (int)(uc - ray * nt) * 32 + (lane & 31);
+        const bool valid = uvalid && s < S;
+        const int64_t mc = ray * S + (s < S ? s : S - 1);
+        const float* q = tn_stash_at(a.b.stash, a.b.L.stash_rows, mc) + zrow;
+        float dzh[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dzh[i] = valid ? q[32 * i] : 0.0f;
+        tx_bwd_tile<HID>(p, lds, a, dzh, mc, valid, lane, lds_bnd);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    tx_bound_flush<NW>(lds_bnd0, a.b.stash + TN_BOUND_OFF(a.b.L, a.b.Mp), TNB_DZ(0), lane, wave);
+}
+
+// rays < waves: the tile route (above).  TNERF_X3_UNITS=rays / tiles overrides (A/B runs, the bitwise test of the two routes).
+static bool tnx3_tile_units(int64_t R, int32_t S, int n_cu) {
+    const char* e = getenv("TNERF_X3_UNITS");                        // (read per launch: a test flips it between two calls)
+    const int force = !e ? 0 : (e[0] == 't' ? 1 : (e[0] == 'r' ? -1 : 0));
+    if (force) return force > 0 && S > 0;
+    return S > 32 && R < (int64_t)4 * n_cu;
+}
+
 // units: rays (fused) or 32-sample tiles (mlp_only) — one per wave and pass
 int tnx3_launch_dgrad(const BwdX3Args& a, bool mlp_only, hipStream_t stream, const char* who) {
     const int dev = tn_stream_device(stream), n_cu = tn_device_cus(dev);
@@ -585,6 +805,25 @@ int tnx3_launch_dgrad(const BwdX3Args& a, bool mlp_only, hipStream_t stream, con
     const int64_t units = mlp_only ? (a.b.M + 31) / 32 : a.b.R, groups = (units + nw - 1) / nw;
     const dim3 grid((unsigned)(groups < n_cu ? groups : n_cu)), block(nw * 64);
     const size_t lds_bytes = TX_LDS_BYTES(a.n, nw, false);
+    if (!mlp_only && tnx3_tile_units(a.b.R, a.b.sa.S, n_cu)) {       // fewer rays than waves: tiles as the unit (k_tilex3_bwd)
+        CompX3Args c{};
+        c.L = a.b.L; c.stash = a.b.stash; c.Mp = a.b.Mp; c.rs = a.b.rs; c.sa = a.b.sa; c.R = a.b.R; c.white = a.b.white;
+        c.g_comp = a.b.g_comp; c.g_stride = a.b.g_stride;
+        hipLaunchKernelGGL((k_compx3<false, true>), dim3((unsigned)((a.b.R + 3) / 4)), dim3(256), 0, stream, c);
+        TN_HIP_CHECK_LAUNCH(who);
+        const int64_t tiles = a.b.R * ((a.b.sa.S + 31) / 32), tg = (tiles + nw - 1) / nw;
+        const dim3 tgrid((unsigned)(tg < n_cu ? tg : n_cu));
+#define TX_TCASE(H_)                                                                                                          \
+        if (a.n.hidden == H_) {                                                                                               \
+            static std::atomic<uint32_t> seen_[TN_MAX_DEVICES];                                                               \
+            if (int rc_ = tn_grant_dyn_lds(reinterpret_cast<const void*>(&k_tilex3_bwd<H_>), lds_bytes, dev, seen_, who)) return rc_; \
+            hipLaunchKernelGGL((k_tilex3_bwd<H_>), tgrid, block, lds_bytes, stream, a);                                       \
+            TN_HIP_CHECK_LAUNCH(who);                                                                                         \
+            return TNERF_OK;                                                                                                  \
+        }
+        TX_TCASE(256) TX_TCASE(128)
+#undef TX_TCASE
+    }
 #define TX_CASE(H_, K_, M_)                                                                                                  \
     if (a.n.hidden == H_ && mlp_only == M_) {                                                                                 \
         static std::atomic<uint32_t> seen_[TN_MAX_DEVICES];                                                                   \
@@ -624,6 +863,28 @@ int tnx3_launch_fwd(const FwdX3Args& a, bool train, hipStream_t stream, const ch
     const int64_t units = mlp_only ? (a.f.M + 31) / 32 : a.f.R, groups = (units + nw - 1) / nw;
     const dim3 grid((unsigned)(groups < n_cu ? groups : n_cu)), block(nw * 64);
     const size_t lds_bytes = TX_LDS_BYTES(a.n, nw, true);
+    if (train && !mlp_only && tnx3_tile_units(a.f.R, a.f.sa.S, n_cu)) {      // fewer rays than waves: tiles as the unit, then the rays' compositing
+        const int64_t tiles = a.f.R * ((a.f.sa.S + 31) / 32), tg = (tiles + nw - 1) / nw;
+        const dim3 tgrid((unsigned)(tg < n_cu ? tg : n_cu));
+        int launched = 0;
+#define TX_TCASE(H_)                                                                                                          \
+        if (a.n.hidden == H_) {                                                                                               \
+            static std::atomic<uint32_t> seen_[TN_MAX_DEVICES];                                                               \
+            if (int rc_ = tn_grant_dyn_lds(reinterpret_cast<const void*>(&k_tilex3_fwd<H_>), lds_bytes, dev, seen_, who)) return rc_; \
+            hipLaunchKernelGGL((k_tilex3_fwd<H_>), tgrid, block, lds_bytes, stream, a);                                       \
+            TN_HIP_CHECK_LAUNCH(who);                                                                                         \
+            launched = 1;                                                                                                     \
+        }
+        TX_TCASE(256) TX_TCASE(128)
+#undef TX_TCASE
+        if (!launched) { tn_set_error("%s: no x3 kernel for hidden=%d", who, a.n.hidden); return TNERF_EUNSUPPORTED; }
+        CompX3Args c{};
+        c.L = a.f.L; c.stash = a.f.stash; c.Mp = a.f.Mp; c.rs = a.f.rs; c.sa = a.f.sa; c.R = a.f.R; c.white = a.f.white;
+        c.comp = a.f.comp; c.depth = a.f.depth; c.acc = a.f.acc; c.loss = a.f.loss;
+        hipLaunchKernelGGL((k_compx3<true, false>), dim3((unsigned)((a.f.R + 3) / 4)), dim3(256), 0, stream, c);
+        TN_HIP_CHECK_LAUNCH(who);
+        return TNERF_OK;
+    }
 #define TX_CASE(H_, T_)                                                                                                      \
     if (a.n.hidden == H_ && train == T_) {                                                                                    \
         static std::atomic<uint32_t> seen_[TN_MAX_DEVICES];                                                                   \
