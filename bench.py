@@ -418,11 +418,11 @@ def run(args):
         dom = max(chain, key=lambda k: kern[k])                      # the MFMA-bound kernels of the step (wgrad is HBM-bound, below)
         ach = fl[dom] / (kern[dom] * 1e-3) / 1e12
         peak = PEAK_X3_TFLOPS if x3 else PEAK_F32_MFMA_TFLOPS
-        cap = measured_traffic("r03_traffic.json")
+        cap = measured_traffic("r04_traffic.json")
         out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                            "frac": ach / peak,
                            "traffic": cap[dom]["hbm_bytes"] if cap and dom in cap else None,
-                           "traffic_source": f"profiles/r03_traffic.json (PMC passes on kernel sources {cap['kernel_source_sha']})" if cap and dom in cap else None,
+                           "traffic_source": f"profiles/r04_traffic.json (PMC passes on kernel sources {cap['kernel_source_sha']})" if cap and dom in cap else None,
                            "flops_per_launch": fl[dom], "ms_per_launch": kern[dom],
                            "frac_of_fp32_mfma_peak": ach / PEAK_F32_MFMA_TFLOPS,      # north_star's yardstick (157.3 TFLOP/s): > 1 on the bf16 pipe
                            "note": ("algorithmic fp32 FLOP per launch; each product runs as 3 fp16 MFMA partial products (two-piece operands), "
@@ -614,7 +614,7 @@ def run(args):
             hbm = {"train_fwd": tiles * ((2 + DEPTH * NT) * 2048 + DEPTH * (HIDDEN // 64) * 256 + 512),
                    "dgrad": tiles * (DEPTH * NT + 1) * 2048,
                    "wgrad": tiles * wg_tiles * 2048}
-            cap16 = measured_traffic("r03_traffic_bf16.json") or {}
+            cap16 = measured_traffic("r04_traffic_bf16.json") or {}
             kern16 = {}
             for name, ms in k16.items():
                 kern16[name] = {"ms": ms, "ms_alone": k16_alone[name], "tflops": fl[name] / (ms * 1e-3) / 1e12,

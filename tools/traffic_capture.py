@@ -8,7 +8,7 @@ On the GPU box (the profiler's program goes straight after `--`):
     rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python3 bench.py --steps 5 --warmup 3 --psnr-steps 0 --no-cpu-baseline --no-extra
     rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python3 bench.py --steps 5 --warmup 3 --psnr-steps 0 --no-cpu-baseline --no-extra
     python3 tools/traffic_capture.py gpurun_out/pmc_fetch gpurun_out/pmc_write
-writes profiles/r03_traffic.json and profiles/r03_traffic_bf16.json tagged with the sha of csrc/ (bench.py reports them only
+writes profiles/r04_traffic.json and profiles/r04_traffic_bf16.json tagged with the sha of csrc/ (bench.py reports them only
 while the kernel sources are the ones that were profiled)."""
 import csv
 import glob
@@ -28,8 +28,8 @@ KERNELS = [
     ("void k_renderx3<256, false>", "fp32", "render_fwd", 1),
     ("void k_render_fused<256, 20, true>", "fp32", "train_fwd_fp32_mfma", 1),
     ("void k_train_bwd<256>", "fp32", "dgrad_fp32_mfma", 1),
-    ("void k_wgrad<true>", "fp32", "wgrad", 2),
-    ("void k_wgrad<false>", "fp32", "wgrad_fp32_mfma", 2),
+    ("void k_wgrad<1>", "fp32", "wgrad", 2),
+    ("void k_wgrad<0>", "fp32", "wgrad_fp32_mfma", 2),
     ("void k_render_fused<256, 20, false>", "fp32", "render_fwd_fp32_mfma", 1),
     ("void k_finish<true, true>", "fp32", "finish", 1),
     ("void k_render16<256, true>", "bf16", "train_fwd", 1),
@@ -82,7 +82,7 @@ def main():
             "--psnr-steps 0 --no-cpu-baseline --no-extra; mean per dispatch.  gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE "
             "counts half the bytes of a 16-B-per-lane coalesced read stream -> x2 where fetch_correction = 2 (the weight-gradient kernels' "
             "operand streams); the 4-B-per-lane stores/loads of the chain kernels are uncalibrated (raw values kept).")
-    for fam, name in (("fp32", "r03_traffic.json"), ("bf16", "r03_traffic_bf16.json")):
+    for fam, name in (("fp32", "r04_traffic.json"), ("bf16", "r04_traffic_bf16.json")):
         d = {"_note": note, "kernel_source_sha": sha}
         d.update(out[fam])
         with open(os.path.join(ROOT, "profiles", name), "w") as fh:
