@@ -148,6 +148,21 @@ def test_two_forwards_of_equal_size_then_one_backward(mods, dev, tag):
             pl2[2].mul_(1.0)
         with pytest.raises(RuntimeError, match="modified by an inplace"):
             l2.backward()
+        # the framework's own optimizer writes the flat parameter buffer with a raw kernel (torch's _version counters do not move):
+        # a step between two backward passes over one graph is refused all the same (ModelState.generation)
+        m3 = make_model(mods, cfg, params, dev)
+        pl3 = m3._param_list()
+        if kind == "fused":
+            out = mods["ops"].render_rays_fused(m3._ensure_packed(), pl3, ro_all[i1].to(dev), rd_all[i1].to(dev), 2.0, 6.0, S, True, t_rand=u[:128].to(dev))[0]
+            l3 = ((out - tgt[i1].to(dev)) ** 2).mean()
+        else:
+            r_, s_ = m3(xa.to(dev))
+            l3 = (r_ * wa.to(dev)).sum() + (s_ * sa.to(dev)).sum()
+        opt3 = mods["trainer"].FlatAdam(m3, lr=1e-3)
+        l3.backward(retain_graph=True)
+        opt3.step()
+        with pytest.raises(RuntimeError, match="modified by an inplace"):
+            l3.backward()
 
 
 def test_rebinding_an_interior_parameter_is_noticed(mods, dev):

@@ -381,6 +381,8 @@ class ModelState:
         # moment they are not; an explicit matrix_pipe="x3" / "fp32_mfma" is never changed.
         self.pipe_policy = "auto" if flags is None else "fixed"
         self.pipe_switched: Optional[str] = None           # why an "auto" model left the x3 pipe (None: it has not)
+        self.generation = 0                                # bumped by every update the framework itself makes to the flat parameters (raw kernels
+                                                           # do not move torch's _version counters): FlatAdam.step, the trainers' steps
         self._x3_packs = 0
         if flags is None:      # TNERF_FP32_PIPE=mfma32 selects the plain fp32-MFMA kernels for models built from now on (A/B runs)
             env = os.environ.get("TNERF_FP32_PIPE", "").lower()
@@ -579,7 +581,9 @@ class _Bf16TrainPlan:
 def _check_versions(ctx, who: str) -> None:
     """The backward reads the packed weights of NOW against the activations of the forward: refuse, like autograd does for saved
     tensors, when a parameter was modified in place in between (an optimizer step before a second backward(retain_graph=True))."""
-    if tuple(p._version for p in ctx.params) != ctx.versions:
+    # (torch's _version counters see in-place edits made through torch; the framework's own updates — FlatAdam.step, the trainers' steps —
+    #  write the flat buffer with raw kernels and bump ModelState.generation instead)
+    if tuple(p._version for p in ctx.params) != ctx.versions or ctx.st.generation != ctx.generation:
         raise RuntimeError(f"{who}: one of the parameters needed for gradient computation has been modified by an inplace operation "
                            "since the forward (e.g. optimizer.step() between two backward passes over the same graph)")
 
@@ -606,7 +610,7 @@ class _MlpFn(torch.autograd.Function):
                 lease.buf.data_ptr() if train else None, plan.Mp if train else 0, _stream(dev))
         ctx.st, ctx.plan, ctx.M, ctx.lease, ctx.x3 = st, plan, M, lease, x3
         ctx.shapes = [p.shape for p in params]
-        ctx.params, ctx.versions = params, tuple(p._version for p in params)
+        ctx.params, ctx.versions, ctx.generation = params, tuple(p._version for p in params), st.generation
         return rgb, sigma
 
     @staticmethod
@@ -722,10 +726,11 @@ class _FusedRaysFn(torch.autograd.Function):
                         _stream(dev))
             ctx.save_for_backward(rays_o, rays_d, ztab, t_rand if t_rand is not None else ztab)
             ctx.args = (st, plan, R, S, rnd, t_rand is not None, seed, off, white)
+            ctx.st = st
             ctx.x3 = x3
             ctx.lease = lease
             ctx.shapes = [p.shape for p in params]
-            ctx.params, ctx.versions = params, tuple(p._version for p in params)
+            ctx.params, ctx.versions, ctx.generation = params, tuple(p._version for p in params), st.generation
             return comp, None, None
         depth = torch.empty(R, 1, dtype=torch.float32, device=dev)
         acc = torch.empty(R, 1, dtype=torch.float32, device=dev)

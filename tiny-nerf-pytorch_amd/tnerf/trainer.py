@@ -73,6 +73,7 @@ class FlatAdam(torch.optim.Optimizer):
         _l.call("tnerf_adam_step", st.flat.data_ptr(), st.grad.data_ptr(), self._m.data_ptr(), self._v.data_ptr(), st.n_params,
                 float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), self._t, float(grad_scale),
                 torch.cuda.current_stream(st.device).cuda_stream)
+        st.generation += 1                       # (a raw kernel wrote the parameters: torch's _version counters did not move)
         st.packed_key = None                     # the packed copies (fp32 fragments, bf16 stream, x3 records) are stale now
         if st.bf16 is not None:
             st.bf16.key = None
@@ -360,6 +361,7 @@ class DatasetTrainer:
         self._calls += 1
         self.opt._t += 1
         st = self.st
+        st.generation += 1                       # the finishing kernel wrote the parameters (ops._check_versions)
         # the finishing kernel re-packed THIS precision's copies of the weights; the others are stale now
         if self.precision == "fp32":
             if st.bf16 is not None:
