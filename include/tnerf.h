@@ -463,6 +463,12 @@ int tnerf_x3_plan_sizes(const tnerf_mlp_desc* d, tnerf_bf16_sizes* out);        
 int tnerf_x3_pack_table(const tnerf_mlp_desc* d, int32_t* table);                           /* HOST: table[pack_entries] */
 int tnerf_mlp_pack_x3(const tnerf_mlp_desc* d, const float* params, const int32_t* table, void* packed3,
                       tnerf_stream_t stream);
+/* The same with the layers' scales chosen for max(max|W_l|, scale_floor).  A caller that hands the stream to tnerf_train_step_dataset
+ * passes 16 * lr: that entry point re-scatters the updated weights with the scale chosen before the update (and keeps the same headroom
+ * itself from then on), so a layer whose weights are smaller than one optimizer step — a near-zero initialised layer — cannot outgrow
+ * the fp16 range of its stream in its first step.  0 = tnerf_mlp_pack_x3. */
+int tnerf_mlp_pack_x3_floor(const tnerf_mlp_desc* d, const float* params, const int32_t* table, void* packed3,
+                            float scale_floor, tnerf_stream_t stream);
 /* The x3 pipe's DOMAIN.  Its scales are one power of two per layer (weights) and per sample (activations); an element keeps its 22
  * bits down to 2^-15 of its block's maximum and loses them below.  counts [4 * (depth + 1)] (device, uint32) receives per layer
  * (index depth = the heads): nonzero weights, weights below 2^-13 max|W_l|, nonzero biases, biases below 2^-14 max|b_l| — against the

@@ -667,6 +667,47 @@ def test_degenerate_weights_through_the_x3_kernels(mods, dev, case):
     assert max(relmax(p.grad.cpu(), q) for p, q in zip(m.parameters(), go)) <= 5e-5
 
 
+# ------------------------------------------------------------------ a layer smaller than one optimizer step
+def test_dataset_trainer_from_a_near_zero_layer(mods, dev):
+    """The device-resident step re-scatters the UPDATED weights into the x3 stream with the scale chosen BEFORE the update.  A layer
+    initialised at 1e-6 moves by ~lr = 5e-4 in its first Adam step — 500x — and used to leave the fp16 range of its stream (silent
+    clamp in tx_piece_bits: wrong forward from the second step on).  The scales are now chosen with headroom for one step (16 lr:
+    tnerf_mlp_pack_x3_floor at the trainer's start, k_x3stats_final afterwards): the loop follows the per-call path, which re-packs
+    from the fp32 weights with exact scales every step."""
+    from data import make_synthetic_scene
+    T = mods["trainer"]
+    scene = make_synthetic_scene(n_images=3, H=20, W=20, seed=5)
+    images = torch.from_numpy(scene["images"]).to(dev); poses = torch.from_numpy(scene["poses"]).to(dev); focal = float(scene["focal"])
+    N, H, W, _ = images.shape
+    R, S, seed = 160, 32, 77
+
+    def fresh():
+        torch.manual_seed(0)
+        m = mods["nerf"].TinyNeRF(39, 128, 3, 2, matrix_pipe="x3").to(dev)
+        with torch.no_grad():
+            m.sigma[0].bias += 0.5
+            m.layers[1].weight.mul_(1e-6); m.layers[1].bias.mul_(1e-6)
+        return m
+    ma = fresh()
+    ta = T.DatasetTrainer(ma, T.FlatAdam(ma, lr=5e-4), images, poses, focal, R, S, 2.0, 6.0, seed=seed, graph=False, record_pixels=True)
+    la, pix = [], []
+    for _ in range(5):
+        l, _ = ta.step()
+        la.append(float(l)); pix.append(ta.pix.clone())
+    mb = fresh()
+    tb = T.FusedTrainer(mb, T.FlatAdam(mb, lr=5e-4), 2.0, 6.0, S)
+    pixels = images.view(N, H * W, 3)
+    lb = []
+    for s in range(5):
+        l, _ = tb.step_camera(poses[s % N], H, W, focal, pix[s].long(), pixels[s % N], philox=(seed, s * R * S))
+        lb.append(float(l))
+    assert all(math.isfinite(v) for v in la)
+    assert max(abs(a - b) / b for a, b in zip(la, lb)) <= 1e-4, (la, lb)
+    for a, b in zip(ma.parameters(), mb.parameters()):
+        assert float((a.detach() - b.detach()).abs().max()) <= 2e-6 * max(1.0, float(b.detach().abs().max())) + 1e-7
+    assert float(ma.layers[1].weight.abs().max()) > 1e-4            # the layer did move by hundreds of its initial size
+
+
 # ------------------------------------------------------------------ sub-ray work units: 32-sample tiles instead of rays
 @pytest.mark.parametrize("tag,R,S", [("8x256", 300, 64), ("8x256", 77, 100), ("4x128", 130, 256), ("8x256", 5, 33)])
 def test_tile_units_equal_ray_units_bitwise(mods, dev, tag, R, S, monkeypatch):

@@ -73,5 +73,5 @@ struct FinishArgs {
     // (post = 1) behind the finishing kernel.
     const int32_t* scatter3; int32_t width3; void* packed3; int64_t x3_elems; NetX3 n3;
 };
-int tnx3_launch_stats(const NetX3& n, const float* params, const int32_t* table, void* packed3, int post, hipStream_t stream);
+int tnx3_launch_stats(const NetX3& n, const float* params, const int32_t* table, void* packed3, int post, hipStream_t stream, float scale_floor);
 int tn_launch_finish(const FinishArgs& f, hipStream_t stream);

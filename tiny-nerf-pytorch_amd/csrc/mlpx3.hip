@@ -1040,19 +1040,23 @@ __global__ __launch_bounds__(256) void k_x3stats_scan(const float* __restrict__ 
 //   post = 1 (the finishing kernel has just re-scattered every weight with the scale the record's [3] named, accumulating the
 //            maxima of the updated parameters): [0] <- 1 / [3], then [1], [2], [3] from the maxima — the chain kernels of the next
 //            step read the scale that is in the stream and bounds that hold for the weights that are in the stream.
-__global__ __launch_bounds__(64) void k_x3stats_final(int n_layers, float* __restrict__ meta, int post) {
+//   floor: the scale is chosen for max(max|W|, floor).  The step path passes 16 lr: the finishing kernel re-scatters the UPDATED weights
+//            with the scale chosen BEFORE the update, Adam moves a weight by at most ~lr per step, so a layer whose weights are smaller
+//            than the step (a near-zero initialised layer) can no longer outgrow the fp16 range of its stream in one step (tx_piece_bits
+//            would clamp silently).  Costs nothing: a weight 2^-15 below the scale's maximum still has all its 22 bits.
+__global__ __launch_bounds__(64) void k_x3stats_final(int n_layers, float* __restrict__ meta, int post, float floor) {
     const int l = threadIdx.x;
     if (l >= n_layers) return;
     float* m = meta + l * TX_META;
     const float mw = __uint_as_float(reinterpret_cast<unsigned*>(m)[4]), mb = __uint_as_float(reinterpret_cast<unsigned*>(m)[5]);
     const float wsc_old = m[3];
-    const float wsc_new = tx_exp2i(12 - __builtin_amdgcn_frexp_expf(mw));      // max|W| = f 2^e, f in [0.5, 1): max|W| 2^(12-e) in [2^11, 2^12)
+    const float wsc_new = tx_exp2i(12 - __builtin_amdgcn_frexp_expf(fmaxf(mw, floor)));      // max|W| = f 2^e, f in [0.5, 1): max|W| 2^(12-e) in [2^11, 2^12)
     m[0] = 1.0f / (post ? wsc_old : wsc_new);                                   // a power of two: exact
     m[1] = mw; m[2] = mb; m[3] = wsc_new;
     reinterpret_cast<unsigned*>(m)[4] = 0u; reinterpret_cast<unsigned*>(m)[5] = 0u;
 }
 
-int tnx3_launch_stats(const NetX3& n, const float* params, const int32_t* table, void* packed3, int post, hipStream_t stream) {
+int tnx3_launch_stats(const NetX3& n, const float* params, const int32_t* table, void* packed3, int post, hipStream_t stream, float scale_floor) {
     float* meta = reinterpret_cast<float*>(static_cast<unsigned char*>(packed3) + n.meta_off);
     if (!post) {                                                               // full scan (the buffer may be fresh memory: clear first)
         hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, stream, reinterpret_cast<unsigned*>(meta), (n.depth + 1) * TX_META);
@@ -1060,7 +1064,7 @@ int tnx3_launch_stats(const NetX3& n, const float* params, const int32_t* table,
         hipLaunchKernelGGL(k_x3stats_scan, dim3((unsigned)((n.depth + 1) * TX_SCAN_NB)), dim3(256), 0, stream, params, table, n, meta);
         TN_HIP_CHECK_LAUNCH("x3 weight statistics (scan)");
     }
-    hipLaunchKernelGGL(k_x3stats_final, dim3(1), dim3(64), 0, stream, n.depth + 1, meta, post);
+    hipLaunchKernelGGL(k_x3stats_final, dim3(1), dim3(64), 0, stream, n.depth + 1, meta, post, scale_floor);
     TN_HIP_CHECK_LAUNCH("x3 weight statistics");
     return TNERF_OK;
 }
@@ -1135,12 +1139,17 @@ __global__ __launch_bounds__(256) void k_packx3(const float* __restrict__ params
 
 extern "C" int tnerf_mlp_pack_x3(const tnerf_mlp_desc* d, const float* params, const int32_t* table, void* packed3,
                                  tnerf_stream_t stream) {
+    return tnerf_mlp_pack_x3_floor(d, params, table, packed3, 0.0f, stream);
+}
+
+extern "C" int tnerf_mlp_pack_x3_floor(const tnerf_mlp_desc* d, const float* params, const int32_t* table, void* packed3,
+                                       float scale_floor, tnerf_stream_t stream) {
     NetX3 n; int rc = tn_build_netx3(d, &n); if (rc) return rc;
-    if (!params || !table || !packed3) {
-        tn_set_error("tnerf_mlp_pack_x3: params=%p table=%p packed3=%p", (const void*)params, (const void*)table, packed3);
+    if (!params || !table || !packed3 || !(scale_floor >= 0.0f)) {
+        tn_set_error("tnerf_mlp_pack_x3: params=%p table=%p packed3=%p scale_floor=%g", (const void*)params, (const void*)table, packed3, scale_floor);
         return TNERF_EINVAL;
     }
-    if ((rc = tnx3_launch_stats(n, params, table, packed3, 0, (hipStream_t)stream))) return rc;
+    if ((rc = tnx3_launch_stats(n, params, table, packed3, 0, (hipStream_t)stream, scale_floor))) return rc;
     const int64_t n_w = (int64_t)(n.n_rec + n.n_bw_rec) * n.rec_frags * 512;
     unsigned char* base = static_cast<unsigned char*>(packed3);
     hipLaunchKernelGGL(k_packx3, dim3((unsigned)((n.pack_entries + 255) / 256)), dim3(256), 0, (hipStream_t)stream, params, table, n, n_w,

@@ -83,7 +83,7 @@ extern "C" int tnerf_train_step_dataset(const tnerf_step_args* a, tnerf_stream_t
     }
     if ((rc = tn_launch_finish(f, stream))) return rc;
     // the finishing kernel re-scattered every weight into the x3 stream: publish the scale it used and refresh the layers' maxima
-    if (f.scatter3) return tnx3_launch_stats(f.n3, a->params, a->pack_x3, f.packed3, 1, stream);
+    if (f.scatter3) return tnx3_launch_stats(f.n3, a->params, a->pack_x3, f.packed3, 1, stream, 16.0f * a->lr);      // headroom for the next update (k_x3stats_final)
     return TNERF_OK;
 }
 

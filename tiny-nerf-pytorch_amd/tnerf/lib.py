@@ -119,6 +119,7 @@ SIGNATURES = {
     "tnerf_x3_plan_sizes": (C.c_int, [_DESC, C.POINTER(Bf16Sizes)]),
     "tnerf_x3_pack_table": (C.c_int, [_DESC, _P]),
     "tnerf_mlp_pack_x3": (C.c_int, [_DESC, _P, _P, _P, _P]),
+    "tnerf_mlp_pack_x3_floor": (C.c_int, [_DESC, _P, _P, _P, C.c_float, _P]),
     "tnerf_x3_domain_counts": (C.c_int, [_DESC, _P, _P, _P, _P, _P]),
     "tnerf_render_fused_x3": (C.c_int, [_DESC, _P, _P, _P, _I64, _I32, _P, _I32, _P, _U64, _U64, _I32, _P, _P, _P, _P]),
     "tnerf_render_fused_cam_x3": (C.c_int, [_DESC, _P, C.POINTER(Camera), _I64, _I32, _P, _I32, _P, _U64, _U64, _I32, _P, _P, _P, _P]),

@@ -464,15 +464,16 @@ class ModelState:
             b.key = key
         return b
 
-    def repack_x3(self, key=None) -> "_X3State":
+    def repack_x3(self, key=None, scale_floor: float = 0.0) -> "_X3State":
         """x3 chain (fp32-grade products on the fp16 matrix pipe): (re)build the two-piece record stream, its scale records and the fp32 biases.
         An "auto" model checks the x3 pipe's domain on its first pack and on every 64th after it (one 72-byte read-back)."""
         if self.x3 is None:
             self.x3 = _X3State(self)
         b = self.x3
         if key is None or key != b.key:
-            _l.call("tnerf_mlp_pack_x3", C.byref(self.desc), self.flat.data_ptr(), b.table.data_ptr(), b.packed.data_ptr(),
-                    _stream(self.device))
+            # scale_floor: DatasetTrainer passes 16 lr (include/tnerf.h, tnerf_mlp_pack_x3_floor)
+            _l.call("tnerf_mlp_pack_x3_floor", C.byref(self.desc), self.flat.data_ptr(), b.table.data_ptr(), b.packed.data_ptr(),
+                    float(scale_floor), _stream(self.device))
             b.key = key
             if self.pipe_policy == "auto" and self._x3_packs % 64 == 0:
                 self.check_x3_domain()

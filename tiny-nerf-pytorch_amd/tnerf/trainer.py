@@ -276,7 +276,8 @@ class DatasetTrainer:
             self._stash, self._stride = self._lease.buf, self._plan.Mp
             tab = st.pack_table.cpu().numpy()
             if st.x3_capable and not (st.desc.flags & _l.FLAG_FP32_MFMA):    # forward on the x3 chain kernel; the finishing kernel keeps its stream current
-                x3 = st.repack_x3(tuple(p._version for p in model._param_list()))
+                # (key None: always packed here, with headroom for the finishing kernel's first re-scatter — tnerf_mlp_pack_x3_floor)
+                x3 = st.repack_x3(None, scale_floor=16.0 * float(optimizer.param_groups[0]["lr"]))
                 if st.uses_x3:                                                # (an "auto" model whose weights are outside the x3 domain has just switched)
                     self._x3_packed, self._x3_table = x3.packed, x3.table
                     self._x3_scatter = torch.from_numpy(_scatter_table(x3.table.cpu().numpy(), st.n_params)).to(dev)
@@ -340,7 +341,7 @@ class DatasetTrainer:
             st.packed_key = None
             self.model._ensure_packed()
             if self._x3_packed is not None:
-                st.repack_x3(None)
+                st.repack_x3(None, scale_floor=16.0 * float(self.opt.param_groups[0]["lr"]))
         else:
             st.repack_bf16(None)
         self._param_key = key
