@@ -26,7 +26,11 @@ struct TxProf { unsigned long long walk = 0, epi = 0, t = 0; unsigned long long*
 #define TX_PROF_BEGIN(pf) (pf).t = __builtin_amdgcn_s_memtime()
 #define TX_PROF_ADD(pf, field) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); (pf).field += n_ - (pf).t; (pf).t = n_; } while (0)
 // a time stamp per pass of the FIRST tile of workgroup 0 / wave 0 (marks != nullptr there only)
+#ifdef TN_STAGE_STAMPS      // (the stage stamps of tx_boundary are taken instead: no marks between the passes)
+#define TX_PROF_MARK(pf) do {} while (0)
+#else
 #define TX_PROF_MARK(pf) do { if ((pf).marks && (pf).n < 60) { (pf).marks[(pf).n++] = __builtin_amdgcn_s_memtime(); } } while (0)
+#endif
 #else
 struct TxProf {};
 #define TX_PROF_BEGIN(pf) do {} while (0)
@@ -64,7 +68,7 @@ __device__ __forceinline__ void tx_stash_input(const FwdX3Args& a, int h, int la
 // The network for one 32-sample tile.  m: this lane's sample index in the stash (valid if `valid`).  res[4]: r,g,b after
 // sigmoid, sigma after ReLU (lane-half 0).  E: this lane's LDS slots of the input pieces, scaled by 2^in.te (rescaled in place for
 // the skip layer).
-template <int HID, bool TRAIN>
+template <int HID, bool TRAIN, bool ACC_ASM = true>
 __device__ __forceinline__ void tx_mlp_tile(PipeX& p, const unsigned char* lds, const FwdX3Args& a, int h, int lane, unsigned char* E, const TxIn& in,
                                             int64_t m, bool valid, float (&res)[4], TxProf& pf, unsigned char* lds_bnd) {
     constexpr int NT = HID / 32;
@@ -106,9 +110,14 @@ __device__ __forceinline__ void tx_mlp_tile(PipeX& p, const unsigned char* lds, 
     };
     if constexpr (TRAIN) tx_bound_note(lds_bnd, TNB_ENC, in.encmax);
     // steps 0..3 = part V, 4..8 = part S    (mlpx3_core.hpp)
+#ifdef TX_NO_ASM_ACC_READ
+    constexpr bool AR = false;
+#else
+    constexpr bool AR = (HID == 256 || TX_ASM_ACC_128) && ACC_ASM;      // (mlpx3_core.hpp, tx_acc_get)
+#endif
     auto epi_full = [&](auto halfc, auto& acc, auto ic, auto kc) TN_INLINE_LAMBDA {
         constexpr int HALF = decltype(halfc)::value, I = decltype(ic)::value, K = decltype(kc)::value;
-        if constexpr (K < TX_VSTEPS) tx_epi_fwd_value<HID, HALF, I, K, TRAIN>(acc, es, sc, lds, vbe, mword);
+        if constexpr (K < TX_VSTEPS) tx_epi_fwd_value<HID, HALF, I, K, TRAIN, AR>(acc, es, sc, lds, vbe, mword);
         else tx_epi_split<HID, HALF, I, K, TRAIN, true>(X, es, sc, srow);
     };
     auto epiA = [&](auto ic, auto kc) TN_INLINE_LAMBDA { epi_full(std::integral_constant<int, 0>{}, accA, ic, kc); };
@@ -188,6 +197,9 @@ __global__ TX_PLAIN_F32 __launch_bounds__((TxCfg<HID, TRAIN>::NW * 64), 1) void 
 #ifdef TN_STAMPS
     const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
     if (a.f.stamps && blockIdx.x == 0 && wave == 0) pf.marks = a.f.stamps + (size_t)gridDim.x * NW * 8;      // behind the per-wave records
+#ifdef TN_STAGE_STAMPS
+    if (a.f.stamps && blockIdx.x == 0 && wave == 0) p.smarks = a.f.stamps + (size_t)gridDim.x * NW * 8 + 64;
+#endif
 #endif
 
     // Every wave of the workgroup runs the same number of network passes (the stage barriers are workgroup-wide): rays beyond
@@ -350,13 +362,23 @@ __device__ __forceinline__ void tx_bwd_tile(PipeX& p, const unsigned char* lds, 
         t_prev = t_out;
     };
     // steps 0..3 = part V, 4..8 = part S    (mlpx3_core.hpp)
-    auto epi_full = [&](auto halfc, auto& acc, auto ic, auto kc) TN_INLINE_LAMBDA {
+#ifdef TX_NO_ASM_ACC_READ
+    constexpr bool AR = false;
+#else
+    constexpr bool AR = HID == 256 || TX_ASM_ACC_128;              // (mlpx3_core.hpp, tx_acc_get)
+#endif
+    auto epi_full = [&](auto halfc, auto arc, auto& acc, auto ic, auto kc) TN_INLINE_LAMBDA {
         constexpr int HALF = decltype(halfc)::value, I = decltype(ic)::value, K = decltype(kc)::value;
-        if constexpr (K < TX_VSTEPS) tx_epi_bwd_value<HID, HALF, I, K>(acc, es, sc, mw);
+        if constexpr (K < TX_VSTEPS) tx_epi_bwd_value<HID, HALF, I, K, decltype(arc)::value>(acc, es, sc, mw);
         else tx_epi_split<HID, HALF, I, K, true, false>(X, es, sc, zrow);
     };
-    auto epiA = [&](auto ic, auto kc) TN_INLINE_LAMBDA { epi_full(std::integral_constant<int, 0>{}, accA, ic, kc); };
-    auto epiB = [&](auto ic, auto kc) TN_INLINE_LAMBDA { epi_full(std::integral_constant<int, 1>{}, accB, ic, kc); };
+    using ArC = std::integral_constant<bool, AR>;
+    // drains (right behind the MFMAs that produce the values: compiler-visible reads) ...
+    auto epiA = [&](auto ic, auto kc) TN_INLINE_LAMBDA { epi_full(std::integral_constant<int, 0>{}, std::false_type{}, accA, ic, kc); };
+    auto epiB = [&](auto ic, auto kc) TN_INLINE_LAMBDA { epi_full(std::integral_constant<int, 1>{}, std::false_type{}, accB, ic, kc); };
+    // ... and the windows that ride on the other half's pass (accumulators read from their AGPRs where they are)
+    auto epiA_w = [&](auto ic, auto kc) TN_INLINE_LAMBDA { epi_full(std::integral_constant<int, 0>{}, ArC{}, accA, ic, kc); };
+    auto epiB_w = [&](auto ic, auto kc) TN_INLINE_LAMBDA { epi_full(std::integral_constant<int, 1>{}, ArC{}, accB, ic, kc); };
     constexpr int SPF = HID == 256 ? 1 : 4;
     constexpr int GB = HID == 256 ? TX_GB256 : G2, GA = HID == 256 ? TX_GA256 : G2;      // see tx_mlp_tile
     static_assert(tx_half_b_ok<HID, GB, SPF>(), "half B's epilogue window overruns the first read of its pieces");
@@ -374,8 +396,8 @@ __device__ __forceinline__ void tx_bwd_tile(PipeX& p, const unsigned char* lds, 
     // and waited for (>= TX_LEAD boundaries later) at the start of pass B, where dZ_{l-1}'s half A epilogue begins
     for (int l = depth - 1; l >= 1; --l) {
         mk.fetch(mrow + (int64_t)(l - 1) * (Mp + 32) * NT);
-        tx_pass<HID, 1, true, NW>(p, lds, X, nullptr, accA, tx_window<0, GB, NP, 0, TX_NSTEP, SPF>(epiB));
-        auto wa = tx_window<TX_WA, GA, NP, 0, TX_NSTEP, SPF>(epiA);
+        tx_pass<HID, 1, true, NW>(p, lds, X, nullptr, accA, tx_window<0, GB, NP, 0, TX_NSTEP, SPF>(epiB_w));
+        auto wa = tx_window<TX_WA, GA, NP, 0, TX_NSTEP, SPF>(epiA_w);
         tx_pass<HID, 1, true, NW>(p, lds, X, nullptr, accB, [&](auto sc_) TN_INLINE_LAMBDA {
             if constexpr (decltype(sc_)::value == 0) {
                 mk.template wait<TxCfg<HID>::DPW * TX_LEAD>();
@@ -527,7 +549,7 @@ __global__ TX_PLAIN_F32 __launch_bounds__((TxCfg<HID, TRAIN>::NW * 64), 1) void 
         tx_split_input(Er, tx_exp2i(in.te), [&](auto ac) TN_INLINE_LAMBDA { return encf[decltype(ac)::value]; });
         tx_store_input(E, Er);
         float res[4];
-        tx_mlp_tile<HID, TRAIN>(p, lds, a, h, lane, E, in, mc, valid, res, pf, lds_bnd);
+        tx_mlp_tile<HID, TRAIN, !TRAIN>(p, lds, a, h, lane, E, in, mc, valid, res, pf, lds_bnd);      // (training: the asm accumulator reads cost this kernel 9 spilled values)
         // the sample index is formed again behind the tile (from a lane id the compiler cannot match with the one above): kept alive
         // across the layer walk, the 64-bit index was what spilled to scratch in the 256-wide training kernel
         int lane2 = lane; asm volatile("" : "+v"(lane2));

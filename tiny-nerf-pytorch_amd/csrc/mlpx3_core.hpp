@@ -94,6 +94,9 @@ struct PipeX {
     uint32_t voff;               // lane * 16 + wave * DPW * 1024: this wave's first piece of a stage
     const unsigned char* pend_src; uint32_t pend_dst;      // the stage whose pieces are being issued behind MFMAs (tx_defer_stage)
     uint32_t par;                // parity of the stage boundaries taken: the odd ones carry the wait and the barrier (tx_boundary)
+#ifdef TN_STAGE_STAMPS           // diagnostic build (tools/x3_stage_probe.py): s_memtime at every stage boundary of workgroup 0 / wave 0
+    unsigned long long* smarks; int sn;
+#endif
 };
 
 // This wave's DPW pieces of a stage are 1 KB each, consecutive in the stream and in the slot: piece i is the pending
@@ -144,6 +147,9 @@ __device__ __forceinline__ void tx_defer_stage(PipeX& p) {
 // issues its pieces with tx_issue_piece before the next boundary).
 template <int DPW, bool DEFER>
 __device__ __forceinline__ void tx_boundary(PipeX& p) {
+#ifdef TN_STAGE_STAMPS
+    if (p.smarks && p.sn < 500) p.smarks[p.sn++] = __builtin_amdgcn_s_memtime();
+#endif
 #ifndef TX_BAR1
     // ONE barrier per TWO stages.  At an even boundary s the wave waits for its own DMA of stages s AND s+1 (stages s+2 .. s+4 may
     // stay in flight), then the barrier: both stages are readable by everyone, and everyone has issued its last read of stage s-1
@@ -196,6 +202,9 @@ __device__ __forceinline__ void tx_prologue(PipeX& p, unsigned char* lds, const 
     for (int i = 0; i < TX_LEAD; ++i) tx_issue_stage<DPW>(p);
     p.cur = TX_RING - TX_SLOT;                   // the first boundary moves it onto slot 0
     p.par = 0u;                                  // ... and is a barrier boundary
+#ifdef TN_STAGE_STAMPS
+    p.smarks = nullptr; p.sn = 0;
+#endif
 }
 #define TX_CONST_BYTES(n) ((uint32_t)(((n).n_bias + ((n).depth + 1) * TX_META + 3) / 4 * 4) * 4)
 // Behind the ring and the constants: the network-input pieces of every wave's tile (forward kernels; [piece][k-step][lane] x 16 B).
@@ -461,21 +470,42 @@ __device__ __forceinline__ void tx_epi_split(ActX<HID>& X, TxEpi& e, TxScale& sc
     }
 }
 
+// An accumulator element into a VGPR, from WHERE IT IS: an AGPR.  Left to itself the register allocator gives the two halves' accumulators
+// one set of 128 AGPRs and, at every pass boundary, copies the half that has just been finished into VGPRs for the epilogue to read — 128
+// v_accvgpr_read in a burst with no MFMA to hide behind, ~900 cycles per half-pass (stage stamps: the stage around a pass boundary took
+// 1.8-1.9 k cycles, every other one 0.98 k) — and then runs out of VGPRs and parks activation pieces in AGPRs.  An asm read with an "a"
+// operand keeps each half in its own AGPRs until the epilogue step that needs the value, one read per value in an MFMA's shadow.
+// ASM = false (tx_drain: the epilogue runs right behind the MFMAs that produce the values): plain C++, the compiler inserts the MFMA ->
+// VALU wait states itself; the windows start >= 6 MFMAs (192 cycles) behind the last MFMA of the half they read.
+#ifndef TX_ASM_ACC_128
+#define TX_ASM_ACC_128 0          // 128-wide kernels: measured below
+#endif
+template <bool ASM>
+__device__ __forceinline__ float tx_acc_get(const f32x16& a, int r) {
+    if constexpr (ASM) {
+        float x;
+        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x) : "a"(a[r]));
+        return x;
+    } else {
+        return a[r];
+    }
+}
+
 // Forward part V (steps 0..3): leading + correction, descale + bias (fp32, LDS byte offset vb + 16 h: this layer's biases for rows
 // 4h..), ReLU.  TRAIN: the ReLU sign bits ride on a NEGATED pre-activation: the LDS table holds nb = 0 - b (so that b = +-0 gives
 // +0) and dsc is negative, nz = fma(acc, dsc, nb) = -z; then bit 31 of nz IS "z > 0" (z = +-0 gives nz = +0: not set, as
 // torch's relu'(0) = 0), one v_alignbit per value shifts it into the sign word, and ReLU is med3(-nz, 0, 3.39e38) — source modifier,
 // ONE instruction: fmaxf behind TX_KEEP needs a canonicalising v_max first, and med3 against a visible inf is folded into exactly
 // that fmaxf; the clamp is the opaque constant of TxScale (an activation of 3.4e38 has overflowed every product downstream anyway).  (Round 3: v_add_u32 0x7fffffff + v_alignbit on the ReLU output.)
-template <int HID, int HALF, int I, int K, bool TRAIN>
+template <int HID, int HALF, int I, int K, bool TRAIN, bool AR = false>
 __device__ __forceinline__ void tx_epi_fwd_value(const f32x16 (&acc)[TX_ACCN(HID)], TxEpi& e, const TxScale& sc, const unsigned char* lds, uint32_t vb,
                                                  uint32_t* __restrict__ mword) {
     using P = TxPair<HID, HALF, I>;
     constexpr int u = I % 4;
     if constexpr (K == 0) {
         e.b[u] = *reinterpret_cast<const f32x2*>(lds + vb + P::row0 * 4);
-        e.v[u][0] = acc[P::tl][P::r0]; e.v[u][1] = acc[P::tl][P::r1];
-        e.c[u][0] = acc[P::tl + P::NH][P::r0]; e.c[u][1] = acc[P::tl + P::NH][P::r1];
+        e.v[u][0] = tx_acc_get<AR>(acc[P::tl], P::r0); e.v[u][1] = tx_acc_get<AR>(acc[P::tl], P::r1);
+        e.c[u][0] = tx_acc_get<AR>(acc[P::tl + P::NH], P::r0); e.c[u][1] = tx_acc_get<AR>(acc[P::tl + P::NH], P::r1);
         TX_KEEP(e.v[u]); TX_KEEP(e.c[u]);
     } else if constexpr (K == 1) {
         e.v[u][0] += e.c[u][0]; e.v[u][1] += e.c[u][1]; TX_KEEP(e.v[u]);
@@ -500,13 +530,13 @@ __device__ __forceinline__ void tx_epi_fwd_value(const f32x16 (&acc)[TX_ACCN(HID
 }
 // Backward part V: leading + correction, descale, ReLU backward with the forward's sign bits (mw: the words of the layer this
 // activation gradient belongs to).
-template <int HID, int HALF, int I, int K>
+template <int HID, int HALF, int I, int K, bool AR = false>
 __device__ __forceinline__ void tx_epi_bwd_value(const f32x16 (&acc)[TX_ACCN(HID)], TxEpi& e, const TxScale& sc, const uint32_t (&mw)[HID / 64]) {
     using P = TxPair<HID, HALF, I>;
     constexpr int u = I % 4;
     if constexpr (K == 0) {
-        e.v[u][0] = acc[P::tl][P::r0]; e.v[u][1] = acc[P::tl][P::r1];
-        e.c[u][0] = acc[P::tl + P::NH][P::r0]; e.c[u][1] = acc[P::tl + P::NH][P::r1];
+        e.v[u][0] = tx_acc_get<AR>(acc[P::tl], P::r0); e.v[u][1] = tx_acc_get<AR>(acc[P::tl], P::r1);
+        e.c[u][0] = tx_acc_get<AR>(acc[P::tl + P::NH], P::r0); e.c[u][1] = tx_acc_get<AR>(acc[P::tl + P::NH], P::r1);
         TX_KEEP(e.v[u]); TX_KEEP(e.c[u]);
     } else if constexpr (K == 1) {
         e.v[u][0] += e.c[u][0]; e.v[u][1] += e.c[u][1]; TX_KEEP(e.v[u]);

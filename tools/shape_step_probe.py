@@ -1,0 +1,19 @@
+import os, sys, time
+ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tiny-nerf-pytorch_amd"), os.path.join(ROOT, "tiny-nerf-pytorch_amd", "src")]
+import torch
+from tnerf import trainer
+from data import make_synthetic_scene
+import nerf as nerf_mod
+dev = torch.device("cuda:0"); torch.cuda.set_stream(torch.cuda.Stream(dev))
+scene = make_synthetic_scene(seed=0)
+images = torch.from_numpy(scene["images"]).to(dev); poses = torch.from_numpy(scene["poses"]).to(dev); focal = float(scene["focal"])
+for (L, hid, dep, skip, R) in ((10, 128, 4, 2, 2048), (6, 256, 8, 4, 4096)):
+    torch.manual_seed(0)
+    m = nerf_mod.TinyNeRF(6 * L + 3, hid, dep, skip).to(dev)
+    with torch.no_grad(): m.sigma[0].bias += 0.5
+    tr = trainer.DatasetTrainer(m, trainer.FlatAdam(m, lr=5e-4), images, poses, focal, R, 64, 2.0, 6.0, seed=1234)
+    for _ in range(30): tr.step()
+    torch.cuda.synchronize(); t0 = time.perf_counter(); n = 300
+    for _ in range(n): tr.step()
+    torch.cuda.synchronize(); print(f"{dep}x{hid} L={L} R={R}: {(time.perf_counter() - t0) / n * 1e3:.4f} ms/step", flush=True)
