@@ -77,6 +77,10 @@ __device__ __forceinline__ float tn_philox_uniform(uint64_t seed, uint64_t index
 __device__ __forceinline__ uint32_t tn_philox_u32(uint64_t seed, uint64_t index) {
     uint32_t c0 = (uint32_t)(index >> 2), c1 = (uint32_t)(index >> 34), c2 = 0u, c3 = 0u;
     uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    // The seed is a kernel argument (wave-uniform).  Left visible, the ten round keys are loop-invariant scalars that hipcc computes once
+    // per kernel and keeps — 18 SGPRs per seed, which the chain kernels do not have: they went to VGPR lanes (v_writelane), i.e. into
+    // the vector registers the layer walk needs.  Behind this barrier the keys are formed where they are used (18 s_add per call).
+    asm volatile("" : "+s"(k0), "+s"(k1));
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
         const uint32_t h0 = tn_mulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;

@@ -13,7 +13,7 @@
 // plain instructions they stand for 104 (tools/microbench/pk_mfma.hip).  hipcc's post-RA peephole unpacks the ones it believes to be in a
 // shadow and leaves the rest (72 per layer in the dgrad loop); with the feature off the 8x256 dgrad kernel runs 2.7 % faster.  The
 // forward kernels keep it: there the extra instructions cost as much as the stalls (measured: +-0).
-#if defined(__HIP_DEVICE_COMPILE__)            // (hipcc's host pass of this file does not know the feature and would warn)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(TX_ALLOW_PK)      // (hipcc's host pass of this file does not know the feature and would warn; TX_ALLOW_PK: diagnostic A/B builds)
 #define TX_PLAIN_F32 __attribute__((target("no-packed-fp32-ops")))
 #else
 #define TX_PLAIN_F32
@@ -55,12 +55,13 @@ __device__ __forceinline__ void tx_stash_input(const FwdX3Args& a, int h, int la
     const int64_t ms = valid ? m : a.f.Mp + (lane & 31);           // padding lanes write to the dump block
     float* __restrict__ q = tn_stash_at(a.f.stash, L.stash_rows, ms) + (int64_t)(L.enc_row0 + h) * 32;      // row enc_row0 + 2 st + h
     // NE is 20 (in_dim <= 40) or 32 input steps: one uniform branch, then straight-line stores with immediate offsets
-    if (L.NE == 20) {
+    int ne = L.NE; asm volatile("" : "+s"(ne));                    // (opaque: see tx_encode — no hoisted lane masks)
+    if (ne == 20) {
         tn_static_for<20>([&](auto sc) TN_INLINE_LAMBDA { constexpr int st = decltype(sc)::value; TN_STASH_STORE(&q[2 * st * 32], encf[st]); });
     } else {
         tn_static_for<8 * TN16_KE>([&](auto sc) TN_INLINE_LAMBDA {
             constexpr int st = decltype(sc)::value;
-            if (st < L.NE) TN_STASH_STORE(&q[2 * st * 32], encf[st]);
+            if (st < ne) TN_STASH_STORE(&q[2 * st * 32], encf[st]);
         });
     }
 }
@@ -68,34 +69,37 @@ __device__ __forceinline__ void tx_stash_input(const FwdX3Args& a, int h, int la
 // The network for one 32-sample tile.  m: this lane's sample index in the stash (valid if `valid`).  res[4]: r,g,b after
 // sigmoid, sigma after ReLU (lane-half 0).  E: this lane's LDS slots of the input pieces, scaled by 2^in.te (rescaled in place for
 // the skip layer).
-template <int HID, bool TRAIN, bool ACC_ASM = true>
+template <int HID, bool TRAIN, int NW, bool ACC_ASM = true>
 __device__ __forceinline__ void tx_mlp_tile(PipeX& p, const unsigned char* lds, const FwdX3Args& a, int h, int lane, unsigned char* E, const TxIn& in,
                                             int64_t m, bool valid, float (&res)[4], TxProf& pf, unsigned char* lds_bnd) {
     constexpr int NT = HID / 32;
     const MlpLayout& L = a.f.L;
     const int depth = a.n.depth, skip_at = a.n.skip_at;
-    const uint32_t vb0 = TX_RING + 16u * h;                        // + layer * HID * 4
     float* __restrict__ stash = a.f.stash;
     const int64_t Mp = a.f.Mp;
     const int64_t ms = valid ? m : Mp + (lane & 31);               // padding lanes write to the dump block: stores need no branch
-    uint32_t* __restrict__ mrow = TRAIN ? reinterpret_cast<uint32_t*>(stash + TN_STASH_BODY_FLOATS(L, Mp)) + (2 * ms + h) * (NT / 2) : nullptr;
-    constexpr int NH = NT / 2, KH = HID / 16, NP = NH * 8, NW = TxCfg<HID, TRAIN>::NW, G2 = KH / 2 * NH;
+    // (this lane's sign words of layer 0; point_at steps the pointer from layer to layer — no second copy of it lives through the walk)
+    uint32_t* __restrict__ mword = TRAIN ? reinterpret_cast<uint32_t*>(stash + TN_STASH_BODY_FLOATS(L, Mp)) + (2 * ms + h) * (NT / 2) : nullptr;
+    constexpr int NH = NT / 2, KH = HID / 16, NP = NH * 8, G2 = KH / 2 * NH;
     ActX<HID> X;
     f32x16 accA[TX_ACCN(HID)], accB[TX_ACCN(HID)];
     TxEpi es;
     TxScale sc{0.0f, 0.0f, {0.0f, 0.0f}, tx_konst()};
     int t_prev = in.te;                                            // exponent of the scale of the pieces the running passes consume
     // per-lane stash pointers of the layer whose epilogue is running (training)
-    TxDst srow{}; uint32_t* __restrict__ mword = nullptr;
-    uint32_t dst_off0 = 0;
-    if constexpr (TRAIN) { srow = tx_dst_tile(stash, L.stash_rows, m, valid, h); dst_off0 = srow.off; }
-    uint32_t vbe = vb0;                                            // LDS offset of that layer's biases
+    TxDst srow{};
+    if constexpr (TRAIN) srow = tx_dst_tile(stash, L.stash_rows, m, valid, h);       // (.off: + the layer's first row, stepped by point_at)
+    uint32_t vbe = TX_RING_OF(NW) + 16u * h;                       // LDS offset of the biases of the layer whose epilogue is running (+ HID * 4 per layer)
     // Layer l's epilogues are about to start: its input's L1 norm is complete (the previous layer's half B epilogue ended in the
     // middle of pass A), so the bound on its outputs — and with it the scale of its pieces — is known.
+    // (called for l = 0, 1, .. depth-1 in this order: the per-layer addresses are STEPPED, so that only one copy of each is live)
     auto point_at = [&](int l) TN_INLINE_LAMBDA {
-        vbe = vb0 + l * HID * 4;
-        if constexpr (TRAIN) { srow.off = dst_off0 + (uint32_t)L.h_row0[l] * 128u; mword = mrow + (int64_t)l * (Mp + 32) * NT; }
-        const f32x4 mt = tx_meta(lds, a.n, l);                     // {2^-s, max|W|, max|b|}
+        if (l > 0) vbe += HID * 4;
+        if constexpr (TRAIN) {
+            srow.off += (uint32_t)(L.h_row0[l] - (l > 0 ? L.h_row0[l - 1] : 0)) * 128u;
+            if (l > 0) mword += (Mp + 32) * NT;
+        }
+        const f32x4 mt = tx_meta<NW>(lds, a.n, l);                 // {2^-s, max|W|, max|b|}
         const float l1_own = sc.l1[0] + sc.l1[1];
         float l1_in = l == 0 ? in.l1 : l1_own + tx_partner(l1_own);
         if (l > 0 && l == skip_at) l1_in += in.l1;
@@ -168,16 +172,16 @@ __device__ __forceinline__ void tx_mlp_tile(PipeX& p, const unsigned char* lds, 
     TX_PROF_MARK(pf);
     TX_PROF_ADD(pf, walk);
     // heads: rows 0..2 = rgb.0 (sigmoid), row 3 = sigma.0 (ReLU)                                   nerf.py:39-40
-    const f32x4 hb = *reinterpret_cast<const f32x4*>(lds + TX_RING + depth * HID * 4);
-    const float dh = tx_meta(lds, a.n, depth)[0] * tx_exp2i(-t_prev);
+    const f32x4 hb = *reinterpret_cast<const f32x4*>(lds + TX_RING_OF(NW) + depth * HID * 4);
+    const float dh = tx_meta<NW>(lds, a.n, depth)[0] * tx_exp2i(-t_prev);
 #pragma unroll
     for (int i = 0; i < 3; ++i) res[i] = 1.0f / (1.0f + expf(-(__builtin_fmaf(accA[0][i] + accA[NH][i], dh, hb[i]))));
     res[3] = fmaxf(__builtin_fmaf(accA[0][3] + accA[NH][3], dh, hb[3]), 0.0f);
 }
 
 template <int HID, bool TRAIN>
-__global__ TX_PLAIN_F32 __launch_bounds__((TxCfg<HID, TRAIN>::NW * 64), 1) void k_renderx3(FwdX3Args a) {
-    constexpr int NW = TxCfg<HID, TRAIN>::NW;
+__global__ TX_PLAIN_F32 __launch_bounds__((TRAIN ? TxCfg<HID>::RAY : TxCfg<HID>::RENDER) * 64, 1) void k_renderx3(FwdX3Args a) {
+    constexpr int NW = TRAIN ? TxCfg<HID>::RAY : TxCfg<HID>::RENDER;
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
 #ifdef TN_STAMPS
     const unsigned long long st_entry = __builtin_amdgcn_s_memrealtime();
@@ -192,7 +196,7 @@ __global__ TX_PLAIN_F32 __launch_bounds__((TxCfg<HID, TRAIN>::NW * 64), 1) void 
     unsigned char* lds_bnd0 = lds + TX_BND_OFF(a.n, NW, true);
     unsigned char* lds_bnd = lds_bnd0 + lane * 4;                  // this lane's bound words (forward: TNB_H(l) = l, TNB_ENC)
     tx_prologue<NW, TRAIN>(p, lds, a.packed3, a.n, a.packed3, a.n.n_stage, lane, wave, TRAIN ? lds_bnd0 : nullptr);
-    unsigned char* E = lds + TX_RING + TX_CONST_BYTES(a.n) + wave * TX_ELDS_WAVE + lane * 16;      // this lane's input pieces
+    unsigned char* E = lds + TX_RING_OF(NW) + TX_CONST_BYTES(a.n) + wave * TX_ELDS_WAVE + lane * 16;      // this lane's input pieces
     TxProf pf;
 #ifdef TN_STAMPS
     const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
@@ -210,10 +214,8 @@ __global__ TX_PLAIN_F32 __launch_bounds__((TxCfg<HID, TRAIN>::NW * 64), 1) void 
         const int64_t ray = g * NW + wave;
         const bool rvalid = ray < R;
         const int64_t rayc = rvalid ? ray : R - 1;
-        float ro_[3], rd_[3];
-        tn_fetch_ray(rs, rayc, ro_, rd_);
-        const float ox = ro_[0], oy = ro_[1], oz = ro_[2], dx = rd_[0], dy = rd_[1], dz = rd_[2];
-        const float dn = tn_norm3(dx, dy, dz);
+        float dn;
+        { float ro_[3], rd_[3]; tn_fetch_ray(rs, rayc, ro_, rd_); dn = tn_norm3(rd_[0], rd_[1], rd_[2]); }
         float T_in = 1.0f, cr = 0.f, cg = 0.f, cb = 0.f, cd = 0.f, ca = 0.f;
         // March the ray 32 samples per pass; every second pass (or the last one) the 64 lanes composite a segment: lane l <- sample s0 + l.
         float v[4] = {0.f, 0.f, 0.f, 0.f};
@@ -223,7 +225,12 @@ __global__ TX_PLAIN_F32 __launch_bounds__((TxCfg<HID, TRAIN>::NW * 64), 1) void 
                 const bool valid = rvalid && s < S;
                 const int sc = s < S ? s : S - 1;
                 const float z = tn_depth(sa, rayc, sc);
-                const float px = tn_point(ox, dx, z), py = tn_point(oy, dy, z), pz = tn_point(oz, dz, z);
+                // the ray is fetched again for every tile (behind a barrier the loop-invariant-code motion cannot cross): origin and
+                // direction are needed HERE only, and six registers held through the layer walk are six the walk does not have
+                int64_t rayt = rayc; asm volatile("" : "+s"(rayt));
+                float ro_[3], rd_[3];
+                tn_fetch_ray(rs, rayt, ro_, rd_);
+                const float px = tn_point(ro_[0], rd_[0], z), py = tn_point(ro_[1], rd_[1], z), pz = tn_point(ro_[2], rd_[2], z);
                 EncX Er;
                 float encf[8 * TN16_KE];
                 tx_encode(px, py, pz, Lf, h, encf);
@@ -235,7 +242,7 @@ __global__ TX_PLAIN_F32 __launch_bounds__((TxCfg<HID, TRAIN>::NW * 64), 1) void 
                 tx_split_input(Er, tx_exp2i(in.te), [&](auto ac) TN_INLINE_LAMBDA { return encf[decltype(ac)::value]; });
                 tx_store_input(E, Er);
                 float res[4];
-                tx_mlp_tile<HID, TRAIN>(p, lds, a, h, lane, E, in, rayc * S + sc, valid, res, pf, lds_bnd);
+                tx_mlp_tile<HID, TRAIN, NW>(p, lds, a, h, lane, E, in, rayc * S + sc, valid, res, pf, lds_bnd);
                 const bool upper = (sb & 32) != 0;                            // wave-uniform
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -316,7 +323,7 @@ template <> struct TxMask<2> {
 };
 
 // dzh[4]: this lane's head gradients (r,g,b,sigma pre-activation) for sample m.
-template <int HID>
+template <int HID, int NW>
 __device__ __forceinline__ void tx_bwd_tile(PipeX& p, const unsigned char* lds, const BwdX3Args& a, const float (&dzh)[4], int64_t m, bool valid,
                                             int lane, unsigned char* lds_bnd) {
     constexpr int NT = HID / 32;
@@ -330,7 +337,9 @@ __device__ __forceinline__ void tx_bwd_tile(PipeX& p, const unsigned char* lds, 
 #pragma unroll
         for (int i = 0; i < 4; ++i) pl[(L.dzh_row0 + i) * 32] = dzh[i];
     }
-    const uint32_t* __restrict__ mrow = reinterpret_cast<const uint32_t*>(stash + TN_STASH_BODY_FLOATS(L, Mp)) + (2 * ms + h) * (NT / 2);
+    // this lane's sign words of layer depth-1; stepped down a layer with every fetch (as the row offset below: one live copy each)
+    const uint32_t* __restrict__ mptr = reinterpret_cast<const uint32_t*>(stash + TN_STASH_BODY_FLOATS(L, Mp)) + (2 * ms + h) * (NT / 2)
+                                        + (int64_t)(depth - 1) * (Mp + 32) * NT;
     ActX<HID> X;
     EncX Z;                                                        // the head gradient as the B operand of the heads^T k-step (slot (h=0, e<4) = row e)
     // scale of the head gradient: its largest magnitude; the bound on dH_{depth-1} = W_head^T dZ_head: max|W_head| ||dZ_head||_1
@@ -345,17 +354,16 @@ __device__ __forceinline__ void tx_bwd_tile(PipeX& p, const unsigned char* lds, 
         const u32x4 w1 = {a0, a1, 0u, 0u}, w2 = {b0, b1, 0u, 0u};
         Z.p1[0] = w1; Z.p2[0] = w2;
     }
-    constexpr int NH = NT / 2, KH = HID / 16, NP = NH * 8, NW = TxCfg<HID>::NW, G2 = KH / 2 * NH;
+    constexpr int NH = NT / 2, KH = HID / 16, NP = NH * 8, G2 = KH / 2 * NH, DPW = TX_STAGE / NW;
     f32x16 accA[TX_ACCN(HID)], accB[TX_ACCN(HID)];
     uint32_t mw[NT / 2];
     TxEpi es;
     TxScale sc{0.0f, 0.0f, {0.0f, 0.0f}, tx_konst()};
     TxMask<NT / 2> mk;                                             // asm load + counted wait (above)
     TxDst zrow = tx_dst_tile(stash, L.stash_rows, m, valid, h);
-    const uint32_t dst_off0 = zrow.off;
     // The product W_l^T dZ_l (l = depth: the heads) is about to enter its epilogues: the L1 norm of dZ_l is complete.
     auto scale_for = [&](int l, float l1_in) TN_INLINE_LAMBDA {
-        const f32x4 mt = tx_meta(lds, a.n, l);
+        const f32x4 mt = tx_meta<NW>(lds, a.n, l);
         const int t_out = tx_scale_exp(mt[1] * l1_in);
         tx_bound_note(lds_bnd, l - 1, mt[1] * l1_in);                          // bounds dH_{l-1}, hence dZ_{l-1} (local index of TNB_DZ(l - 1))
         sc.dsc = mt[0] * tx_exp2i(-t_prev); sc.osc = tx_exp2i(t_out); sc.l1 = f32x2{0.0f, 0.0f};
@@ -384,26 +392,27 @@ __device__ __forceinline__ void tx_bwd_tile(PipeX& p, const unsigned char* lds, 
     static_assert(tx_half_b_ok<HID, GB, SPF>(), "half B's epilogue window overruns the first read of its pieces");
     static_assert(tx_half_a_ok<HID, TX_WA, GA, SPF>(), "half A's epilogue window writes an activation slot pass B still reads, or overruns the pass");
     // dH_{depth-1} = W_head^T dZ_head: both halves; half A's epilogue has nothing to hide behind
-    mk.fetch(mrow + (int64_t)(depth - 1) * (Mp + 32) * NT);
+    mk.fetch(mptr);
     tx_pass_headsT<HID, NW>(p, lds, Z, accA, accB);
-    mk.template wait<TxCfg<HID>::DPW>();                           // one boundary (DPW DMAs) was issued behind the fetch
+    mk.template wait<DPW>();                           // one boundary (DPW DMAs) was issued behind the fetch
 #pragma unroll
     for (int w = 0; w < NT / 2; ++w) mw[w] = mk.v[w];
-    zrow.off = dst_off0 + (uint32_t)L.dz_row0[depth - 1] * 128u;
+    zrow.off += (uint32_t)L.dz_row0[depth - 1] * 128u;
     scale_for(depth, (fabsf(dzh[0]) + fabsf(dzh[1])) + (fabsf(dzh[2]) + fabsf(dzh[3])));
     tx_drain<NP, TX_NSTEP>(epiA);
     // layer l (dH_{l-1} = W_l^T dZ_l): dZ_l's half B epilogue behind pass A; the sign words of layer l-1 are fetched before pass A
     // and waited for (>= TX_LEAD boundaries later) at the start of pass B, where dZ_{l-1}'s half A epilogue begins
     for (int l = depth - 1; l >= 1; --l) {
-        mk.fetch(mrow + (int64_t)(l - 1) * (Mp + 32) * NT);
+        mptr -= (Mp + 32) * NT;
+        mk.fetch(mptr);
         tx_pass<HID, 1, true, NW>(p, lds, X, nullptr, accA, tx_window<0, GB, NP, 0, TX_NSTEP, SPF>(epiB_w));
         auto wa = tx_window<TX_WA, GA, NP, 0, TX_NSTEP, SPF>(epiA_w);
         tx_pass<HID, 1, true, NW>(p, lds, X, nullptr, accB, [&](auto sc_) TN_INLINE_LAMBDA {
             if constexpr (decltype(sc_)::value == 0) {
-                mk.template wait<TxCfg<HID>::DPW * TX_LEAD>();
+                mk.template wait<DPW * TX_LEAD_OF(NW)>();
 #pragma unroll
                 for (int w = 0; w < NT / 2; ++w) mw[w] = mk.v[w];
-                zrow.off = dst_off0 + (uint32_t)L.dz_row0[l - 1] * 128u;
+                zrow.off += (uint32_t)(L.dz_row0[l - 1] - L.dz_row0[l]) * 128u;      // (mod 2^32)
                 const float l1_own = sc.l1[0] + sc.l1[1];
                 scale_for(l, l1_own + tx_partner(l1_own));
             }
@@ -414,8 +423,8 @@ __device__ __forceinline__ void tx_bwd_tile(PipeX& p, const unsigned char* lds, 
 }
 
 template <int HID>
-__global__ TX_PLAIN_F32 __launch_bounds__(TxCfg<HID>::NW * 64, 1) void k_dgradx3(BwdX3Args a) {
-    constexpr int NW = TxCfg<HID>::NW;
+__global__ TX_PLAIN_F32 __launch_bounds__(TxCfg<HID>::RAY * 64, 1) void k_dgradx3(BwdX3Args a) {
+    constexpr int NW = TxCfg<HID>::RAY;
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
     if (!tn_stash_tag_is(a.b.stash, a.b.L, a.b.Mp, TN_TAG_X3)) return;      // not an x3 forward's stash: its sign words mean something else
     const int lane = tn_lane();
@@ -492,7 +501,7 @@ __global__ TX_PLAIN_F32 __launch_bounds__(TxCfg<HID>::NW * 64, 1) void k_dgradx3
                 for (int i = 0; i < 4; ++i) dzh[i] = __shfl(d4[i], 32 * half + (lane & 31), 64);
                 const int st = sb + (lane & 31);
                 const bool valid = rvalid && st < S;
-                tx_bwd_tile<HID>(p, lds, a, dzh, rayc * S + (st < S ? st : S - 1), valid, lane, lds_bnd);
+                tx_bwd_tile<HID, NW>(p, lds, a, dzh, rayc * S + (st < S ? st : S - 1), valid, lane, lds_bnd);
             }
         }
     }
@@ -517,9 +526,9 @@ __device__ __forceinline__ void tx_load_input(const float* __restrict__ xrow, bo
 }
 
 template <int HID, bool TRAIN>
-__global__ TX_PLAIN_F32 __launch_bounds__((TxCfg<HID, TRAIN>::NW * 64), 1) void k_mlpx3_fwd(FwdX3Args a) {
+__global__ TX_PLAIN_F32 __launch_bounds__(TxCfg<HID>::RAY * 64, 1) void k_mlpx3_fwd(FwdX3Args a) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
-    constexpr int NW = TxCfg<HID, TRAIN>::NW;
+    constexpr int NW = TxCfg<HID>::RAY;
     const int lane = tn_lane();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int j = lane & 31, h = lane >> 5;
@@ -527,7 +536,7 @@ __global__ TX_PLAIN_F32 __launch_bounds__((TxCfg<HID, TRAIN>::NW * 64), 1) void 
     unsigned char* lds_bnd0 = lds + TX_BND_OFF(a.n, NW, true);
     unsigned char* lds_bnd = lds_bnd0 + lane * 4;                  // this lane's bound words (forward: TNB_H(l) = l, TNB_ENC)
     tx_prologue<NW, TRAIN>(p, lds, a.packed3, a.n, a.packed3, a.n.n_stage, lane, wave, TRAIN ? lds_bnd0 : nullptr);
-    unsigned char* E = lds + TX_RING + TX_CONST_BYTES(a.n) + wave * TX_ELDS_WAVE + lane * 16;
+    unsigned char* E = lds + TX_RING_OF(NW) + TX_CONST_BYTES(a.n) + wave * TX_ELDS_WAVE + lane * 16;
     TxProf pf;
     const int64_t M = a.f.M, n_tiles = (M + 31) / 32, n_groups = (n_tiles + NW - 1) / NW;
     const int in_dim = a.n.in_dim, Lf = a.n.Lf;
@@ -549,7 +558,7 @@ __global__ TX_PLAIN_F32 __launch_bounds__((TxCfg<HID, TRAIN>::NW * 64), 1) void 
         tx_split_input(Er, tx_exp2i(in.te), [&](auto ac) TN_INLINE_LAMBDA { return encf[decltype(ac)::value]; });
         tx_store_input(E, Er);
         float res[4];
-        tx_mlp_tile<HID, TRAIN, !TRAIN>(p, lds, a, h, lane, E, in, mc, valid, res, pf, lds_bnd);      // (training: the asm accumulator reads cost this kernel 9 spilled values)
+        tx_mlp_tile<HID, TRAIN, NW, !TRAIN>(p, lds, a, h, lane, E, in, mc, valid, res, pf, lds_bnd);      // (training: the asm accumulator reads cost this kernel 9 spilled values)
         // the sample index is formed again behind the tile (from a lane id the compiler cannot match with the one above): kept alive
         // across the layer walk, the 64-bit index was what spilled to scratch in the 256-wide training kernel
         int lane2 = lane; asm volatile("" : "+v"(lane2));
@@ -571,9 +580,9 @@ __global__ TX_PLAIN_F32 __launch_bounds__((TxCfg<HID, TRAIN>::NW * 64), 1) void 
 }
 
 template <int HID>
-__global__ TX_PLAIN_F32 __launch_bounds__(TxCfg<HID>::NW * 64, 1) void k_mlpx3_bwd(BwdX3Args a) {
+__global__ TX_PLAIN_F32 __launch_bounds__(TxCfg<HID>::TILE * 64, 1) void k_mlpx3_bwd(BwdX3Args a) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
-    constexpr int NW = TxCfg<HID>::NW;
+    constexpr int NW = TxCfg<HID>::TILE;
     if (!tn_stash_tag_is(a.b.stash, a.b.L, a.b.Mp, TN_TAG_X3)) return;      // not an x3 forward's stash
     const int lane = tn_lane();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -594,7 +603,7 @@ __global__ TX_PLAIN_F32 __launch_bounds__(TxCfg<HID>::NW * 64, 1) void k_mlpx3_b
         }
         const float sg = tn_stash_at(a.b.stash, a.b.L.stash_rows, mc)[(a.b.L.out_row0 + 3) * 32];
         dzh[3] = (valid && sg > 0.0f) ? a.b.d_sigma[mc] : 0.0f;                            // ReLU backward
-        tx_bwd_tile<HID>(p, lds, a, dzh, mc, valid, lane, lds_bnd);
+        tx_bwd_tile<HID, NW>(p, lds, a, dzh, mc, valid, lane, lds_bnd);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     tx_bound_flush<NW>(lds_bnd0, a.b.stash + TN_BOUND_OFF(a.b.L, a.b.Mp), TNB_DZ(0), lane, wave);
@@ -612,8 +621,8 @@ __global__ TX_PLAIN_F32 __launch_bounds__(TxCfg<HID>::NW * 64, 1) void k_mlpx3_b
 //   k_tilex3_bwd  tile -> head gradients from the stash -> the dgrad chain (tx_bwd_tile)
 // The launchers take this route when rays < waves (tnx3_tile_units); results are bit-identical to the ray kernels'.
 template <int HID>
-__global__ TX_PLAIN_F32 __launch_bounds__((TxCfg<HID, true>::NW * 64), 1) void k_tilex3_fwd(FwdX3Args a) {
-    constexpr int NW = TxCfg<HID, true>::NW;
+__global__ TX_PLAIN_F32 __launch_bounds__(TxCfg<HID>::TILE * 64, 1) void k_tilex3_fwd(FwdX3Args a) {
+    constexpr int NW = TxCfg<HID>::TILE;
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
     const int lane = tn_lane();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -625,7 +634,7 @@ __global__ TX_PLAIN_F32 __launch_bounds__((TxCfg<HID, true>::NW * 64), 1) void k
     unsigned char* lds_bnd0 = lds + TX_BND_OFF(a.n, NW, true);
     unsigned char* lds_bnd = lds_bnd0 + lane * 4;
     tx_prologue<NW, true>(p, lds, a.packed3, a.n, a.packed3, a.n.n_stage, lane, wave, lds_bnd0);
-    unsigned char* E = lds + TX_RING + TX_CONST_BYTES(a.n) + wave * TX_ELDS_WAVE + lane * 16;
+    unsigned char* E = lds + TX_RING_OF(NW) + TX_CONST_BYTES(a.n) + wave * TX_ELDS_WAVE + lane * 16;
     TxProf pf;
     const int64_t R = a.f.R, units = R * nt, n_groups = (units + NW - 1) / NW;
     for (int64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {         // every wave of the workgroup runs every pass (stage barriers)
@@ -653,7 +662,7 @@ __global__ TX_PLAIN_F32 __launch_bounds__((TxCfg<HID, true>::NW * 64), 1) void k
         tx_split_input(Er, tx_exp2i(in.te), [&](auto ac) TN_INLINE_LAMBDA { return encf[decltype(ac)::value]; });
         tx_store_input(E, Er);
         float res[4];
-        tx_mlp_tile<HID, true>(p, lds, a, h, lane, E, in, m, valid, res, pf, lds_bnd);
+        tx_mlp_tile<HID, true, NW>(p, lds, a, h, lane, E, in, m, valid, res, pf, lds_bnd);
         int lane2 = lane; asm volatile("" : "+v"(lane2));             // (as k_mlpx3_fwd: the index is formed again behind the tile)
         const int s2 = sb + (lane2 & 31);
         if (uvalid && s2 < S && (lane2 >> 5) == 0) {
@@ -781,9 +790,9 @@ __global__ __launch_bounds__(256) void k_compx3(CompX3Args a) {
 }
 
 template <int HID>
-__global__ TX_PLAIN_F32 __launch_bounds__(TxCfg<HID>::NW * 64, 1) void k_tilex3_bwd(BwdX3Args a) {
+__global__ TX_PLAIN_F32 __launch_bounds__(TxCfg<HID>::TILE * 64, 1) void k_tilex3_bwd(BwdX3Args a) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
-    constexpr int NW = TxCfg<HID>::NW;
+    constexpr int NW = TxCfg<HID>::TILE;
     if (!tn_stash_tag_is(a.b.stash, a.b.L, a.b.Mp, TN_TAG_X3)) return;
     const int lane = tn_lane();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -806,44 +815,61 @@ __global__ TX_PLAIN_F32 __launch_bounds__(TxCfg<HID>::NW * 64, 1) void k_tilex3_
         float dzh[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) dzh[i] = valid ? q[32 * i] : 0.0f;
-        tx_bwd_tile<HID>(p, lds, a, dzh, mc, valid, lane, lds_bnd);
+        tx_bwd_tile<HID, NW>(p, lds, a, dzh, mc, valid, lane, lds_bnd);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     tx_bound_flush<NW>(lds_bnd0, a.b.stash + TN_BOUND_OFF(a.b.L, a.b.Mp), TNB_DZ(0), lane, wave);
 }
 
+#ifdef TX_SKIP256      // compile-time experiments on the 128-wide kernels only (never in a library build: -DTN_DIAG)
+#ifndef TN_DIAG
+#error "TX_SKIP256 is a diagnostic knob"
+#endif
+#define TX_IF256(...)
+#else
+#define TX_IF256(...) __VA_ARGS__
+#endif
 // rays < waves: the tile route (above).  TNERF_X3_UNITS=rays / tiles overrides (A/B runs, the bitwise test of the two routes).
-static bool tnx3_tile_units(int64_t R, int32_t S, int n_cu) {
+// 128-wide networks train through the tile kernels whenever a ray has more than one tile: those run two waves per SIMD (TxCfg), which the
+// ray kernels' compositing state does not leave the registers for.
+static bool tnx3_tile_units(int64_t R, int32_t S, int64_t n_waves, int hidden) {
     const char* e = getenv("TNERF_X3_UNITS");                        // (read per launch: a test flips it between two calls)
     const int force = !e ? 0 : (e[0] == 't' ? 1 : (e[0] == 'r' ? -1 : 0));
     if (force) return force > 0 && S > 0;
-    return S > 32 && R < (int64_t)4 * n_cu;
+    return S > 32 && (R < n_waves || (hidden == 128 && TxCfg<128>::TILE > TxCfg<128>::RAY));
+}
+static int tnx3_waves(int hidden, int kind) {      // kind 0: ray training kernels + module forward, 1: tile kernels + module backward, 2: inference render
+    if (hidden == 256) return kind == 0 ? TxCfg<256>::RAY : (kind == 1 ? TxCfg<256>::TILE : TxCfg<256>::RENDER);
+    return kind == 0 ? TxCfg<128>::RAY : (kind == 1 ? TxCfg<128>::TILE : TxCfg<128>::RENDER);
 }
 
 // units: rays (fused) or 32-sample tiles (mlp_only) — one per wave and pass
 int tnx3_launch_dgrad(const BwdX3Args& a, bool mlp_only, hipStream_t stream, const char* who) {
     const int dev = tn_stream_device(stream), n_cu = tn_device_cus(dev);
-    const int nw = a.n.hidden == 256 ? TxCfg<256>::NW : TxCfg<128>::NW;
+    const int nw = tnx3_waves(a.n.hidden, mlp_only ? 1 : 0);        // k_mlpx3_bwd | k_dgradx3
     const int64_t units = mlp_only ? (a.b.M + 31) / 32 : a.b.R, groups = (units + nw - 1) / nw;
     const dim3 grid((unsigned)(groups < n_cu ? groups : n_cu)), block(nw * 64);
     const size_t lds_bytes = TX_LDS_BYTES(a.n, nw, false);
-    if (!mlp_only && tnx3_tile_units(a.b.R, a.b.sa.S, n_cu)) {       // fewer rays than waves: tiles as the unit (k_tilex3_bwd)
+    if (!mlp_only && tnx3_tile_units(a.b.R, a.b.sa.S, (int64_t)nw * n_cu, a.n.hidden)) {       // tiles as the unit (k_tilex3_bwd)
+        const int tw = tnx3_waves(a.n.hidden, 1);
+        const dim3 tblock(tw * 64);
+        const size_t tlds = TX_LDS_BYTES(a.n, tw, false);
         CompX3Args c{};
         c.L = a.b.L; c.stash = a.b.stash; c.Mp = a.b.Mp; c.rs = a.b.rs; c.sa = a.b.sa; c.R = a.b.R; c.white = a.b.white;
         c.g_comp = a.b.g_comp; c.g_stride = a.b.g_stride;
         hipLaunchKernelGGL((k_compx3<false, true>), dim3((unsigned)((a.b.R + 3) / 4)), dim3(256), 0, stream, c);
         TN_HIP_CHECK_LAUNCH(who);
-        const int64_t tiles = a.b.R * ((a.b.sa.S + 31) / 32), tg = (tiles + nw - 1) / nw;
+        const int64_t tiles = a.b.R * ((a.b.sa.S + 31) / 32), tg = (tiles + tw - 1) / tw;
         const dim3 tgrid((unsigned)(tg < n_cu ? tg : n_cu));
 #define TX_TCASE(H_)                                                                                                          \
         if (a.n.hidden == H_) {                                                                                               \
             static std::atomic<uint32_t> seen_[TN_MAX_DEVICES];                                                               \
-            if (int rc_ = tn_grant_dyn_lds(reinterpret_cast<const void*>(&k_tilex3_bwd<H_>), lds_bytes, dev, seen_, who)) return rc_; \
-            hipLaunchKernelGGL((k_tilex3_bwd<H_>), tgrid, block, lds_bytes, stream, a);                                       \
+            if (int rc_ = tn_grant_dyn_lds(reinterpret_cast<const void*>(&k_tilex3_bwd<H_>), tlds, dev, seen_, who)) return rc_; \
+            hipLaunchKernelGGL((k_tilex3_bwd<H_>), tgrid, tblock, tlds, stream, a);                                           \
             TN_HIP_CHECK_LAUNCH(who);                                                                                         \
             return TNERF_OK;                                                                                                  \
         }
-        TX_TCASE(256) TX_TCASE(128)
+        TX_IF256(TX_TCASE(256)) TX_TCASE(128)
 #undef TX_TCASE
     }
 #define TX_CASE(H_, K_, M_)                                                                                                  \
@@ -854,7 +880,7 @@ int tnx3_launch_dgrad(const BwdX3Args& a, bool mlp_only, hipStream_t stream, con
         TN_HIP_CHECK_LAUNCH(who);                                                                                             \
         return TNERF_OK;                                                                                                      \
     }
-    TX_CASE(256, k_dgradx3, false) TX_CASE(128, k_dgradx3, false) TX_CASE(256, k_mlpx3_bwd, true) TX_CASE(128, k_mlpx3_bwd, true)
+    TX_IF256(TX_CASE(256, k_dgradx3, false)) TX_CASE(128, k_dgradx3, false) TX_IF256(TX_CASE(256, k_mlpx3_bwd, true)) TX_CASE(128, k_mlpx3_bwd, true)
 #undef TX_CASE
     tn_set_error("%s: no x3 kernel for hidden=%d", who, a.n.hidden);
     return TNERF_EUNSUPPORTED;
@@ -881,23 +907,26 @@ int tnx3_launch_fwd(const FwdX3Args& a, bool train, hipStream_t stream, const ch
         hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, stream, reinterpret_cast<unsigned*>(a.f.stash + TN_BOUND_OFF(a.f.L, a.f.Mp)), TN_BOUND_FLOATS);
         TN_HIP_CHECK_LAUNCH(who);
     }
-    const int nw = a.n.hidden == 256 ? 4 : (train ? TxCfg<128, true>::NW : TxCfg<128, false>::NW);
+    const int nw = tnx3_waves(a.n.hidden, (mlp_only || train) ? 0 : 2);      // k_mlpx3_fwd, k_renderx3<.., true> | k_renderx3<.., false>
     const int64_t units = mlp_only ? (a.f.M + 31) / 32 : a.f.R, groups = (units + nw - 1) / nw;
     const dim3 grid((unsigned)(groups < n_cu ? groups : n_cu)), block(nw * 64);
     const size_t lds_bytes = TX_LDS_BYTES(a.n, nw, true);
-    if (train && !mlp_only && tnx3_tile_units(a.f.R, a.f.sa.S, n_cu)) {      // fewer rays than waves: tiles as the unit, then the rays' compositing
-        const int64_t tiles = a.f.R * ((a.f.sa.S + 31) / 32), tg = (tiles + nw - 1) / nw;
+    if (train && !mlp_only && tnx3_tile_units(a.f.R, a.f.sa.S, (int64_t)nw * n_cu, a.n.hidden)) {      // tiles as the unit, then the rays' compositing
+        const int tw = tnx3_waves(a.n.hidden, 1);
+        const dim3 tblock(tw * 64);
+        const size_t tlds = TX_LDS_BYTES(a.n, tw, true);
+        const int64_t tiles = a.f.R * ((a.f.sa.S + 31) / 32), tg = (tiles + tw - 1) / tw;
         const dim3 tgrid((unsigned)(tg < n_cu ? tg : n_cu));
         int launched = 0;
 #define TX_TCASE(H_)                                                                                                          \
         if (a.n.hidden == H_) {                                                                                               \
             static std::atomic<uint32_t> seen_[TN_MAX_DEVICES];                                                               \
-            if (int rc_ = tn_grant_dyn_lds(reinterpret_cast<const void*>(&k_tilex3_fwd<H_>), lds_bytes, dev, seen_, who)) return rc_; \
-            hipLaunchKernelGGL((k_tilex3_fwd<H_>), tgrid, block, lds_bytes, stream, a);                                       \
+            if (int rc_ = tn_grant_dyn_lds(reinterpret_cast<const void*>(&k_tilex3_fwd<H_>), tlds, dev, seen_, who)) return rc_; \
+            hipLaunchKernelGGL((k_tilex3_fwd<H_>), tgrid, tblock, tlds, stream, a);                                           \
             TN_HIP_CHECK_LAUNCH(who);                                                                                         \
             launched = 1;                                                                                                     \
         }
-        TX_TCASE(256) TX_TCASE(128)
+        TX_IF256(TX_TCASE(256)) TX_TCASE(128)
 #undef TX_TCASE
         if (!launched) { tn_set_error("%s: no x3 kernel for hidden=%d", who, a.n.hidden); return TNERF_EUNSUPPORTED; }
         CompX3Args c{};
@@ -915,7 +944,7 @@ int tnx3_launch_fwd(const FwdX3Args& a, bool train, hipStream_t stream, const ch
         TN_HIP_CHECK_LAUNCH(who);                                                                                             \
         return TNERF_OK;                                                                                                      \
     }
-    if (!mlp_only) { TX_CASE(256, false) TX_CASE(256, true) TX_CASE(128, false) TX_CASE(128, true) }
+    if (!mlp_only) { TX_IF256(TX_CASE(256, false) TX_CASE(256, true)) TX_CASE(128, false) TX_CASE(128, true) }
 #undef TX_CASE
 #define TX_CASE(H_, T_)                                                                                                      \
     if (a.n.hidden == H_ && train == T_) {                                                                                    \
@@ -925,7 +954,7 @@ int tnx3_launch_fwd(const FwdX3Args& a, bool train, hipStream_t stream, const ch
         TN_HIP_CHECK_LAUNCH(who);                                                                                             \
         return TNERF_OK;                                                                                                      \
     }
-    if (mlp_only) { TX_CASE(256, false) TX_CASE(256, true) TX_CASE(128, false) TX_CASE(128, true) }
+    if (mlp_only) { TX_IF256(TX_CASE(256, false) TX_CASE(256, true)) TX_CASE(128, false) TX_CASE(128, true) }
 #undef TX_CASE
     tn_set_error("%s: no x3 kernel for hidden=%d", who, a.n.hidden);
     return TNERF_EUNSUPPORTED;

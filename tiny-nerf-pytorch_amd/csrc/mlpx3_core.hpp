@@ -42,9 +42,13 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define TX_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
 
 #define TX_SLOT (TX_STAGE * 1024)              // bytes per stage
-#define TX_NS 7                                // ring slots
-#define TX_RING (TX_NS * TX_SLOT)              // 112 KB
-#define TX_LEAD 5                              // stages in flight behind the published one (LEAD + 2 <= NS)
+// The ring by the workgroup's wave count.  4 waves (one per SIMD, 512 registers each: the 256-wide kernels): 7 slots = 112 KB, 5 stages
+// in flight behind the published one.  8 waves (two per SIMD, 256 registers each: the 128-wide fused kernels, TxCfg): the eight
+// waves' input pieces take 64 KB of LDS, so 5 slots = 80 KB and 3 stages in flight — the two waves of a SIMD share its matrix pipe,
+// a stage lasts twice as long on the wall clock and a DMA still has ~3 k cycles to land.  NS = LEAD + 2 always (tx_boundary).
+#define TX_NS_OF(nw) ((nw) == 8 ? 5 : 7)                        // ring slots
+#define TX_LEAD_OF(nw) (TX_NS_OF(nw) - 2)                       // stages in flight behind the published one
+#define TX_RING_OF(nw) (TX_NS_OF(nw) * TX_SLOT)                 // 112 KB / 80 KB
 #ifndef TX_WAIT_EXTRA
 #define TX_WAIT_EXTRA 0                            // TN_DIAG timing experiments only: a non-zero value makes the stage wait too lax (wrong results)
 #elif !defined(TN_DIAG)
@@ -52,12 +56,25 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #endif
 #define TX_TOP 14                              // scaled activations stay below 2^TX_TOP
 #define TX_BND_N (TN_MAXD + 1)                 // row groups whose magnitude bounds a training kernel keeps (see TX_BND_OFF)
-template <int HID, bool TRAIN_FWD = false> struct TxCfg {
-    static constexpr int NW = 4;                                  // one wave per SIMD (the split accumulators need its 512 registers)
-    static constexpr int DPW = TX_STAGE / NW;                     // DMA pieces per wave and stage
-    static_assert(TX_STAGE % NW == 0 && DPW <= 8, "ring budget");
+// Waves per workgroup, by kernel.  256-wide: one wave per SIMD everywhere (pieces 128 + split accumulators 256 registers).  128-wide:
+// pieces 64 + accumulators 128 registers fit a 256-register wave, so the kernels that carry little besides the tile run TWO waves per
+// SIMD.  Why: one wave gets ~3 non-MFMA instructions per MFMA for free and pays ~4 cycles for each further one — a 128-wide epilogue
+// carries 8 to 9 per MFMA; a second wave's MFMAs fill exactly those gaps (tools/microbench/two_waves.hip: the training mixture at 6
+// per MFMA runs at 102 cycles per 3 MFMAs with two waves, 136 with one; measured on the kernels: DESIGN.md).
+//   TILE    k_tilex3_fwd / k_tilex3_bwd / k_mlpx3_bwd                 8 at 128-wide
+//   RENDER  k_renderx3<.., false> (inference)                         8 at 128-wide
+//   RAY     k_renderx3<.., true> / k_dgradx3 (a ray's compositing state rides through the walk: 10-15 values too many for 256
+//           registers) and k_mlpx3_fwd (its in-memory input rows)     4: the launchers send 128-wide TRAINING through the tile kernels
+template <int HID> struct TxCfg {
+#ifdef TX_NW128                                                   // diagnostic builds: the 128-wide kernels at 4 waves again (A/B timing)
+    static constexpr int NW2 = HID == 128 ? TX_NW128 : 4;
+#else
+    static constexpr int NW2 = HID == 128 ? 8 : 4;
+#endif
+    static constexpr int TILE = NW2, RENDER = NW2, RAY = 4;
+    static_assert(TX_STAGE % NW2 == 0 && (NW2 == 4 || NW2 == 8), "ring budget");
 };
-static_assert(TX_LEAD + 2 <= TX_NS && TX_LEAD >= 3, "ring budget");
+static_assert(TX_LEAD_OF(8) >= 3 && TX_LEAD_OF(4) >= 3, "ring budget");
 
 // ---- fp16 pieces
 __device__ __forceinline__ unsigned tx_cvt2(float lo, float hi) {             // v_cvt_pk_f16_f32: two fp32 -> one dword of two fp16 (RNE)
@@ -117,7 +134,7 @@ __device__ __forceinline__ void tx_issue_stage(PipeX& p) {
     const unsigned char* s = p.src + p.src_off;
     tn_static_for<DPW>([&](auto ic) TN_INLINE_LAMBDA { tx_issue_piece<decltype(ic)::value>(s, p.voff, p.lds_dst0 + p.dst_off); });
     p.src_off += TX_SLOT; if (p.src_off == p.stream_bytes) p.src_off = 0;
-    p.dst_off += TX_SLOT; if (p.dst_off == TX_RING) p.dst_off = 0;
+    p.dst_off += TX_SLOT; if (p.dst_off == TX_RING_OF(TX_STAGE / DPW)) p.dst_off = 0;
 }
 // M0 for a whole deferred stage.  hipcc emits no M0 use of its own in these kernels (tests/test_kernel_resources.py checks the
 // ISA for that), and every other DMA (tx_issue_piece, tn_glds16) saves and restores it, so M0 written at the stage boundary still
@@ -134,11 +151,12 @@ __device__ __forceinline__ void tx_issue_piece_m0(const unsigned char* src, uint
 }
 // ... or piece by piece behind the MFMAs of the stage that has just been published (tx_pass): back-to-back DMA instructions
 // cost the wave more issue time than the same pieces spread over as many MFMA groups.
+template <int DPW>
 __device__ __forceinline__ void tx_defer_stage(PipeX& p) {
     p.pend_src = p.src + p.src_off; p.pend_dst = p.lds_dst0 + p.dst_off;
     tx_m0_set(p.pend_dst);
     p.src_off += TX_SLOT; if (p.src_off == p.stream_bytes) p.src_off = 0;
-    p.dst_off += TX_SLOT; if (p.dst_off == TX_RING) p.dst_off = 0;
+    p.dst_off += TX_SLOT; if (p.dst_off == TX_RING_OF(TX_STAGE / DPW)) p.dst_off = 0;
 }
 
 // Start of a stage: wait for this wave's DMA of the stage (LEAD-1 younger ones may stay in flight; the training kernels' stash
@@ -147,6 +165,7 @@ __device__ __forceinline__ void tx_defer_stage(PipeX& p) {
 // issues its pieces with tx_issue_piece before the next boundary).
 template <int DPW, bool DEFER>
 __device__ __forceinline__ void tx_boundary(PipeX& p) {
+    constexpr int LEAD = TX_LEAD_OF(TX_STAGE / DPW), RING = TX_RING_OF(TX_STAGE / DPW);
 #ifdef TN_STAGE_STAMPS
     if (p.smarks && p.sn < 500) p.smarks[p.sn++] = __builtin_amdgcn_s_memtime();
 #endif
@@ -159,19 +178,19 @@ __device__ __forceinline__ void tx_boundary(PipeX& p) {
     // wave loses at every barrier (stamps with and without barriers: 8.1 k / 9.0 k against 7.3 k / 8.3 k cycles per pass).
     p.par ^= 1u;
     if (p.par) {                                 // wave-uniform
-        TN16_WAIT_VM(DPW * (TX_LEAD - 2) + TX_WAIT_EXTRA);
+        TN16_WAIT_VM(DPW * (LEAD - 2) + TX_WAIT_EXTRA);
 #ifndef TX_NO_BARRIER    // diagnostic (races): what the stage barriers cost
         __builtin_amdgcn_s_barrier();
 #endif
     }
 #else
-    TN16_WAIT_VM(DPW * (TX_LEAD - 1) + TX_WAIT_EXTRA);
+    TN16_WAIT_VM(DPW * (LEAD - 1) + TX_WAIT_EXTRA);
 #ifndef TX_NO_BARRIER    // diagnostic (races): what the stage barriers cost
     __builtin_amdgcn_s_barrier();
 #endif
 #endif
-    if constexpr (DEFER) tx_defer_stage(p); else tx_issue_stage<DPW>(p);
-    p.cur += TX_SLOT; if (p.cur == TX_RING) p.cur = 0;
+    if constexpr (DEFER) tx_defer_stage<DPW>(p); else tx_issue_stage<DPW>(p);
+    p.cur += TX_SLOT; if (p.cur == RING) p.cur = 0;
 }
 
 // Workgroup prologue: biases + scale records -> LDS, LEAD stages in flight, the first one landed; the first tx_boundary
@@ -182,7 +201,7 @@ __device__ __forceinline__ void tx_prologue(PipeX& p, unsigned char* lds, const 
                                             const unsigned char* src, int n_stage, int lane, int wave, unsigned char* lds_bnd = nullptr) {
     constexpr int DPW = TX_STAGE / NW;
     {
-        float* bl = reinterpret_cast<float*>(lds + TX_RING);
+        float* bl = reinterpret_cast<float*>(lds + TX_RING_OF(NW));
         const float* bg = reinterpret_cast<const float*>(packed + n.bias_off);
         const int nf = n.n_bias + (n.depth + 1) * TX_META;            // the scale records follow the biases
         const int nneg = NEGB ? n.depth * n.hidden : 0;
@@ -199,8 +218,8 @@ __device__ __forceinline__ void tx_prologue(PipeX& p, unsigned char* lds, const 
     p.voff = lane * 16 + wave * DPW * 1024;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int i = 0; i < TX_LEAD; ++i) tx_issue_stage<DPW>(p);
-    p.cur = TX_RING - TX_SLOT;                   // the first boundary moves it onto slot 0
+    for (int i = 0; i < TX_LEAD_OF(NW); ++i) tx_issue_stage<DPW>(p);
+    p.cur = TX_RING_OF(NW) - TX_SLOT;                   // the first boundary moves it onto slot 0
     p.par = 0u;                                  // ... and is a barrier boundary
 #ifdef TN_STAGE_STAMPS
     p.smarks = nullptr; p.sn = 0;
@@ -215,7 +234,7 @@ __device__ __forceinline__ void tx_prologue(PipeX& p, unsigned char* lds, const 
 // first index) x 64 lanes: every lane keeps its own word (ds_max_u32 on per-lane addresses: one instruction, no conflict between
 // the lanes of a wave; a wave-uniform address would make hipcc emit a 64-step scalar reduction loop and an EXEC-masked atomic in
 // the middle of the MFMA stream), reduced over lanes and added to the stash's bound words once, at the end of the kernel.
-#define TX_BND_OFF(n, nw, fwd) (TX_RING + TX_CONST_BYTES(n) + ((fwd) ? (uint32_t)(nw) * TX_ELDS_WAVE : 0u))
+#define TX_BND_OFF(n, nw, fwd) (TX_RING_OF(nw) + TX_CONST_BYTES(n) + ((fwd) ? (uint32_t)(nw) * TX_ELDS_WAVE : 0u))
 #define TX_LDS_BYTES(n, nw, fwd) ((size_t)TX_BND_OFF(n, nw, fwd) + TX_BND_N * 64 * 4)
 // lds_bnd: this LANE's word of row group 0; idx: local row-group index
 __device__ __forceinline__ void tx_bound_note(unsigned char* lds_bnd, int idx, float bound) {
@@ -236,8 +255,9 @@ __device__ __forceinline__ void tx_bound_flush(const unsigned char* lds_bnd0, fl
     }
 }
 // scale record of layer l (l = depth: heads) in the LDS copy: {2^-s, max|W|, max|b|, -}
+template <int NW>
 __device__ __forceinline__ f32x4 tx_meta(const unsigned char* lds, const NetX3& n, int l) {
-    return *reinterpret_cast<const f32x4*>(lds + TX_RING + (n.n_bias + l * TX_META) * 4);
+    return *reinterpret_cast<const f32x4*>(lds + TX_RING_OF(NW) + (n.n_bias + l * TX_META) * 4);
 }
 
 // The activation of a wave's 32-sample tile: two fp16 pieces of every k-step operand.
@@ -273,7 +293,7 @@ __device__ __forceinline__ FragX tx_frag_load(const unsigned char* base, int tl)
 // The A fragments of a (tile, k-step) GROUP (three MFMAs = 96 cycles) are read TX_FD groups ahead (behind the first MFMA of a
 // group), and the stage boundary (wait, barrier, next DMA stage named) of every stage but the pass's first is taken TX_FD groups
 // EARLY, so that the new stage's first fragments are read behind MFMAs as well.  TX_FD = 2 measured the same as 1 (621 / 815 /
-// 722 us against 622 / 810 / 726 for render / training forward / dgrad) and costs eight registers: 1.  (The ring has the spare slot this needs: TX_LEAD + 2 <= TX_NS; the
+// 722 us against 622 / 810 / 726 for render / training forward / dgrad) and costs eight registers: 1.  (The ring has the spare slot this needs: LEAD + 2 = NS; the
 // slot a boundary hands to the DMA held the stage before the one whose last TX_FD groups are still running.)
 // elds: this lane's slot of the wave's network-input pieces in LDS (KIND 0; tx_store_input), read one k-step ahead.
 #ifndef TX_FD
@@ -664,6 +684,9 @@ __device__ __forceinline__ void tx_rescale_input(unsigned char* elds, int d) {
 // PositionalEncoding(L, include_input=True) of one point, fp32-accurate (tn_sincos, as the fp32 kernels), in the step numbering
 // of the training stash: encf[a], a = 8u + e.                                                reference src/encoding.py:27-33
 __device__ __forceinline__ void tx_encode(float px, float py, float pz, int Lf, int h, float (&encf)[8 * TN16_KE]) {
+    // Lf is a kernel argument: every `slot < 3 Lf` below is a loop-invariant wave-uniform condition, and hipcc hoists all ~60 of them out of
+    // the tile loop as 64-bit lane masks — 120 SGPRs, spilled to VGPR lanes.  Opaque here, they are evaluated per tile (scalar compares).
+    asm volatile("" : "+s"(Lf));
     // every slot is DEFINED before the conditional writes below (a slot written only under run-time conditions the compiler cannot
     // prove exhaustive would be an undefined value on the paths it cannot rule out)
     tn_static_for<8 * TN16_KE>([&](auto ac) TN_INLINE_LAMBDA { encf[decltype(ac)::value] = 0.0f; });

@@ -17,3 +17,11 @@ for (L, hid, dep, skip, R) in ((10, 128, 4, 2, 2048), (6, 256, 8, 4, 4096)):
     torch.cuda.synchronize(); t0 = time.perf_counter(); n = 300
     for _ in range(n): tr.step()
     torch.cuda.synchronize(); print(f"{dep}x{hid} L={L} R={R}: {(time.perf_counter() - t0) / n * 1e3:.4f} ms/step", flush=True)
+    # inference: a 400x400 image in chunks of 32768 rays (render_one's kernel)
+    import train as train_mod, encoding as enc_mod
+    enc = enc_mod.PositionalEncoding(L).to(dev)
+    with torch.no_grad():
+        for _ in range(3): train_mod.render_one(m, enc, 400, 400, focal * 4, poses[0], dev, 64, 2.0, 6.0, chunk=32768)
+        torch.cuda.synchronize(); t0 = time.perf_counter(); n = 10
+        for _ in range(n): train_mod.render_one(m, enc, 400, 400, focal * 4, poses[0], dev, 64, 2.0, 6.0, chunk=32768)
+        torch.cuda.synchronize(); print(f"{dep}x{hid} L={L}: render 400x400x64 {(time.perf_counter() - t0) / n * 1e3:.3f} ms/image", flush=True)

@@ -5,6 +5,7 @@ import ctypes as C, os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tiny-nerf-pytorch_amd")); sys.path.insert(0, os.path.join(ROOT, "tiny-nerf-pytorch_amd", "src"))
+os.environ["TNERF_X3_UNITS"] = "rays"            # the stamps live in the ray kernels
 os.environ["TNERF_LIB"] = os.path.join(ROOT, "tiny-nerf-pytorch_amd", "tnerf", f"libtnerf_variant_{sys.argv[1] if len(sys.argv) > 1 else 'x3stamps'}.so")
 from tnerf import ops, lib
 import nerf
@@ -21,11 +22,14 @@ for (L, hidden, depth, skip, R, S) in ((6, 256, 8, 4, 4096, 64), (10, 128, 4, 2,
     o = (-4.0 * d).to(dev).contiguous(); d = d.to(dev).contiguous()
     ztab = ops.depth_table(2.0, 6.0, S, dev)
     comp = torch.empty(R, 3, device=dev)
-    n_wave = 256 * 4
+    nw_inf = (int(sys.argv[2]) if len(sys.argv) > 2 else 8) if hidden <= 128 else 4      # waves per workgroup of the inference kernel (TxCfg::RENDER; argv[2]: a -DTX_NW128 build)
+    n_wave = 256 * 8
     stamps = torch.zeros(n_wave * 8 + 64, dtype=torch.int64, device=dev)
     H = 128 if hidden <= 128 else 256
     in_pad = 16 * ((6 * L + 3 + 15) // 16 + (0 if (6 * L + 3) % 16 else 0))
     for train in (False, True):
+        nw = 4 if train else nw_inf                              # (the ray training kernel: TxCfg::RAY)
+        stamps.zero_()
         plan = st.plan(R * S) if train else None
         for it in range(60):
             rc = dbg.tnerf_debug_renderx3_stamps(C.byref(st.desc), C.c_void_p(x3.packed.data_ptr()), C.c_void_p(o.data_ptr()), C.c_void_p(d.data_ptr()),
@@ -34,8 +38,8 @@ for (L, hidden, depth, skip, R, S) in ((6, 256, 8, 4, 4096, 64), (10, 128, 4, 2,
                                                  C.c_void_p(stamps.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream))
             assert rc == 0
         torch.cuda.synchronize()
-        marks = stamps.cpu().numpy()[n_wave * 8:]
-        s = stamps.cpu().numpy()[: n_wave * 8].reshape(n_wave, 8).astype(np.float64)
+        marks = stamps.cpu().numpy()[256 * nw * 8:]
+        s = stamps.cpu().numpy()[: 256 * nw * 8].reshape(256 * nw, 8).astype(np.float64)
         s = s[s[:, 0] > 0]
         cyc, rt, walk, epi = s[:, 0], s[:, 1], s[:, 2], s[:, 3]
         tiles = R * S / 32 / len(s)
@@ -47,7 +51,7 @@ for (L, hidden, depth, skip, R, S) in ((6, 256, 8, 4, 4096, 64), (10, 128, 4, 2,
         if t_in.max() > 0:
             z = t_in.min(); q = lambda a: " ".join(f"{v / 100:.1f}" for v in np.percentile(a, [0, 5, 50, 95, 100]))
             print(f"   absolute times in us from the first wave's entry (min p5 p50 p95 max): entry {q(t_in - z)} | prologue done {q(t_p - z)} | exit {q(t_out - z)} | lifetime {q(t_out - t_in)}")
-            xcd = (np.arange(len(s)) // 4) % 8
+            xcd = (np.arange(len(s)) // nw) % 8
             print("   per XCD (workgroup % 8) median exit us: " + " ".join(f"{np.median((t_out - z)[xcd == x]) / 100:.1f}" for x in range(8)) + "; median clock GHz: " + " ".join(f"{np.median((cyc / rt)[xcd == x]) * 0.1:.3f}" for x in range(8)))
         nm = int(marks[63])
         if nm > 1:
