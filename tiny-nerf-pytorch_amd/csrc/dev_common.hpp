@@ -63,6 +63,25 @@ __device__ __forceinline__ unsigned short tx_piece_bits(float x, float wsc, int 
     return __builtin_bit_cast(unsigned short, p);
 }
 
+// Running maxima of the scale records -> the records (thread l = layer l, l < n_layers), and the maxima cleared for the next round
+// (the semantics of post / floor: k_x3stats_final in mlpx3.hip, which is this function as a kernel; the finishing kernel's last
+// workgroup calls it directly).  The maxima were written with atomics by other workgroups: read them at the L2, not from a line
+// this CU may have cached when it read the old scale.
+#define TX_META_DONE 6          // record 0's spare word: the finishing kernel's count of workgroups that are through
+__device__ __forceinline__ void tx_stats_final(float* __restrict__ meta, int l, int n_layers, int post, float floor) {
+    if (l >= n_layers) return;
+    float* m = meta + l * TX_META;
+    unsigned* mu = reinterpret_cast<unsigned*>(m);
+    const float mw = __uint_as_float(__hip_atomic_load(mu + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    const float mb = __uint_as_float(__hip_atomic_load(mu + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    const float wsc_old = m[3];
+    const int e = 12 - __builtin_amdgcn_frexp_expf(fmaxf(mw, floor));      // max|W| = f 2^e', f in [0.5, 1): max|W| 2^(12-e') in [2^11, 2^12)
+    const float wsc_new = __uint_as_float((uint32_t)(min(max(e, -126), 127) + 127) << 23);
+    m[0] = 1.0f / (post ? wsc_old : wsc_new);                               // a power of two: exact
+    m[1] = mw; m[2] = mb; m[3] = wsc_new;
+    mu[4] = 0u; mu[5] = 0u;
+}
+
 // ----------------------------------------------------------------------------- Philox4x32-10
 // Counter-based generator for the "speed mode" jitter (t_rand == NULL).  One 128-bit block per
 // (sample index / 4); lane takes word (index & 3).  u in [0,1) with 24 random bits, like

@@ -69,9 +69,10 @@ struct FinishArgs {
     // elements of the fragment stream, the rest fp32 (biases) counted from bias_base
     const int32_t* scatter; int32_t width; void* packed; int64_t bf16_elems; int64_t bias_off_bytes;
     // second re-pack target: the x3 record stream (element i carries piece (i >> 9) mod TX_NP of its parameter times the layer's
-    // scale, record [3] of the TX_META floats at n3.meta_off; biases behind x3_elems).  The caller launches tnx3_launch_stats
-    // (post = 1) behind the finishing kernel.
+    // scale, record [3] of the TX_META floats at n3.meta_off; biases behind x3_elems).  The kernel's last workgroup publishes the
+    // scale records (tx_stats_final, post = 1).
     const int32_t* scatter3; int32_t width3; void* packed3; int64_t x3_elems; NetX3 n3;
+    float scale_floor;      // scatter3: the floor under max|W| when the finishing kernel's last workgroup chooses the next scales (tx_stats_final)
 };
 int tnx3_launch_stats(const NetX3& n, const float* params, const int32_t* table, void* packed3, int post, hipStream_t stream, float scale_floor);
 int tn_launch_finish(const FinishArgs& f, hipStream_t stream);

@@ -1096,15 +1096,7 @@ __global__ __launch_bounds__(256) void k_x3stats_scan(const float* __restrict__ 
 //            than the step (a near-zero initialised layer) can no longer outgrow the fp16 range of its stream in one step (tx_piece_bits
 //            would clamp silently).  Costs nothing: a weight 2^-15 below the scale's maximum still has all its 22 bits.
 __global__ __launch_bounds__(64) void k_x3stats_final(int n_layers, float* __restrict__ meta, int post, float floor) {
-    const int l = threadIdx.x;
-    if (l >= n_layers) return;
-    float* m = meta + l * TX_META;
-    const float mw = __uint_as_float(reinterpret_cast<unsigned*>(m)[4]), mb = __uint_as_float(reinterpret_cast<unsigned*>(m)[5]);
-    const float wsc_old = m[3];
-    const float wsc_new = tx_exp2i(12 - __builtin_amdgcn_frexp_expf(fmaxf(mw, floor)));      // max|W| = f 2^e, f in [0.5, 1): max|W| 2^(12-e) in [2^11, 2^12)
-    m[0] = 1.0f / (post ? wsc_old : wsc_new);                                   // a power of two: exact
-    m[1] = mw; m[2] = mb; m[3] = wsc_new;
-    reinterpret_cast<unsigned*>(m)[4] = 0u; reinterpret_cast<unsigned*>(m)[5] = 0u;
+    tx_stats_final(meta, (int)threadIdx.x, n_layers, post, floor);
 }
 
 int tnx3_launch_stats(const NetX3& n, const float* params, const int32_t* table, void* packed3, int post, hipStream_t stream, float scale_floor) {

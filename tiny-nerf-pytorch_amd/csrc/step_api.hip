@@ -78,13 +78,12 @@ extern "C" int tnerf_train_step_dataset(const tnerf_step_args* a, tnerf_stream_t
         if (a->precision == 0 && a->packed_x3 && a->scatter_x3) {
             NetX3 n; if ((rc = tn_build_netx3(&a->desc, &n))) return rc;
             f.scatter3 = a->scatter_x3; f.width3 = a->scatter_x3_width; f.packed3 = const_cast<void*>(a->packed_x3);
-            f.x3_elems = (int64_t)(n.n_rec + n.n_bw_rec) * n.rec_frags * 512; f.n3 = n;
+            f.x3_elems = (int64_t)(n.n_rec + n.n_bw_rec) * n.rec_frags * 512; f.n3 = n; f.scale_floor = 16.0f * a->lr;
         }
     }
-    if ((rc = tn_launch_finish(f, stream))) return rc;
-    // the finishing kernel re-scattered every weight into the x3 stream: publish the scale it used and refresh the layers' maxima
-    if (f.scatter3) return tnx3_launch_stats(f.n3, a->params, a->pack_x3, f.packed3, 1, stream, 16.0f * a->lr);      // headroom for the next update (k_x3stats_final)
-    return TNERF_OK;
+    // (the finishing kernel re-scatters every weight into the x3 stream; its last workgroup publishes the scale it used and refreshes the
+    //  layers' maxima, with headroom for the next update: tx_stats_final)
+    return tn_launch_finish(f, stream);
 }
 
 // ------------------------------------------------------------------------------------------- hipGraph

@@ -630,8 +630,25 @@ __global__ __launch_bounds__(256) void k_finish(FinishArgs f) {
         float* meta = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(f.packed3) + f.n3.meta_off);
         if (x3_key >= 0) atomicMax(&smax[x3_key], x3_bits);
         __syncthreads();
+        // The LAST parameter workgroup to get here publishes the scale records (what k_x3stats_final did in a launch of its own: 4 us of
+        // a 0.3 ms step): every workgroup has scattered its weights with the old scales and added its maxima by then.  Counter: the
+        // spare word TX_META_DONE of record 0, left at zero for the next step.  Ordering without a fence (an agent-scope release
+        // writes back the XCD's whole L2: measured +110 us per step with one in each of 1850 workgroups): the maxima are RETURNING
+        // atomics — performed at the memory side, where the eight L2s agree, before their results come back — and the count is taken
+        // behind the wait for those results; the last workgroup reads the maxima with atomic loads.
+        unsigned seen = 0u;
         for (int j = threadIdx.x; j < 2 * (f.n3.depth + 1); j += 256)
-            if (smax[j]) atomicMax(reinterpret_cast<unsigned*>(meta) + (j >> 1) * TX_META + 4 + (j & 1), smax[j]);
+            if (smax[j]) seen |= atomicMax(reinterpret_cast<unsigned*>(meta) + (j >> 1) * TX_META + 4 + (j & 1), smax[j]);
+        asm volatile("s_waitcnt vmcnt(0)" :: "v"(seen) : "memory");
+        __shared__ unsigned last_;
+        __syncthreads();
+        unsigned* done = reinterpret_cast<unsigned*>(meta) + TX_META_DONE;
+        if (threadIdx.x == 0) last_ = atomicAdd(done, 1u) == (unsigned)nb - 1u;
+        __syncthreads();
+        if (last_) {
+            tx_stats_final(meta, (int)threadIdx.x, f.n3.depth + 1, 1, f.scale_floor);
+            if (threadIdx.x == 0) *done = 0u;
+        }
     }
 }
 
