@@ -290,6 +290,13 @@ struct RaySource {
 };
 #define TN_PIX_KEY 0x9E3779B97F4A7C15ull      // the pixel draw and the jitter draw use different Philox keys
 
+// The null checks of these wave-uniform pointers sit inside the chain kernels' tile loops.  Left visible, hipcc evaluates each once per
+// kernel and keeps the RESULT as a 64-bit lane mask: two SGPRs per check on top of the pointer, in kernels whose SGPRs already spill
+// into VGPR lanes (the registers the layer walk needs).  Called on the local copies at the top of the loop, the checks are redone there.
+__device__ __forceinline__ void tn_opaque_sources(RaySource& rs, SampleArgs& sa) {
+    asm volatile("" : "+s"(rs.rays_o), "+s"(rs.index), "+s"(rs.c2w), "+s"(rs.step), "+s"(sa.t_rand));
+}
+
 // Dataset mode: read the device step counter ONCE and bind this launch's image / Philox counters (local copies).
 __device__ __forceinline__ int64_t tn_uniform64(int64_t v) {      // a wave-uniform value, moved to SGPRs
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);

@@ -247,6 +247,7 @@ __device__ __forceinline__ float tn16_sin_turns(float y, float quarter) {
 }
 
 __device__ __forceinline__ void tn16_encode(float px, float py, float pz, int Lf, int h, bf16x8 (&enc)[TN16_KE]) {
+    asm volatile("" : "+s"(Lf));       // opaque: otherwise every `slot < 3 Lf` below is hoisted out of the tile loop as a 64-bit lane mask (tx_encode, mlpx3_core.hpp)
     const float quarter = h ? 0.25f : 0.0f;
     tn_static_for<TN16_KE>([&](auto uc) TN_INLINE_LAMBDA {
         constexpr int u = decltype(uc)::value;

@@ -58,21 +58,25 @@ __global__ __launch_bounds__(512, 2) void k_render16(Fwd16Args a) {
         const int64_t ray = g * 8 + wave;
         const bool rvalid = ray < a.R;
         const int64_t rayc = rvalid ? ray : a.R - 1;
-        float ro_[3], rd_[3];
-        tn_fetch_ray(rs, rayc, ro_, rd_);
-        const float ox = ro_[0], oy = ro_[1], oz = ro_[2], dx = rd_[0], dy = rd_[1], dz = rd_[2];
-        const float dn = tn_norm3(dx, dy, dz);
+        float dn;
+        { float ro_[3], rd_[3]; tn_fetch_ray(rs, rayc, ro_, rd_); dn = tn_norm3(rd_[0], rd_[1], rd_[2]); }
         float T_in = 1.0f, cr = 0.f, cg = 0.f, cb = 0.f, cd = 0.f, ca = 0.f;
         // March the ray 32 samples per pass; every second pass (or the last one) the 64 lanes composite a segment:
         // lane l <- sample s0 + l.
         float v[4] = {0.f, 0.f, 0.f, 0.f};
         for (int sb = 0; sb < S; sb += 32) {
+            tn_opaque_sources(rs, sa);
             {
                 const int s = sb + j;
                 const int sc = s < S ? s : S - 1;
                 const float z = tn_depth(sa, rayc, sc);
                 bf16x8 enc[TN16_KE];
-                tn16_encode(tn_point(ox, dx, z), tn_point(oy, dy, z), tn_point(oz, dz, z), Lf, h, enc);
+                // (the ray is fetched again for every tile, behind a barrier the loop-invariant-code motion cannot cross: origin and direction
+                //  are needed here only — six registers less held through the layer walk; as k_renderx3)
+                int64_t rayt = rayc; asm volatile("" : "+s"(rayt));
+                float ro_[3], rd_[3];
+                tn_fetch_ray(rs, rayt, ro_, rd_);
+                tn16_encode(tn_point(ro_[0], rd_[0], z), tn_point(ro_[1], rd_[1], z), tn_point(ro_[2], rd_[2], z), Lf, h, enc);
                 Stash16 st{};
                 int64_t tile = 0;
                 if constexpr (TRAIN) {

@@ -52,10 +52,10 @@ int tn_step32_core(const char* who, const tnerf_mlp_desc* d, const float* packed
                    uint64_t seed, uint64_t offset, int32_t white, float* comp_rgb, float* stash, int64_t Mp,
                    const int32_t* job_table, int64_t n_jobs, float* slabs, hipStream_t stream);
 int tnx3_mlp_dgrad(const char* who, const BwdArgs& b, const tnerf_mlp_desc* d, const void* packed3, hipStream_t stream);
-int tnx3_train_dgrad(const char* who, const BwdArgs& b, const tnerf_mlp_desc* d, const void* packed3, hipStream_t stream);
+int tnx3_train_dgrad(const char* who, const BwdArgs& b, const tnerf_mlp_desc* d, const void* packed3, hipStream_t stream, bool heads_done = false);
 int tnx3_train_fwd(const char* who, const tnerf_mlp_desc* d, const void* packed3, const RaySource& rs, const TnStepRef& sr,
                    const LossArgs& loss, int64_t R, int32_t S, const float* ztab, int32_t randomized, const float* t_rand,
-                   uint64_t seed, uint64_t offset, int32_t white, float* comp, float* stash, int64_t Mp, hipStream_t stream);
+                   uint64_t seed, uint64_t offset, int32_t white, float* comp, float* stash, int64_t Mp, hipStream_t stream, bool* heads_done = nullptr);
 // The finishing kernel of a step: [slab reduction -> grads] [+ loss = inv_denom * sum ray_ws[.,3]] [+ Adam + re-pack of the updated weights]
 struct FinishArgs {
     // reduce (slabs == NULL: grads already hold the gradient, e.g. after the all-reduce)

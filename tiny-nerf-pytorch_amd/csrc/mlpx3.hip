@@ -844,7 +844,8 @@ static int tnx3_waves(int hidden, int kind) {      // kind 0: ray training kerne
 }
 
 // units: rays (fused) or 32-sample tiles (mlp_only) — one per wave and pass
-int tnx3_launch_dgrad(const BwdX3Args& a, bool mlp_only, hipStream_t stream, const char* who) {
+// heads_done: the forward's compositing kernel has already written the head gradients (k_compx3<true, true>, tnx3_launch_fwd)
+int tnx3_launch_dgrad(const BwdX3Args& a, bool mlp_only, hipStream_t stream, const char* who, bool heads_done = false) {
     const int dev = tn_stream_device(stream), n_cu = tn_device_cus(dev);
     const int nw = tnx3_waves(a.n.hidden, mlp_only ? 1 : 0);        // k_mlpx3_bwd | k_dgradx3
     const int64_t units = mlp_only ? (a.b.M + 31) / 32 : a.b.R, groups = (units + nw - 1) / nw;
@@ -854,11 +855,13 @@ int tnx3_launch_dgrad(const BwdX3Args& a, bool mlp_only, hipStream_t stream, con
         const int tw = tnx3_waves(a.n.hidden, 1);
         const dim3 tblock(tw * 64);
         const size_t tlds = TX_LDS_BYTES(a.n, tw, false);
-        CompX3Args c{};
-        c.L = a.b.L; c.stash = a.b.stash; c.Mp = a.b.Mp; c.rs = a.b.rs; c.sa = a.b.sa; c.R = a.b.R; c.white = a.b.white;
-        c.g_comp = a.b.g_comp; c.g_stride = a.b.g_stride;
-        hipLaunchKernelGGL((k_compx3<false, true>), dim3((unsigned)((a.b.R + 3) / 4)), dim3(256), 0, stream, c);
-        TN_HIP_CHECK_LAUNCH(who);
+        if (!heads_done) {
+            CompX3Args c{};
+            c.L = a.b.L; c.stash = a.b.stash; c.Mp = a.b.Mp; c.rs = a.b.rs; c.sa = a.b.sa; c.R = a.b.R; c.white = a.b.white;
+            c.g_comp = a.b.g_comp; c.g_stride = a.b.g_stride;
+            hipLaunchKernelGGL((k_compx3<false, true>), dim3((unsigned)((a.b.R + 3) / 4)), dim3(256), 0, stream, c);
+            TN_HIP_CHECK_LAUNCH(who);
+        }
         const int64_t tiles = a.b.R * ((a.b.sa.S + 31) / 32), tg = (tiles + tw - 1) / tw;
         const dim3 tgrid((unsigned)(tg < n_cu ? tg : n_cu));
 #define TX_TCASE(H_)                                                                                                          \
@@ -880,6 +883,7 @@ int tnx3_launch_dgrad(const BwdX3Args& a, bool mlp_only, hipStream_t stream, con
         TN_HIP_CHECK_LAUNCH(who);                                                                                             \
         return TNERF_OK;                                                                                                      \
     }
+    if (heads_done) { tn_set_error("%s: the forward took the tile route, the backward does not (TNERF_X3_UNITS changed in between?)", who); return TNERF_EINVAL; }
     TX_IF256(TX_CASE(256, k_dgradx3, false)) TX_CASE(128, k_dgradx3, false) TX_IF256(TX_CASE(256, k_mlpx3_bwd, true)) TX_CASE(128, k_mlpx3_bwd, true)
 #undef TX_CASE
     tn_set_error("%s: no x3 kernel for hidden=%d", who, a.n.hidden);
@@ -887,11 +891,11 @@ int tnx3_launch_dgrad(const BwdX3Args& a, bool mlp_only, hipStream_t stream, con
 }
 
 // dgrad of a train step on the x3 kernel (train_api.hip calls this instead of the fp32-MFMA dgrad when packed3 is given).
-int tnx3_train_dgrad(const char* who, const BwdArgs& b, const tnerf_mlp_desc* d, const void* packed3, hipStream_t stream) {
+int tnx3_train_dgrad(const char* who, const BwdArgs& b, const tnerf_mlp_desc* d, const void* packed3, hipStream_t stream, bool heads_done) {
     BwdX3Args a{};
     int rc = tn_build_netx3(d, &a.n); if (rc) return rc;
     a.b = b; a.packed3 = static_cast<const unsigned char*>(packed3);
-    return tnx3_launch_dgrad(a, false, stream, who);
+    return tnx3_launch_dgrad(a, false, stream, who, heads_done);
 }
 
 // Clears a few words.  A kernel, NOT hipMemsetAsync: these launches are captured into the train step's hipGraph, and on ROCm 7.0 a
@@ -901,7 +905,10 @@ __global__ void k_zero_words(unsigned* __restrict__ w, int n) {
     for (int i = threadIdx.x; i < n; i += blockDim.x) w[i] = 0u;
 }
 
-int tnx3_launch_fwd(const FwdX3Args& a, bool train, hipStream_t stream, const char* who, bool mlp_only = false) {
+// heads_done (a train step: the backward follows at once, on the loss gradient this forward forms): where the tile route is taken, ONE
+// compositing kernel does the forward, the loss gradient and the compositing backward (k_compx3<true, true>) and *heads_done is set —
+// tnx3_launch_dgrad then goes straight to the tile kernel.  One launch (~7 us) and one pass over the head outputs less per step.
+int tnx3_launch_fwd(const FwdX3Args& a, bool train, hipStream_t stream, const char* who, bool mlp_only = false, bool* heads_done = nullptr) {
     const int dev = tn_stream_device(stream), n_cu = tn_device_cus(dev);
     if (train) {       // the stash's magnitude bounds start from zero with every training forward (the dgrad kernel adds its own)
         hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, stream, reinterpret_cast<unsigned*>(a.f.stash + TN_BOUND_OFF(a.f.L, a.f.Mp)), TN_BOUND_FLOATS);
@@ -932,7 +939,12 @@ int tnx3_launch_fwd(const FwdX3Args& a, bool train, hipStream_t stream, const ch
         CompX3Args c{};
         c.L = a.f.L; c.stash = a.f.stash; c.Mp = a.f.Mp; c.rs = a.f.rs; c.sa = a.f.sa; c.R = a.f.R; c.white = a.f.white;
         c.comp = a.f.comp; c.depth = a.f.depth; c.acc = a.f.acc; c.loss = a.f.loss;
-        hipLaunchKernelGGL((k_compx3<true, false>), dim3((unsigned)((a.f.R + 3) / 4)), dim3(256), 0, stream, c);
+        if (heads_done && c.loss.ray_ws && c.loss.target) {
+            hipLaunchKernelGGL((k_compx3<true, true>), dim3((unsigned)((a.f.R + 3) / 4)), dim3(256), 0, stream, c);
+            *heads_done = true;
+        } else {
+            hipLaunchKernelGGL((k_compx3<true, false>), dim3((unsigned)((a.f.R + 3) / 4)), dim3(256), 0, stream, c);
+        }
         TN_HIP_CHECK_LAUNCH(who);
         return TNERF_OK;
     }
@@ -1038,13 +1050,13 @@ extern "C" int tnerf_debug_renderx3_stamps(const tnerf_mlp_desc* d, const void* 
 // Training forward into the fp32 stash (tn_step32_core and tnerf_train_fwd_fused_x3 call this instead of the fp32-MFMA forward).
 int tnx3_train_fwd(const char* who, const tnerf_mlp_desc* d, const void* packed3, const RaySource& rs, const TnStepRef& sr,
                    const LossArgs& loss, int64_t R, int32_t S, const float* ztab, int32_t randomized, const float* t_rand,
-                   uint64_t seed, uint64_t offset, int32_t white, float* comp, float* stash, int64_t Mp, hipStream_t stream) {
+                   uint64_t seed, uint64_t offset, int32_t white, float* comp, float* stash, int64_t Mp, hipStream_t stream, bool* heads_done) {
     FwdX3Args a{};
     int rc = x3_args(who, a, d, packed3, rs, R, S, ztab, randomized, t_rand, seed, offset, white); if (rc) return rc;
     if (R < 1 || !comp || !stash || Mp < R * S) { tn_set_error("%s: comp=%p stash=%p Mp=%lld < R*S=%lld", who, (void*)comp, (void*)stash, (long long)Mp, (long long)(R * S)); return TNERF_EINVAL; }
     a.f.comp = comp; a.f.stash = stash; a.f.Mp = Mp; a.f.loss = loss;
     a.f.sa.step = sr.step; a.f.sa.per_step = sr.per_step;
-    return tnx3_launch_fwd(a, true, stream, who);
+    return tnx3_launch_fwd(a, true, stream, who, false, heads_done);
 }
 
 extern "C" int tnerf_train_fwd_fused_x3(const tnerf_mlp_desc* d, const void* packed3, const float* rays_o, const float* rays_d,

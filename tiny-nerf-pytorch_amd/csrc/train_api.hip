@@ -56,7 +56,8 @@ extern "C" int tnerf_mlp_bwd_x3(const tnerf_mlp_desc* d, const void* packed_x3, 
 static int train_bwd_impl(const char* who, const tnerf_mlp_desc* d, const float* packed, const void* packed3, const RaySource& rs, const TnStepRef& sr,
                           int64_t R, int32_t S, const float* ztab, int32_t randomized, const float* t_rand, uint64_t seed,
                           uint64_t offset, int32_t white, const float* g_comp, int32_t g_stride, float* stash, int64_t Mp,
-                          const int32_t* job_table, int64_t n_jobs, float* slabs, const int32_t* reduce_table, float* grads, hipStream_t s) {
+                          const int32_t* job_table, int64_t n_jobs, float* slabs, const int32_t* reduce_table, float* grads, hipStream_t s,
+                          bool heads_done = false) {
     FwdArgs f{};
     int rc = tn_fused_args(who, f, d, packed, rs, R, S, ztab, randomized, t_rand, seed, offset, white); if (rc) return rc;
     if (R < 1 || !g_comp) { tn_set_error("%s: R=%lld g_comp=%p", who, (long long)R, (const void*)g_comp); return TNERF_EINVAL; }
@@ -67,7 +68,7 @@ static int train_bwd_impl(const char* who, const tnerf_mlp_desc* d, const float*
     a.sa.step = sr.step; a.sa.per_step = sr.per_step;
     a.white = white; a.g_comp = g_comp; a.g_stride = g_stride;
     const bool x3 = packed3 && !(d->flags & TNERF_FLAG_FP32_MFMA);
-    if (x3) rc = tnx3_train_dgrad(who, a, d, packed3, s);
+    if (x3) rc = tnx3_train_dgrad(who, a, d, packed3, s, heads_done);
     else    rc = tn_launch_train_bwd(a, s);
     if (rc) return rc;
     if ((rc = tn_launch_wgrad(stash, a.L.stash_rows, R * S, job_table, n_jobs, slabs, sr.step, s, x3 ? 1 : 0, stash + TN_BOUND_OFF(a.L, Mp)))) return rc;
@@ -145,13 +146,14 @@ int tn_step32_core(const char* who, const tnerf_mlp_desc* d, const float* packed
                    uint64_t seed, uint64_t offset, int32_t white, float* comp_rgb, float* stash, int64_t Mp,
                    const int32_t* job_table, int64_t n_jobs, float* slabs, hipStream_t stream) {
     int rc;
+    bool heads_done = false;      // x3 tile route: the forward's compositing kernel also ran the compositing backward (tnx3_launch_fwd)
     if (packed3 && !(d->flags & TNERF_FLAG_FP32_MFMA))
-        rc = tnx3_train_fwd(who, d, packed3, rs, sr, loss, R, S, ztab, randomized, t_rand, seed, offset, white, comp_rgb, stash, Mp, stream);
+        rc = tnx3_train_fwd(who, d, packed3, rs, sr, loss, R, S, ztab, randomized, t_rand, seed, offset, white, comp_rgb, stash, Mp, stream, &heads_done);
     else
         rc = tn_train_fwd_impl(who, d, packed, rs, sr, loss, R, S, ztab, randomized, t_rand, seed, offset, white, comp_rgb, stash, Mp, stream);
     if (rc) return rc;
     return train_bwd_impl(who, d, packed, packed3, rs, sr, R, S, ztab, randomized, t_rand, seed, offset, white, loss.ray_ws, 4, stash, Mp,
-                          job_table, n_jobs, slabs, nullptr, nullptr, stream);
+                          job_table, n_jobs, slabs, nullptr, nullptr, stream, heads_done);
 }
 
 static int train_step_impl(const char* who, const tnerf_mlp_desc* d, const float* packed, const RaySource& rs, const float* target,
