@@ -144,6 +144,21 @@ def test_two_forwards_of_equal_size_then_one_backward(mods, dev, tag):
             p.grad = None
         l2.backward(retain_graph=True)
         assert all(torch.equal(a, p.grad) for a, p in zip(g1, pl2)), kind
+        # ... and a repeat with a 4096 times SMALLER incoming gradient equals a first backward with that gradient bit for bit: the x3 dgrad
+        # kernel's running maxima of the first pass (the weight-gradient kernel's scales) do not leak into it
+        for p in pl2:
+            p.grad = None
+        (l2 * 2.0 ** -12).backward(retain_graph=True)
+        m4 = make_model(mods, cfg, params, dev)
+        pl4 = m4._param_list()
+        if kind == "fused":
+            out4 = mods["ops"].render_rays_fused(m4._ensure_packed(), pl4, ro_all[i1].to(dev), rd_all[i1].to(dev), 2.0, 6.0, S, True, t_rand=u[:128].to(dev))[0]
+            l4 = ((out4 - tgt[i1].to(dev)) ** 2).mean()
+        else:
+            r_, s_ = m4(xa.to(dev))
+            l4 = (r_ * wa.to(dev)).sum() + (s_ * sa.to(dev)).sum()
+        (l4 * 2.0 ** -12).backward()
+        assert all(torch.equal(q.grad, p.grad) for q, p in zip(pl4, pl2)), kind
         with torch.no_grad():
             pl2[2].mul_(1.0)
         with pytest.raises(RuntimeError, match="modified by an inplace"):

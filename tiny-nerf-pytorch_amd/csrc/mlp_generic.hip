@@ -10,10 +10,12 @@
 //   backward : dZ_head, dH = dZ_rgb W_rgb + dZ_sigma W_sigma, then per layer dW_l = dZ_l^T A_l, db_l = dZ_l^T 1,
 //              dA_l = dZ_l W_l[:, :K], dX += dZ_l W_l[:, K:], dZ_{l-1} = dA_l * (H_{l-1} > 0)
 // The hipBLAS handle is the CALLER's (torch.cuda.current_blas_handle() in the Python binding): the library creates none, so it
-// still allocates no device memory.  libhipblas.so is dlopen'ed on first use (function table written once).
+// still allocates no device memory.  The hipBLAS entry points are bound on first use — to the copy already in the process (blas()).
 #include <hip/hip_runtime.h>
 #include <hipblas/hipblas.h>
 #include <dlfcn.h>
+#include <link.h>
+#include <string.h>
 #include <mutex>
 #include "../../include/tnerf.h"
 #include "tnerf_internal.h"
@@ -35,8 +37,23 @@ Blas* blas() {
     static Blas b{};
     static std::once_flag once;
     std::call_once(once, [] {
-        const char* names[] = {"libhipblas.so", "libhipblas.so.3", "/opt/rocm/lib/libhipblas.so"};
-        for (const char* n : names) { b.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (b.h) break; }
+        // The handle is the CALLER's: the functions must come from the copy of hipBLAS that created it.  A torch wheel ships its own
+        // libhipblas under torch/lib (its SONAME need not be the system's), so first look for a copy that is ALREADY mapped into the
+        // process (dl_iterate_phdr: any object whose file name contains "libhipblas") and bind to that one (RTLD_NOLOAD: no second copy
+        // is ever loaded beside it); only a process that has none yet loads one by name.
+        struct Found { char path[1024]; } found{};
+        dl_iterate_phdr([](struct dl_phdr_info* info, size_t, void* out) -> int {
+            if (info->dlpi_name && strstr(info->dlpi_name, "libhipblas") && !strstr(info->dlpi_name, "libhipblaslt")) {
+                strncpy(static_cast<Found*>(out)->path, info->dlpi_name, sizeof(Found::path) - 1);
+                return 1;
+            }
+            return 0;
+        }, &found);
+        if (found.path[0]) b.h = dlopen(found.path, RTLD_NOW | RTLD_NOLOAD);
+        if (!b.h) {
+            const char* names[] = {"libhipblas.so", "libhipblas.so.3", "/opt/rocm/lib/libhipblas.so"};
+            for (const char* n : names) { b.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (b.h) break; }
+        }
         if (b.h) {
             b.sgemm = (fn_sgemm)dlsym(b.h, "hipblasSgemm");
             b.set_stream = (fn_set_stream)dlsym(b.h, "hipblasSetStream");

@@ -579,6 +579,16 @@ class _Bf16TrainPlan:
 
 
 # ---------------------------------------------------------------------------------- MLP op
+def _again(ctx, lease, x3: bool) -> None:
+    """A SECOND backward over the same forward (retain_graph=True).  The x3 dgrad kernel keeps running maxima of the activation
+    gradients (the weight-gradient kernel's scales) in the stash's bound words TNB_DZ(0) .. TNB_DZH (csrc/tnerf_internal.h: words 17 ..
+    33 of the last 64 floats); only a forward clears them, so a repeated backward would scale by the maxima of BOTH gradients and
+    not be bit-identical to a first one.  Cleared here, on the (rare) repeat."""
+    if getattr(ctx, "n_backward", 0) and x3:
+        lease.buf[-47:-30].zero_()
+    ctx.n_backward = getattr(ctx, "n_backward", 0) + 1
+
+
 def _check_versions(ctx, who: str) -> None:
     """The backward reads the packed weights of NOW against the activations of the forward: refuse, like autograd does for saved
     tensors, when a parameter was modified in place in between (an optimizer step before a second backward(retain_graph=True))."""
@@ -620,6 +630,7 @@ class _MlpFn(torch.autograd.Function):
         if plan is None:
             raise RuntimeError("TinyNeRF (HIP): backward through a forward that ran without grad enabled")
         _check_versions(ctx, "TinyNeRF (HIP)")
+        _again(ctx, lease, ctx.x3 is not None)
         dev = st.device
         g_rgb = torch.zeros(M, 3, dtype=torch.float32, device=dev) if g_rgb is None else _f32c(g_rgb)
         g_sigma = torch.zeros(M, 1, dtype=torch.float32, device=dev) if g_sigma is None else _f32c(g_sigma)
@@ -751,6 +762,7 @@ class _FusedRaysFn(torch.autograd.Function):
         g_comp = _f32c(g_comp)
         lease = ctx.lease
         _check_versions(ctx, "fused render (HIP)")
+        _again(ctx, lease, ctx.x3 is not None)
         _l.call("tnerf_train_bwd_fused", C.byref(st.desc), st.packed.data_ptr(), rays_o.data_ptr(), rays_d.data_ptr(), R, S,
                 ztab.data_ptr(), rnd, t_rand.data_ptr() if has_tr else None, seed, off, white, g_comp.data_ptr(),
                 lease.buf.data_ptr(), plan.Mp, plan.jobs.data_ptr(), plan.n_jobs, plan.slabs.data_ptr(), plan.reduce.data_ptr(),

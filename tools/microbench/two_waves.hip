@@ -44,6 +44,10 @@ __global__ __launch_bounds__(NT, 1) void k(int iters, unsigned long long* out, f
                 if (KIND == 1) asm volatile("v_mul_f32 %0, %1, %0" : "+v"(r) : "v"(c0));
                 if (KIND == 3) asm volatile("v_fma_mixlo_f16 %0, %1, %2, 0" : "+v"(w) : "v"(r), "v"(c0));
                 if (KIND == 9) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(r) : "a"(ag));
+                if (KIND == 30) asm volatile("s_add_i32 s20, s20, 0x4000" ::: "s20", "scc");
+                if (KIND == 31) asm volatile("s_nop 0");
+                if (KIND == 32) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                if (KIND == 33) asm volatile("s_add_i32 s20, s20, 0x4000\n\ts_cmp_lg_u32 s20, 0x1c000\n\ts_cselect_b32 s20, s20, 0" ::: "s20", "scc");     // a ring pointer's wrap: 3 instructions
                 if (KIND == 11) { u32x4 t; asm volatile("ds_read_b128 %0, %1" : "=v"(t) : "v"(ldsa)); asm volatile("" :: "v"(t)); }
                 if (KIND == 20) {              // the real mixture of a training pair: acc read, fma, alignbit, med3, mix, cvt_pk ...
                     if (i % 6 == 0) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(r) : "a"(ag));
@@ -98,6 +102,13 @@ int main(int argc, char** argv) {
     both<9, 4>(iters, out, sink, "v_accvgpr_read_b32");
     both<9, 6>(iters, out, sink, "v_accvgpr_read_b32");
     both<11, 1>(iters, out, sink, "ds_read_b128");
+    both<30, 2>(iters, out, sink, "s_add_i32");
+    both<30, 4>(iters, out, sink, "s_add_i32");
+    both<30, 8>(iters, out, sink, "s_add_i32");
+    both<31, 4>(iters, out, sink, "s_nop 0");
+    both<31, 8>(iters, out, sink, "s_nop 0");
+    both<32, 4>(iters, out, sink, "s_waitcnt (satisfied)");
+    both<33, 2>(iters, out, sink, "ring wrap (3 SALU) x N");
     both<20, 6>(iters, out, sink, "training-pair mixture");
     both<20, 12>(iters, out, sink, "training-pair mixture");
     return 0;
