@@ -72,7 +72,9 @@ struct FinishArgs {
     // scale, record [3] of the TX_META floats at n3.meta_off; biases behind x3_elems).  The kernel's last workgroup publishes the
     // scale records (tx_stats_final, post = 1).
     const int32_t* scatter3; int32_t width3; void* packed3; int64_t x3_elems; NetX3 n3;
-    float scale_floor;      // scatter3: the floor under max|W| when the finishing kernel's last workgroup chooses the next scales (tx_stats_final)
+    float scale_floor;      // scatter3: the floor under max|W| when the next scales are chosen (tx_stats_final)
+    int32_t fold_stats;     // scatter3: the finishing kernel's last workgroup publishes the scale records (small networks; otherwise the caller launches tnx3_launch_stats(post = 1) behind it)
 };
+#define TN_FOLD_STATS_BLOCKS 512
 int tnx3_launch_stats(const NetX3& n, const float* params, const int32_t* table, void* packed3, int post, hipStream_t stream, float scale_floor);
 int tn_launch_finish(const FinishArgs& f, hipStream_t stream);

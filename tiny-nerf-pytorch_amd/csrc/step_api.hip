@@ -81,9 +81,13 @@ extern "C" int tnerf_train_step_dataset(const tnerf_step_args* a, tnerf_stream_t
             f.x3_elems = (int64_t)(n.n_rec + n.n_bw_rec) * n.rec_frags * 512; f.n3 = n; f.scale_floor = 16.0f * a->lr;
         }
     }
-    // (the finishing kernel re-scatters every weight into the x3 stream; its last workgroup publishes the scale it used and refreshes the
-    //  layers' maxima, with headroom for the next update: tx_stats_final)
-    return tn_launch_finish(f, stream);
+    // The finishing kernel re-scatters every weight into the x3 stream; then the scale it used is published and the layers' maxima are
+    // refreshed, with headroom for the next update (tx_stats_final) — by the kernel's last workgroup for small networks, in a launch of
+    // its own for large ones (k_finish).
+    if (f.scatter3) f.fold_stats = (n_params + 255) / 256 <= TN_FOLD_STATS_BLOCKS;
+    if ((rc = tn_launch_finish(f, stream))) return rc;
+    if (f.scatter3 && !f.fold_stats) return tnx3_launch_stats(f.n3, a->params, a->pack_x3, f.packed3, 1, stream, f.scale_floor);
+    return TNERF_OK;
 }
 
 // ------------------------------------------------------------------------------------------- hipGraph

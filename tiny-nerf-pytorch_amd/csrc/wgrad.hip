@@ -630,12 +630,20 @@ __global__ __launch_bounds__(256) void k_finish(FinishArgs f) {
         float* meta = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(f.packed3) + f.n3.meta_off);
         if (x3_key >= 0) atomicMax(&smax[x3_key], x3_bits);
         __syncthreads();
-        // The LAST parameter workgroup to get here publishes the scale records (what k_x3stats_final did in a launch of its own: 4 us of
-        // a 0.3 ms step): every workgroup has scattered its weights with the old scales and added its maxima by then.  Counter: the
-        // spare word TX_META_DONE of record 0, left at zero for the next step.  Ordering without a fence (an agent-scope release
-        // writes back the XCD's whole L2: measured +110 us per step with one in each of 1850 workgroups): the maxima are RETURNING
-        // atomics — performed at the memory side, where the eight L2s agree, before their results come back — and the count is taken
-        // behind the wait for those results; the last workgroup reads the maxima with atomic loads.
+        // Small networks (f.fold_stats: at most TN_FOLD_STATS_BLOCKS workgroups): the LAST parameter workgroup to get here publishes the
+        // scale records itself — what k_x3stats_final otherwise does in a launch of its own, 4 us of a 0.3 ms step; every workgroup has
+        // scattered its weights with the old scales and added its maxima by then.  Counter: the spare word TX_META_DONE of record 0, left
+        // at zero for the next step.  Ordering without a fence (an agent-scope release writes back the XCD's whole L2: measured +110 us
+        // per step with one in each of 1850 workgroups): the maxima are RETURNING atomics — performed at the memory side, where the eight
+        // L2s agree, before their results come back — and the count is taken behind the wait for those results; the last workgroup
+        // reads the maxima with atomic loads.  Large networks keep the separate launch: 1850 returning atomics on ONE counter word
+        // serialise, and every workgroup waits out two round trips to memory before it can retire (measured: +17 us on the 8x256
+        // finishing kernel against the 4 us launch it saves).
+        if (!f.fold_stats) {
+            for (int j = threadIdx.x; j < 2 * (f.n3.depth + 1); j += 256)
+                if (smax[j]) atomicMax(reinterpret_cast<unsigned*>(meta) + (j >> 1) * TX_META + 4 + (j & 1), smax[j]);
+            return;
+        }
         unsigned seen = 0u;
         for (int j = threadIdx.x; j < 2 * (f.n3.depth + 1); j += 256)
             if (smax[j]) seen |= atomicMax(reinterpret_cast<unsigned*>(meta) + (j >> 1) * TX_META + 4 + (j & 1), smax[j]);
