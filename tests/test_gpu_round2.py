@@ -724,12 +724,14 @@ def test_dataset_trainer_from_a_near_zero_layer(mods, dev):
 
 
 # ------------------------------------------------------------------ sub-ray work units: 32-sample tiles instead of rays
-@pytest.mark.parametrize("tag,R,S", [("8x256", 300, 64), ("8x256", 77, 100), ("4x128", 130, 256), ("8x256", 5, 33)])
+@pytest.mark.parametrize("tag,R,S", [("8x256", 300, 64), ("8x256", 77, 100), ("4x128", 130, 256), ("8x256", 5, 33), ("4x128", 2048, 64)])
 def test_tile_units_equal_ray_units_bitwise(mods, dev, tag, R, S, monkeypatch):
     """Fewer rays than the chip has waves: the x3 training kernels take 32-sample tiles as their unit and composite the rays in a
     kernel of their own (mlpx3.hip, k_tilex3_fwd / k_compx3 / k_tilex3_bwd).  C = C1 + T1 C2 over the tiles of a ray is formed with
     the same segment scans as in the ray kernels, so the two routes must agree BITWISE — colours, loss, every gradient — for S = 64
-    (two tiles), 100 (ragged last tile), 256 (four segments) and 33; and the tile route must sit on the oracle like the ray route."""
+    (two tiles), 100 (ragged last tile), 256 (four segments) and 33; and the tile route must sit on the oracle like the ray route.
+    128-wide networks ALWAYS train through the tile kernels, which run two waves per SIMD there (8-wave workgroups, TxCfg) while the ray
+    kernels keep four: the last case is the reference's default batch (2048 rays x 64: every CU, every wave) through both."""
     ops, lib, T = mods["ops"], mods["lib"], mods["trainer"]
     cfg, params = golden_params(tag)
     g = torch.Generator().manual_seed(21)
