@@ -2,8 +2,9 @@
 // with the MLP's fp32 products formed from three partial products on the fp16 matrix pipe (mlpx3_core.hpp).  Same inputs, outputs, sample bins,
 // encoder arithmetic (fp32-accurate sin/cos), compositing and — when training — the same block-major fp32 stash (activations,
 // ReLU sign bits, head outputs, loss gradient) as the fp32-MFMA kernels of mlp_fwd.hip, so the dgrad / weight-gradient kernels
-// and every caller are unchanged.  One persistent workgroup per CU — 4 waves (one per SIMD, 512-register budget: TxCfg);
-// a wave owns one ray at a time and marches it 32 samples per pass over the record stream.  A layer is two half-passes whose
+// and every caller are unchanged.  One persistent workgroup per CU — 4 waves (one per SIMD, 512-register budget) at 256 wide, 8 waves (two
+// per SIMD, 256 registers each) in the 128-wide tile / inference kernels (TxCfg, mlpx3_core.hpp);
+// a wave owns one ray (or one 32-sample tile) at a time and marches it 32 samples per pass over the record stream.  A layer is two half-passes whose
 // epilogues ride in each other's MFMA shadows (mlpx3_core.hpp).
 #include "mlpx3_core.hpp"
 #include "mlp_args.hpp"

@@ -23,11 +23,11 @@
 //   * k-step-major order in two HALF-PASSES per layer (output tiles 0..NT/2-1 = half A, then half B), all of a half's
 //     accumulators live; the pieces of the input activation X[s] are dead once half B has passed k-step s, so the layer's
 //     output pieces are written back into the same registers.  8x256: 128 (pieces) + 256 (two halves x main / correction)
-//     registers — one wave per SIMD, four waves per workgroup.
+//     registers — one wave per SIMD, four waves per workgroup; 4x128: 64 + 128 — two waves per SIMD, eight per workgroup (TxCfg).
 //   * the epilogue of one half (descale, bias, ReLU, sign bits, stash store, L1 norm, split) is cut into per-pair MICRO-STEPS
 //     issued in the shadows of the other half's MFMAs (tx_pass's hook); the order is pinned with sched_barrier.
 //   * the weight stream: per (half, k-step) record NT/2 x 2 KB through an LDS ring of 16 KB stages (LDS-DMA, counted vmcnt,
-//     one raw barrier per stage), shared by the four waves.
+//     one raw barrier per two stages), shared by the workgroup's waves.
 #pragma once
 #include "mlp16_core.hpp"
 
