@@ -149,8 +149,14 @@ def load():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `python __graft_entry__.py build` "
                 "(tiny-nerf-pytorch_amd/csrc/build.sh).  The HIP path has no CPU fallback.")
-        lib = C.CDLL(LIB_PATH)
         host_only = bool(os.environ.get("TNERF_HOST_ONLY"))      # sanitizer build of csrc/host_plan.cpp alone (tests/test_host_sanitizers.py)
+        if not host_only:
+            # torch FIRST: a ROCm torch wheel ships its own libamdhip64 under torch/lib.  If this library is loaded before torch is
+            # imported, it pulls in the system's copy, torch then brings its own, and the process holds two HIP runtimes — the second one
+            # to initialise finds "no ROCm-capable device" (seen when build() and smoke() ran in one process).  With torch's copy already
+            # mapped, this library's dependency resolves to it.
+            import torch  # noqa: F401
+        lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             try:
                 fn = getattr(lib, name)      # AttributeError if the .so does not export it
