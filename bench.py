@@ -490,6 +490,13 @@ def run(args):
         r = psnr_block(model)
         if r:
             out["psnr"] = r[0]; img_f32 = r[1]
+        # context for `value`: the SAME protocol (W warm-up + K timed steps) on the network as it is now, after the PSNR block's training.
+        # `value` above times the first steps of a freshly initialised network; as the network learns, most activations and nearly all
+        # activation gradients become exact zeros, the matrix pipe draws less power and the chip clocks higher ("Where it stands")
+        dt_tr = timed(args.warmup, args.steps)
+        out["trained_network_step"] = {"ms_per_step": dt_tr / args.steps * 1e3, "value": R_global * args.steps / dt_tr, "unit": "rays/s",
+                                       "after_steps": state["step"] - args.warmup - args.steps,
+                                       "note": "same trainer, same W + K protocol as `value`, on the trained weights: the step's time depends on the data"}
 
     # ---- the same step on the plain fp32-MFMA kernels (TNERF_FLAG_FP32_MFMA): what the x3 pipe buys, driver-timed like `value`
     if not args.no_extra and FP32_PATH_PEAK == PEAK_X3_TFLOPS:
