@@ -539,7 +539,14 @@ __global__ __launch_bounds__(256) void k_finish(FinishArgs f) {
         if (threadIdx.x == 0) f.loss_out[0] = ((part[0] + part[1]) + (part[2] + part[3])) * f.inv_denom;
         return;
     }
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    // Which 256 parameters this workgroup takes: NOT blockIdx.x.  Workgroups go to the eight XCDs round-robin (blockIdx.x % 8), each XCD
+    // has its own L2, and the re-pack below scatters 2- and 4-byte values into MFMA-fragment order, where one 128-byte line holds the
+    // same k range of 8 consecutive weight ROWS — 8 consecutive workgroups for a 256-wide layer, i.e. one partial line in each of the 8
+    // L2s, written back as eight masked partial lines.  With the workgroups of one XCD taking a CONTIGUOUS range of parameter blocks the
+    // lines are completed inside one L2.  (A bijection of the block index: every parameter is still handled exactly once.)
+    const int q_ = nb / 8, r_ = nb % 8, x_ = (int)blockIdx.x % 8, j_ = (int)blockIdx.x / 8;
+    const int blk = x_ * q_ + (x_ < r_ ? x_ : r_) + j_;
+    const int64_t i = (int64_t)blk * 256 + threadIdx.x;
     __shared__ float bc[2];
     if (ADAM) {
         if (threadIdx.x == 0) {
